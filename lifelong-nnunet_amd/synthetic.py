@@ -1,0 +1,61 @@
+"""Deterministic synthetic patches shaped like the reference's data dict.
+
+The reference's iteration consumes ``{'data': (B,C,D,H,W) f32, 'target': [ (B,1,D/2^i,H/2^i,W/2^i) ]_i,
+'keys'}`` (multihead/nnUNetTrainerMultiHead.py:606-608).  There is no dataset in this build, so the
+patches are synthetic: z-scored Gaussian intensities and nested smooth blob labels {0,1,2}, generated
+on the CPU from a seed so the oracle and the GPU path see bit-identical inputs.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _smooth_field(shape, gen, passes=3, k=5):
+    f = torch.randn((1, 1) + tuple(shape), generator=gen)
+    for _ in range(passes):
+        f = F.avg_pool3d(F.pad(f, (k // 2,) * 6, mode='replicate'), k, 1)
+    f = f - f.mean()
+    return f / (f.std() + 1e-8)
+
+
+def make_patch_batch(batch, patch, num_pool, in_channels=1, num_labels=3, seed=12345, blob_scale=1.0):
+    """Returns ``(data, targets)``: data (B,C,D,H,W) f32, targets list of ``num_pool`` tensors
+    (B,1,D/2^i,...) f32 holding integer labels (nearest-neighbour subsampled, positions 0,2,4,...)."""
+    gen = torch.Generator().manual_seed(int(seed))
+    data = torch.randn((batch, in_channels) + tuple(patch), generator=gen)
+    full = torch.zeros((batch, 1) + tuple(patch))
+    for b in range(batch):
+        f = _smooth_field(patch, gen, k=max(3, int(5 * blob_scale) | 1))[0, 0]
+        lab = torch.zeros_like(f)
+        # nested blobs: class 1 where the field is high, class 2 in its core
+        qs = torch.quantile(f.flatten()[:: max(1, f.numel() // 65536)], torch.tensor([0.70, 0.90]))
+        lab[f > qs[0]] = 1
+        if num_labels > 2:
+            lab[f > qs[1]] = 2
+        full[b, 0] = lab
+        # make the image weakly informative about the label so training has signal
+        data[b] += 0.75 * lab[None]
+    targets = [full[:, :, ::2 ** i, ::2 ** i, ::2 ** i].contiguous() for i in range(num_pool)]
+    return data, targets
+
+
+class SyntheticPatchGenerator:
+    """Infinite iterator of data dicts; ``period`` distinct batches are cycled deterministically
+    (the reference pairs batch ``i mod 250`` with stored teacher logits, lwf/nnUNetTrainerLWF.py:349)."""
+
+    def __init__(self, batch, patch, num_pool, in_channels=1, num_labels=3, seed=12345, period=4,
+                 blob_scale=1.0, key_prefix="case"):
+        self.batches = [make_patch_batch(batch, patch, num_pool, in_channels, num_labels, seed + 1000 * i,
+                                         blob_scale) for i in range(period)]
+        self.keys = [[f"{key_prefix}_{i:03d}_{b}" for b in range(batch)] for i in range(period)]
+        self.i = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        d, t = self.batches[self.i % len(self.batches)]
+        k = self.keys[self.i % len(self.batches)]
+        self.i += 1
+        return {'data': d, 'target': t, 'keys': k}
