@@ -1,0 +1,182 @@
+/*
+ * lnn_hip.h -- C-ABI of liblnn_hip.so: the MI355X (gfx950) kernels behind the hot path of
+ * MECLabTUDA/Lifelong-nnUNet (3-D U-Net training step + EWC / LwF regularisers).
+ *
+ * The reference is pure Python and has no FFI; every entry point below replaces a PyTorch op that the
+ * reference reaches on its hot path (file:line relative to the reference repository root).  The
+ * reference-side binding a maintainer would add is a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative lnn_status; never throws; the message of the
+ *     last failure on the calling thread is returned by lnn_last_error().
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator in the build's
+ *     host code).  The library never allocates, frees or retains device memory; work is enqueued
+ *     asynchronously on the passed hipStream_t (void* here so the header needs no HIP include).
+ *   - activations are fp16 ("h"), channels-last NDHWC: element (n,z,y,x,c) at
+ *     ((((n*D+z)*H+y)*W+x)*ld + c); `ld` (channel stride, elements) lets a tensor live inside a wider
+ *     concat buffer -- this is how torch.cat((x, skip), 1) (generic_ViT_UNet.py:263) is eliminated.
+ *     All channel counts and ld must be multiples of 8 (16-byte vectors), except the C==1 image input.
+ *   - parameters / gradients / optimiser state are fp32 in the reference's own tensor layouts
+ *     (Conv3d weight (K,C,3,3,3), ConvTranspose3d weight (Cin,Cout,2,2,2)), so state_dict keys and
+ *     Fisher / theta* dictionaries interoperate (nnUNetTrainerEWC.py:298-304).
+ */
+#ifndef LNN_HIP_H
+#define LNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lnn_stream_t; /* hipStream_t */
+
+enum lnn_status {
+    LNN_OK = 0,
+    LNN_ERR_BAD_ARG = -1,     /* null pointer, misaligned pointer, unsupported channel count ... */
+    LNN_ERR_WORKSPACE = -2,   /* workspace too small */
+    LNN_ERR_LAUNCH = -3,      /* hipGetLastError() after launch */
+    LNN_ERR_UNSUPPORTED = -4
+};
+
+const char* lnn_last_error(void);
+int lnn_version(void);
+/* number of CUs / clock (kHz) / device name of the current device; for roofline reporting */
+int lnn_device_info(int* cu_count, int* clock_khz, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight packing (fp32 parameter tensors -> fp16 MFMA operand panels).  No reference counterpart:
+ * cuDNN does this internally for nn.Conv3d / nn.ConvTranspose3d under autocast
+ * (nnUNetTrainerMultiHead.py:619-621).
+ *   dst[t][m][kc] (m padded to 32, kc padded to 16, zero filled) = src[m*stride_m + kc*stride_kc + t*stride_t]
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_pack_weights(lnn_stream_t s, const float* src, void* dst_h, int ntaps, int M, int KC,
+                     long stride_m, long stride_kc, long stride_t);
+size_t lnn_packed_weight_elems(int ntaps, int M, int KC);
+
+/* ------------------------------------------------------------------------------------------------
+ * nn.Conv3d 3x3x3, padding 1, stride 1|2, bias  (module tree test_MultiHead_Module.py:346-415;
+ * conv_op / strided-conv pooling chosen at nnViTUNetTrainer.py:101-104,122).
+ *   fwd  : y[n,p,k] = b[k] + sum_{c,d} w[k,c,d] x[n, s*p+d-1, c]
+ *   dgrad: dx = conv_transpose(dy, w)           (beta = 1 accumulates into dx: skip connections)
+ *   wgrad: dwp[t][k][c] += sum_{n,p} dy[n,p,k] x[n,s*p+d-1,c]   (fp32 packed panel, see lnn_unpack_wgrad)
+ * x: (N,Di,Hi,Wi,C) ld_x ; y/dy: (N,Do,Ho,Wo,K) ld_y with Do = (Di-1)/s+1.
+ * wp_fwd  = lnn_pack_weights(w, 27, K, C, C*27, 27, 1);  wp_dgrad = lnn_pack_weights(w, 27, C, K, 27, C*27, 1)
+ * C == 1 (image input) is handled by a dedicated path in fwd / wgrad (x is then (N,Di,Hi,Wi) fp16).
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_conv3d_fwd(lnn_stream_t s, const void* x_h, int ld_x, const void* wp_fwd_h, const float* bias,
+                   void* y_h, int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride);
+int lnn_conv3d_dgrad(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp_dgrad_h, void* dx_h, int ld_dx,
+                     int N, int Di, int Hi, int Wi, int C, int K, int stride, int accumulate);
+int lnn_conv3d_wgrad(lnn_stream_t s, const void* x_h, int ld_x, const void* dy_h, int ld_dy, float* dwp,
+                     int N, int Di, int Hi, int Wi, int C, int K, int stride);
+
+/* ------------------------------------------------------------------------------------------------
+ * nn.ConvTranspose3d kernel 2, stride 2, no bias (`tu`, convolutional_upsampling=True
+ * nnViTUNetTrainer.py:122):  y[n,2p+d,k] = sum_c x[n,p,c] W[c,k,d].
+ * x: (N,D,H,W,C) ; y: (N,2D,2H,2W,K).
+ * wp_fwd = lnn_pack_weights(W, 8, K, C, 8, K*8, 1); wp_dgrad = lnn_pack_weights(W, 8, C, K, K*8, 8, 1)
+ * wgrad panel dwp[d][c][k] (fp32).
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_convT3d_k2s2_fwd(lnn_stream_t s, const void* x_h, int ld_x, const void* wp_fwd_h, void* y_h, int ld_y,
+                         int N, int D, int H, int W, int C, int K);
+int lnn_convT3d_k2s2_dgrad(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp_dgrad_h, void* dx_h,
+                           int ld_dx, int N, int D, int H, int W, int C, int K, int accumulate);
+int lnn_convT3d_k2s2_wgrad(lnn_stream_t s, const void* x_h, int ld_x, const void* dy_h, int ld_dy, float* dwp,
+                           int N, int D, int H, int W, int C, int K);
+
+/* dst[m*stride_m + kc*stride_kc + t*stride_t] (+)= scale * dwp[t][m][kc]  (panel rows padded to 32/32) */
+int lnn_unpack_wgrad(lnn_stream_t s, const float* dwp, float* dst, int ntaps, int M, int KC,
+                     long stride_m, long stride_kc, long stride_t, float scale, int accumulate);
+size_t lnn_wgrad_panel_elems(int ntaps, int M, int KC);
+
+/* ------------------------------------------------------------------------------------------------
+ * nn.InstanceNorm3d(eps, affine=True) + nn.LeakyReLU(slope)  (nnViTUNetTrainer.py:111-114; order
+ * conv -> instnorm -> lrelu, test_MultiHead_Module.py:287-291).  y: dense (N,V,C) fp16 (ld = C).
+ *   stats : mean/rstd[n][c] over the V voxels, biased variance.  ws: >= 2*N*C doubles, zeroed by the call.
+ *   fwd   : z = lrelu(gamma*(y-mean)*rstd + beta)  written with ld_z (may target a concat buffer)
+ *   bwd   : g = dz * lrelu'(.) ; dy = gamma*rstd*(g - mean_v(g) - xhat*mean_v(g*xhat)) written IN PLACE
+ *           over y; dgamma/dbeta/dbias (+)= (fp32; dbias is the conv bias gradient = sum_v dy).
+ *           grad_unscale multiplies the parameter gradients (1/loss_scale).
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_instnorm_stats(lnn_stream_t s, const void* y_h, int N, long V, int C, float eps, float* mean,
+                       float* rstd, double* ws);
+int lnn_instnorm_lrelu_fwd(lnn_stream_t s, const void* y_h, void* z_h, int ld_z, int N, long V, int C,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           float slope);
+int lnn_instnorm_lrelu_bwd(lnn_stream_t s, void* y_inout_h, const void* dz_h, int ld_dz, int N, long V, int C,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           float slope, float* dgamma, float* dbeta, float* dbias, float grad_unscale,
+                           double* ws);
+size_t lnn_instnorm_ws_doubles(int N, int C);
+
+/* ------------------------------------------------------------------------------------------------
+ * seg_outputs[u]: nn.Conv3d 1x1x1, no bias (test_MultiHead_Module.py:427-431).
+ *   fwd : logits[n][k][v] (fp32, NCDHW as the reference returns them, generic_ViT_UNet.py:282-284)
+ *   bwd : dz[n,v,c] (+)= sum_k dlogits[n][k][v] w[k][c]  (fp16, dlogits already carry the loss scale)
+ *         dw[k][c] += grad_unscale * sum_{n,v} dlogits[n][k][v] z[n,v,c]
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_seg1x1_fwd(lnn_stream_t s, const void* z_h, int ld_z, const float* w, float* logits, int N, long V,
+                   int C, int K);
+int lnn_seg1x1_bwd(lnn_stream_t s, const void* z_h, int ld_z, const float* w, const float* dlogits, void* dz_h,
+                   int ld_dz, float* dw, int N, long V, int C, int K, int accumulate_dz, float grad_unscale);
+
+/* ------------------------------------------------------------------------------------------------
+ * DC_and_CE_loss({'batch_dice','smooth':1e-5,'do_bg':False},{}) for ONE deep-supervision level
+ * (constructed nnUNetTrainerMultiHead.py:1385; upstream formula SURVEY.md A.3).
+ *   fwd : stats[n][k][3] = soft tp/fp/fn (double), ce_sum (double) -> loss = CE + Dice (fp32, *out_loss)
+ *   bwd : dlogits = gscale * d(loss)/d(logits)   (gscale = ds weight * upstream grad * loss scale)
+ * labels: (N,1,V) float holding integers (nnUNetTrainerMultiHead.py:606-608).  ws >= lnn_dice_ce_ws_doubles.
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_dice_ce_fwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
+                    int batch_dice, float smooth, float* out_loss, double* ws);
+int lnn_dice_ce_bwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
+                    int batch_dice, float smooth, const double* ws, float gscale, float* dlogits);
+size_t lnn_dice_ce_ws_doubles(int N, int K);
+
+/* argmax + per-sample hard TP/FP/FN for the foreground classes (nnUNetTrainerMultiHead.py:938-951).
+ * counts: (N, K-1, 3) float, zeroed by the call. */
+int lnn_online_dice_counts(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
+                           float* counts);
+
+/* ------------------------------------------------------------------------------------------------
+ * LwF distillation (deep_supervision.py:194-196):
+ *   out = (1/N) sum_{n,k,v} softmax(t/T)_k * (logsoftmax(t/T)_k - logsoftmax(y/T)_k)
+ * pred / teach: (N,K,V) fp32.  out: one float.  ws: >= 1 double.
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_kl_logits(lnn_stream_t s, const float* pred, const float* teach, int N, int K, long V, float T,
+                  float* out, double* ws);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat-arena parameter kernels (fp32, n elements).
+ *   EWC penalty  (deep_supervision.py:80):  out = lambda/2 * sum F (theta-theta*)^2 ;
+ *                 bwd: grad += gscale * lambda * F (theta-theta*)
+ *   Fisher       (nnUNetTrainerEWC.py:303): F = (g*unscale)^2 ; accumulate / EMA variants
+ *   grad norm + clip (nnUNetTrainerMultiHead.py:629,640): sumsq of unscaled grads, non-finite flag
+ *   SGD Nesterov (nnUNetTrainerMultiHead.py:299-300): fused unscale*clip, weight decay, momentum, update
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_ewc_penalty_fwd(lnn_stream_t s, const float* theta, const float* theta_star, const float* fisher,
+                        long n, float lambda, float* out, double* ws);
+int lnn_ewc_penalty_bwd(lnn_stream_t s, const float* theta, const float* theta_star, const float* fisher,
+                        long n, float lambda, float gscale, float* grad);
+int lnn_fisher_square(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale);
+int lnn_fisher_accumulate(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale, float weight);
+int lnn_fisher_ema(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale, float alpha);
+/* out[0] = sum (g*unscale)^2 (double), out[1] = number of non-finite elements (double) ; ws >= 2 doubles */
+int lnn_gradnorm_sumsq(lnn_stream_t s, const float* grad, long n, float unscale, double* out2);
+int lnn_sgd_nesterov_step(lnn_stream_t s, float* theta, float* momentum_buf, const float* grad, long n,
+                          float lr, float momentum, float weight_decay, float grad_scale, int first_step);
+
+/* debug: every lane of one wave issues ds_read_b64_tr_b16 at LDS byte address lane*8 over an LDS image
+ * holding its own half-index; out[lane*4+j] (float) = value received.  Used by tests to pin the
+ * hardware transpose-read lane mapping the wgrad kernels rely on. */
+int lnn_debug_tr16_probe(lnn_stream_t s, float* out256);
+
+/* fp32 <-> fp16 helpers for the image input (N,1,D,H,W f32 -> fp16, same memory order when C == 1) */
+int lnn_cast_f32_to_h(lnn_stream_t s, const float* src, void* dst_h, long n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LNN_HIP_H */

@@ -1,0 +1,454 @@
+// Implicit-GEMM 3-D convolution family on gfx950 MFMA (v_mfma_f32_32x32x16_f16), channels-last fp16.
+//
+// One kernel template covers every "gather taps -> contract channels" op of the U-Net:
+//   conv 3x3x3 fwd (stride 1|2), conv dgrad (stride 1; stride 2 as 8 parity classes),
+//   transposed conv k2s2 fwd (8 parity classes, 1 tap each) and its dgrad (8 taps, input stride 2).
+//
+//   OUT[n, os*l+par, m] = bias[m] + sum_{tap} sum_{c} IN[n, IS*l + off(tap) - pad_lo, c] * WP[slot(tap)][m][c]
+//
+// GEMM view per tap: D[m][voxel] += A[m][c] * B[c][voxel]  (A = weight panel rows, B = input voxels),
+// i.e. MFMA rows = output channels, MFMA columns = 32 output voxels, so that each lane ends up with 4
+// consecutive output channels of one voxel per accumulator quad -> 8-byte channels-last stores.
+//
+// Block = 256 threads = 4 waves; block tile = (TZ x TY x 8) loop voxels x (32*MT) output channels.
+// Input channels are processed in chunks of CK; the (halo) input tile of the chunk is staged once in
+// LDS and reused by all taps; weight panels are staged per tap group.
+// LDS rows are padded by 16 B (row pitch 16*odd) so the 16-byte fragment reads are conflict free.
+#include "lnn_common.h"
+
+namespace {
+
+struct TapTable {
+    int ntaps;
+    int taps_per_group;
+    unsigned short pos_off[27];  // offset (in LDS tile positions) of the tap
+    unsigned char slot[27];      // weight panel slot of the tap
+};
+
+struct ConvParams {
+    const half_t* x;
+    const half_t* wp;
+    const float* bias;
+    half_t* y;
+    int ld_x, ld_y;
+    int N, Di, Hi, Wi, Do, Ho, Wo;
+    int C, M, Mpad, KCpad;
+    int Ld, Lh, Lw;
+    int tiles_z, tiles_y, tiles_x;
+    int os, par_z, par_y, par_x;
+    int pad_lo;
+    int accumulate;
+    TapTable taps;
+};
+
+template <int IS, int EXT, int TZ, int TY, int CK, int MT>
+struct ConvCfg {
+    static constexpr int TX = 8;
+    static constexpr int VT = TZ * TY * TX / 128;  // 32-voxel MFMA tiles per wave
+    static constexpr int PZ = IS * (TZ - 1) + EXT, PY = IS * (TY - 1) + EXT, PX = IS * (TX - 1) + EXT;
+    static constexpr int P = PZ * PY * PX;
+    static constexpr int POSB = CK * 2 + 16;   // bytes per tile position
+    static constexpr int WROWB = CK * 2 + 16;  // bytes per weight row
+    static constexpr int MB = 32 * MT;         // output channels per block
+    static constexpr int MAXG = 27;
+    static constexpr int xbytes = P * POSB;
+    static constexpr int wbytes(int tpg) { return tpg * MB * WROWB; }
+};
+
+template <int IS, int EXT, int TZ, int TY, int CK, int MT>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvParams p) {
+    using Cfg = ConvCfg<IS, EXT, TZ, TY, CK, MT>;
+    constexpr int TX = Cfg::TX, VT = Cfg::VT, PY = Cfg::PY, PX = Cfg::PX, P = Cfg::P;
+    constexpr int POSB = Cfg::POSB, WROWB = Cfg::WROWB, MB = Cfg::MB;
+    constexpr int CH8 = CK / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xl = smem;
+    char* wl = smem + Cfg::xbytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- tile decode -----------------------------------------------------------------------------
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; t /= p.tiles_y;
+    const int tz = t % p.tiles_z; t /= p.tiles_z;
+    const int n = t;
+    const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+    const int iz0 = IS * lz0 - p.pad_lo, iy0 = IS * ly0 - p.pad_lo, ix0 = IS * lx0 - p.pad_lo;
+    const int m0 = blockIdx.y * MB;
+
+    // per-lane voxel positions of the wave's VT MFMA tiles
+    const int v = lane & 31, hk = lane >> 5;
+    int lanepos[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+        const int tile = wave * VT + vt;
+        const int z = tile / (TY / 4), y = (tile % (TY / 4)) * 4 + (v >> 3), x = v & 7;
+        lanepos[vt] = ((IS * z * PY + IS * y) * PX + IS * x) * POSB + hk * 16;
+    }
+    const int wlane = (lane & 31) * WROWB + hk * 16;
+
+    floatx16 acc[MT][VT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < VT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const long xbase_n = (long)n * p.Di * p.Hi * p.Wi;
+    const int ntaps = p.taps.ntaps, tpg = p.taps.taps_per_group;
+
+    for (int c0 = 0; c0 < p.C; c0 += CK) {
+        __syncthreads();  // previous chunk's readers are done with xl / wl
+        // ---- stage the input tile of this channel chunk ------------------------------------------
+        for (int idx = tid; idx < P * CH8; idx += 256) {
+            const int pos = idx / CH8, c8 = idx % CH8;
+            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+            const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
+                c0 + c8 * 8 < p.C) {
+                const long off = (xbase_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + c0 + c8 * 8;
+                val = *reinterpret_cast<const half8*>(p.x + off);
+            }
+            *reinterpret_cast<half8*>(xl + pos * POSB + c8 * 16) = val;
+        }
+        for (int g0 = 0; g0 < ntaps; g0 += tpg) {
+            const int gn = min(tpg, ntaps - g0);
+            if (g0 > 0) __syncthreads();  // readers of the previous weight group are done
+            // ---- stage the weight panels of this tap group ---------------------------------------
+            for (int idx = tid; idx < gn * MB * CH8; idx += 256) {
+                const int c8 = idx % CH8, r = (idx / CH8) % MB, tl = idx / (CH8 * MB);
+                const int slot = p.taps.slot[g0 + tl];
+                half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m0 + r < p.Mpad && c0 + c8 * 8 < p.KCpad)
+                    val = *reinterpret_cast<const half8*>(p.wp + ((long)slot * p.Mpad + m0 + r) * p.KCpad + c0 + c8 * 8);
+                *reinterpret_cast<half8*>(wl + (tl * MB + r) * WROWB + c8 * 16) = val;
+            }
+            __syncthreads();
+            // ---- MFMA over the taps of the group -------------------------------------------------
+            for (int tl = 0; tl < gn; ++tl) {
+                const int xo = (int)p.taps.pos_off[g0 + tl] * POSB;
+                const char* wrow = wl + tl * MB * WROWB + wlane;
+#pragma unroll
+                for (int k16 = 0; k16 < CK / 16; ++k16) {
+                    half8 a[MT], b[VT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[mt] = *reinterpret_cast<const half8*>(wrow + mt * 32 * WROWB + k16 * 32);
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt)
+                        b[vt] = *reinterpret_cast<const half8*>(xl + lanepos[vt] + xo + k16 * 32);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int vt = 0; vt < VT; ++vt)
+                            acc[mt][vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[vt], acc[mt][vt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds voxel (lane&31) x channels {8*q + 4*hk + 0..3} per accumulator quad ----
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+        const int tile = wave * VT + vt;
+        const int lz = lz0 + tile / (TY / 4), ly = ly0 + (tile % (TY / 4)) * 4 + (v >> 3), lx = lx0 + (v & 7);
+        if (lz >= p.Ld || ly >= p.Lh || lx >= p.Lw) continue;
+        const int oz = p.os * lz + p.par_z, oy = p.os * ly + p.par_y, ox = p.os * lx + p.par_x;
+        half_t* yrow = p.y + ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.ld_y;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + mt * 32 + q * 8 + hk * 4;
+                if (m >= p.M) continue;
+                float r0 = acc[mt][vt][q * 4 + 0], r1 = acc[mt][vt][q * 4 + 1], r2 = acc[mt][vt][q * 4 + 2],
+                      r3 = acc[mt][vt][q * 4 + 3];
+                if (p.bias) {
+                    const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + m);
+                    r0 += bv[0]; r1 += bv[1]; r2 += bv[2]; r3 += bv[3];
+                }
+                half4* dst = reinterpret_cast<half4*>(yrow + m);
+                if (p.accumulate) {
+                    const half4 old = *dst;
+                    r0 += (float)old[0]; r1 += (float)old[1]; r2 += (float)old[2]; r3 += (float)old[3];
+                }
+                half4 o = {(half_t)r0, (half_t)r1, (half_t)r2, (half_t)r3};
+                *dst = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First layer (C == 1): im2col inside LDS, taps are the contraction dimension (27 -> 32).
+//   y[n,p,m] = b[m] + sum_tap w[m][tap] x[n, p + tap - 1]
+// x tile: (TZ+2)(TY+2)(TX+2) halves.  Weight panel wp[0][Mpad][32].
+// ------------------------------------------------------------------------------------------------
+template <int TZ, int TY, int MT>
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const ConvParams p) {
+    constexpr int TX = 8, VT = TZ * TY * TX / 128, PZ = TZ + 2, PY = TY + 2, PX = TX + 2, P = PZ * PY * PX;
+    __shared__ half_t xl[P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; t /= p.tiles_y;
+    const int tz = t % p.tiles_z; t /= p.tiles_z;
+    const int n = t;
+    const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+    const int m0 = blockIdx.y * 32 * MT;
+    const long xbase_n = (long)n * p.Di * p.Hi * p.Wi;
+    for (int pos = tid; pos < P; pos += 256) {
+        const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+        const int iz = lz0 + pz - 1, iy = ly0 + py - 1, ix = lx0 + px - 1;
+        half_t val = 0;
+        if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+            val = p.x[xbase_n + ((long)iz * p.Hi + iy) * p.Wi + ix];
+        xl[pos] = val;
+    }
+    const int v = lane & 31, hk = lane >> 5;
+    // weight fragments straight from global (tiny, L2 resident)
+    half8 a[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16) {
+            const int m = m0 + mt * 32 + v;
+            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < p.Mpad) val = *reinterpret_cast<const half8*>(p.wp + (long)m * 32 + k16 * 16 + hk * 8);
+            a[mt][k16] = val;
+        }
+    // tap offsets of this lane's 16 contraction slots
+    int toff[2][8];
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kc = k16 * 16 + hk * 8 + j;
+            toff[k16][j] = kc < 27 ? ((kc / 9) * PY + (kc / 3) % 3) * PX + kc % 3 : 0;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+        const int tile = wave * VT + vt;
+        const int z = tile / (TY / 4), y = (tile % (TY / 4)) * 4 + (v >> 3), x = v & 7;
+        const int base = (z * PY + y) * PX + x;
+        floatx16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16) {
+            half8 b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = xl[base + toff[k16][j]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][k16], b, acc[mt], 0, 0, 0);
+        }
+        const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
+        if (lz >= p.Do || ly >= p.Ho || lx >= p.Wo) continue;
+        half_t* yrow = p.y + ((((long)n * p.Do + lz) * p.Ho + ly) * p.Wo + lx) * p.ld_y;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + mt * 32 + q * 8 + hk * 4;
+                if (m >= p.M) continue;
+                floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv = *reinterpret_cast<const floatx4*>(p.bias + m);
+                half4 o = {(half_t)(acc[mt][q * 4 + 0] + bv[0]), (half_t)(acc[mt][q * 4 + 1] + bv[1]),
+                           (half_t)(acc[mt][q * 4 + 2] + bv[2]), (half_t)(acc[mt][q * 4 + 3] + bv[3])};
+                *reinterpret_cast<half4*>(yrow + m) = o;
+            }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+template <int IS, int EXT, int TZ, int TY, int CK, int MT>
+int launch_igemm(hipStream_t s, ConvParams& p, const char* name) {
+    using Cfg = ConvCfg<IS, EXT, TZ, TY, CK, MT>;
+    p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, Cfg::TX);
+    // weight taps per group: as many as fit next to the input tile in <= 64 KB total (2 blocks / CU)
+    const int budget = 64 * 1024 - Cfg::xbytes;
+    int tpg = budget / (Cfg::MB * Cfg::WROWB);
+    if (tpg < 1) tpg = 1;
+    if (tpg > p.taps.ntaps) tpg = p.taps.ntaps;
+    if (p.taps.ntaps == 27) tpg = tpg >= 27 ? 27 : (tpg >= 9 ? 9 : (tpg >= 3 ? 3 : 1));
+    p.taps.taps_per_group = tpg;
+    const size_t lds = Cfg::xbytes + Cfg::wbytes(tpg);
+    auto kern = igemm_conv_kernel<IS, EXT, TZ, TY, CK, MT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((long)p.N * p.tiles_z * p.tiles_y * p.tiles_x), (unsigned)lnn_cdiv(p.M, Cfg::MB));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
+
+template <int IS, int EXT, int TZ, int TY>
+int dispatch_ck_mt(hipStream_t s, ConvParams& p, const char* name) {
+    const bool ck32 = p.C > 16;
+    const bool mt2 = p.M > 32;
+    if (ck32) return mt2 ? launch_igemm<IS, EXT, TZ, TY, 32, 2>(s, p, name) : launch_igemm<IS, EXT, TZ, TY, 32, 1>(s, p, name);
+    return mt2 ? launch_igemm<IS, EXT, TZ, TY, 16, 2>(s, p, name) : launch_igemm<IS, EXT, TZ, TY, 16, 1>(s, p, name);
+}
+
+int check_act(const void* ptr, int ld, int C, const char* what) {
+    LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
+    LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
+    LNN_REQUIRE(C > 0 && C % 8 == 0, "%s: channel count %d must be a positive multiple of 8", what, C);
+    LNN_REQUIRE(ld >= C && ld % 8 == 0, "%s: ld %d must be >= C (%d) and a multiple of 8", what, ld, C);
+    return LNN_OK;
+}
+
+}  // namespace
+
+extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const void* wp, const float* bias, void* y,
+                              int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_fwd: stride %d unsupported", stride);
+    LNN_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0, "lnn_conv3d_fwd: bad dims");
+    LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_conv3d_fwd: weight panel null/misaligned");
+    LNN_REQUIRE(bias == nullptr || lnn_aligned16(bias), "lnn_conv3d_fwd: bias misaligned");
+    if (int e = check_act(y, ld_y, K, "lnn_conv3d_fwd(y)")) return e;
+    ConvParams p{};
+    p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.bias = bias; p.y = (half_t*)y;
+    p.ld_x = ld_x; p.ld_y = ld_y; p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
+    p.Do = (Di - 1) / stride + 1; p.Ho = (Hi - 1) / stride + 1; p.Wo = (Wi - 1) / stride + 1;
+    p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32);
+    p.Ld = p.Do; p.Lh = p.Ho; p.Lw = p.Wo; p.os = 1; p.pad_lo = 1; p.accumulate = 0;
+    if (C == 1) {
+        LNN_REQUIRE(stride == 1, "lnn_conv3d_fwd: C == 1 path supports stride 1 only");
+        LNN_REQUIRE(x != nullptr, "lnn_conv3d_fwd: null x");
+        p.KCpad = 32;
+        p.tiles_z = lnn_cdiv(p.Ld, 4); p.tiles_y = lnn_cdiv(p.Lh, 8); p.tiles_x = lnn_cdiv(p.Lw, 8);
+        dim3 grid((unsigned)((long)N * p.tiles_z * p.tiles_y * p.tiles_x), (unsigned)lnn_cdiv(K, 32));
+        hipLaunchKernelGGL((conv_c1_fwd_kernel<4, 8, 1>), grid, dim3(256), 0, s, p);
+        LNN_CHECK_LAUNCH("lnn_conv3d_fwd(C=1)");
+        return LNN_OK;
+    }
+    if (int e = check_act(x, ld_x, C, "lnn_conv3d_fwd(x)")) return e;
+    p.KCpad = lnn_round_up(C, 16);
+    p.taps.ntaps = 27;
+    if (stride == 1) {
+        constexpr int PY = 10, PX = 10;
+        for (int t = 0; t < 27; ++t) {
+            p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
+            p.taps.slot[t] = (unsigned char)t;
+        }
+        return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
+    }
+    {
+        constexpr int PY = 2 * 7 + 3, PX = 2 * 7 + 3;  // TZ=2, TY=8, TX=8
+        for (int t = 0; t < 27; ++t) {
+            p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
+            p.taps.slot[t] = (unsigned char)t;
+        }
+        const bool mt2 = p.M > 32;
+        return mt2 ? launch_igemm<2, 3, 2, 8, 16, 2>(s, p, "lnn_conv3d_fwd(s2)")
+                   : launch_igemm<2, 3, 2, 8, 16, 1>(s, p, "lnn_conv3d_fwd(s2)");
+    }
+}
+
+extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N,
+                                int Di, int Hi, int Wi, int C, int K, int stride, int accumulate) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_dgrad: stride %d unsupported", stride);
+    LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_conv3d_dgrad: weight panel null/misaligned");
+    if (int e = check_act(dy, ld_dy, K, "lnn_conv3d_dgrad(dy)")) return e;
+    if (int e = check_act(dx, ld_dx, C, "lnn_conv3d_dgrad(dx)")) return e;
+    const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    ConvParams p{};
+    // roles: gathered input = dy (K channels), output = dx (C channels); panel wp[slot][C][K]
+    p.x = (const half_t*)dy; p.wp = (const half_t*)wp; p.bias = nullptr; p.y = (half_t*)dx;
+    p.ld_x = ld_dy; p.ld_y = ld_dx; p.N = N; p.Di = Do; p.Hi = Ho; p.Wi = Wo; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
+    p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16);
+    p.accumulate = accumulate;
+    if (stride == 1) {
+        // dx[q] = sum_d w[d]^T dy[q - d + 1]  -> tap offset d' = 2 - d uses slot d
+        p.Ld = Di; p.Lh = Hi; p.Lw = Wi; p.os = 1; p.pad_lo = 1;
+        p.taps.ntaps = 27;
+        constexpr int PY = 10, PX = 10;
+        for (int t = 0; t < 27; ++t) {
+            const int dz = t / 9, dyy = (t / 3) % 3, dxx = t % 3;
+            p.taps.pos_off[t] = (unsigned short)((dz * PY + dyy) * PX + dxx);
+            p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
+        }
+        return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
+    }
+    // stride 2: dx[2l+par] = sum over taps d with (par - d + 1) even: dy[l + (par - d + 1)/2]
+    //   par = 0 -> d = 1 (offset 0);  par = 1 -> d = 0 (offset +1), d = 2 (offset 0)
+    int rc = LNN_OK;
+    for (int cls = 0; cls < 8 && rc == LNN_OK; ++cls) {
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+        ConvParams q = p;
+        q.os = 2; q.par_z = pz; q.par_y = py; q.par_x = px; q.pad_lo = 0;
+        q.Ld = (Di - pz + 1) / 2; q.Lh = (Hi - py + 1) / 2; q.Lw = (Wi - px + 1) / 2;
+        if (q.Ld <= 0 || q.Lh <= 0 || q.Lw <= 0) {
+            continue;
+        }
+        constexpr int PY = 8 + 1, PX = 8 + 1;  // IS=1, EXT=2, TZ=4, TY=8
+        int nt = 0;
+        const int dzs[2][2] = {{1, -1}, {0, 2}}, offs[2][2] = {{0, 0}, {1, 0}}, cnt[2] = {1, 2};
+        for (int a = 0; a < cnt[pz]; ++a)
+            for (int b = 0; b < cnt[py]; ++b)
+                for (int c = 0; c < cnt[px]; ++c) {
+                    q.taps.pos_off[nt] = (unsigned short)((offs[pz][a] * PY + offs[py][b]) * PX + offs[px][c]);
+                    q.taps.slot[nt] = (unsigned char)(dzs[pz][a] * 9 + dzs[py][b] * 3 + dzs[px][c]);
+                    ++nt;
+                }
+        q.taps.ntaps = nt;
+        rc = dispatch_ck_mt<1, 2, 4, 8>(s, q, "lnn_conv3d_dgrad(s2)");
+    }
+    return rc;
+}
+
+extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s_, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N,
+                                    int D, int H, int W, int C, int K) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_convT3d_k2s2_fwd: weight panel null/misaligned");
+    if (int e = check_act(x, ld_x, C, "lnn_convT3d_k2s2_fwd(x)")) return e;
+    if (int e = check_act(y, ld_y, K, "lnn_convT3d_k2s2_fwd(y)")) return e;
+    ConvParams p{};
+    p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.y = (half_t*)y; p.ld_x = ld_x; p.ld_y = ld_y;
+    p.N = N; p.Di = D; p.Hi = H; p.Wi = W; p.Do = 2 * D; p.Ho = 2 * H; p.Wo = 2 * W;
+    p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32); p.KCpad = lnn_round_up(C, 16);
+    p.Ld = D; p.Lh = H; p.Lw = W; p.os = 2; p.pad_lo = 0;
+    int rc = LNN_OK;
+    for (int cls = 0; cls < 8 && rc == LNN_OK; ++cls) {
+        ConvParams q = p;
+        q.par_z = cls >> 2; q.par_y = (cls >> 1) & 1; q.par_x = cls & 1;
+        q.taps.ntaps = 1; q.taps.pos_off[0] = 0; q.taps.slot[0] = (unsigned char)cls;
+        rc = dispatch_ck_mt<1, 1, 4, 8>(s, q, "lnn_convT3d_k2s2_fwd");
+    }
+    return rc;
+}
+
+extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx,
+                                      int N, int D, int H, int W, int C, int K, int accumulate) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_convT3d_k2s2_dgrad: weight panel null/misaligned");
+    if (int e = check_act(dy, ld_dy, K, "lnn_convT3d_k2s2_dgrad(dy)")) return e;
+    if (int e = check_act(dx, ld_dx, C, "lnn_convT3d_k2s2_dgrad(dx)")) return e;
+    ConvParams p{};
+    // dx[l, c] = sum_d sum_k dy[2l + d, k] W[c, k, d]: gathered input = dy with stride 2, 8 taps
+    p.x = (const half_t*)dy; p.wp = (const half_t*)wp; p.y = (half_t*)dx; p.ld_x = ld_dy; p.ld_y = ld_dx;
+    p.N = N; p.Di = 2 * D; p.Hi = 2 * H; p.Wi = 2 * W; p.Do = D; p.Ho = H; p.Wo = W;
+    p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16);
+    p.Ld = D; p.Lh = H; p.Lw = W; p.os = 1; p.pad_lo = 0; p.accumulate = accumulate;
+    constexpr int PY = 2 * 7 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=8
+    p.taps.ntaps = 8;
+    for (int t = 0; t < 8; ++t) {
+        p.taps.pos_off[t] = (unsigned short)(((t >> 2) * PY + ((t >> 1) & 1)) * PX + (t & 1));
+        p.taps.slot[t] = (unsigned char)t;
+    }
+    const bool mt2 = p.M > 32;
+    return mt2 ? launch_igemm<2, 2, 2, 8, 16, 2>(s, p, "lnn_convT3d_k2s2_dgrad")
+               : launch_igemm<2, 2, 2, 8, 16, 1>(s, p, "lnn_convT3d_k2s2_dgrad");
+}

@@ -1,0 +1,332 @@
+// Weight-gradient implicit GEMM on gfx950 MFMA: the contraction runs over VOXELS, so both operands
+// are "transposed" relative to their channels-last storage.  The transposition is done by the LDS
+// hardware transpose read ds_read_b64_tr_b16 (gfx950), never by scalar LDS traffic.
+//
+//   DWP[slot(tap)][m][c] += sum_{n, l} P[n, l, m] * Q[n, IS*l + off(tap) - pad_lo, c]
+//
+//   conv3d      : P = dy (at output voxel l),  Q = x  (gathered),  IS = stride, 27 taps
+//   convT k2s2  : P = x  (at input voxel l),   Q = dy (gathered),  IS = 2,      8 taps
+//
+// Block = 256 threads = 4 waves, one (32 m) x (32 c) panel tile for ALL taps; wave w owns taps
+// w, w+4, ... (<= 7 accumulators of 16 VGPRs).  Each block walks `tiles_per_block` spatial tiles
+// of TZ x TY x 8 loop voxels, accumulating in registers, and finishes with fp32 atomics into the
+// packed panel (coalesced: c is the fastest index).
+#include "lnn_common.h"
+
+namespace {
+
+struct WTapTable {
+    int ntaps;
+    unsigned short pos_off[27];
+    unsigned char slot[27];
+};
+
+struct WgradParams {
+    const half_t* p;
+    const half_t* q;
+    float* dwp;
+    int ld_p, ld_q;
+    int N, Ld, Lh, Lw, Qd, Qh, Qw;
+    int M, C, Mpad, Cpad;
+    int tiles_z, tiles_y, tiles_x, tiles_total, tiles_per_block;
+    int pad_lo;
+    WTapTable taps;
+};
+
+__device__ __forceinline__ half4 lds_tr16(const char* addr) {
+    fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+        (__attribute__((address_space(3))) fp16x4_t*)(addr));
+    half4 o;
+    __builtin_memcpy(&o, &r, 8);
+    return o;
+}
+
+template <int IS, int EXT, int TZ, int TY, int TPW>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
+    constexpr int TX = 8, TV = TZ * TY * TX;
+    constexpr int PZ = IS * (TZ - 1) + EXT, PY = IS * (TY - 1) + EXT, PX = IS * (TX - 1) + EXT, P = PZ * PY * PX;
+    constexpr int ROWB = 80;  // 32 channels * 2 B + 16 B pad
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ql = smem;             // [P][ROWB]
+    char* pl = smem + P * ROWB;  // [TV][ROWB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
+
+    // transpose-read lane roles: 16-lane group g -> channel base 16*(g&1); lane s in group supplies the
+    // address of voxel (s>>2) (+4r, +8h) and channel sub-block 4*(s&3); it receives channel (s) of 4 voxels.
+    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
+    const int lane_ch_off = (cb + 4 * sq) * 2;
+    // voxel-in-chunk u = 8*hk + 4*r + sj  -> row hk of the chunk, x = 4r + sj
+    const int p_lane = (8 * hk + sj) * ROWB + lane_ch_off;
+    const int q_lane = ((IS * hk) * PX + IS * sj) * ROWB + lane_ch_off;
+
+    floatx16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int tz = t % p.tiles_z; t /= p.tiles_z;
+        const int n = t;
+        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+        const int iz0 = IS * lz0 - p.pad_lo, iy0 = IS * ly0 - p.pad_lo, ix0 = IS * lx0 - p.pad_lo;
+        __syncthreads();
+        // ---- stage Q tile (gathered operand, 32 channels c0..c0+31) ------------------------------
+        const long qbase = (long)n * p.Qd * p.Qh * p.Qw;
+        for (int idx = tid; idx < P * 4; idx += 256) {
+            const int pos = idx >> 2, c8 = idx & 3;
+            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+            const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
+                c0 + c8 * 8 < p.C)
+                val = *reinterpret_cast<const half8*>(p.q + (qbase + ((long)iz * p.Qh + iy) * p.Qw + ix) * p.ld_q + c0 + c8 * 8);
+            *reinterpret_cast<half8*>(ql + pos * ROWB + c8 * 16) = val;
+        }
+        // ---- stage P tile (32 channels m0..m0+31 at the loop voxels) ------------------------------
+        const long pbase = (long)n * p.Ld * p.Lh * p.Lw;
+        for (int idx = tid; idx < TV * 4; idx += 256) {
+            const int vox = idx >> 2, c8 = idx & 3;
+            const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
+            const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
+            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M)
+                val = *reinterpret_cast<const half8*>(p.p + (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8);
+            *reinterpret_cast<half8*>(pl + vox * ROWB + c8 * 16) = val;
+        }
+        __syncthreads();
+        // ---- contraction over the tile's voxels, 16 per MFMA --------------------------------------
+#pragma unroll 2
+        for (int ch = 0; ch < TV / 16; ++ch) {
+            // chunk rows 2ch, 2ch+1 (8 voxels each)
+            const int row = 2 * ch;  // + hk folded into lane offsets
+            const int z = row / TY, y = row % TY;
+            const char* pa = pl + ch * 16 * ROWB + p_lane;
+            half4 a0 = lds_tr16(pa), a1 = lds_tr16(pa + 4 * ROWB);
+            half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const char* qa = ql + ((IS * z * PY + IS * y) * PX) * ROWB + q_lane;
+#pragma unroll
+            for (int ti = 0; ti < TPW; ++ti) {
+                const int tap = wave + 4 * ti;
+                if (tap < p.taps.ntaps) {
+                    const char* qt = qa + (int)p.taps.pos_off[tap] * ROWB;
+                    half4 b0 = lds_tr16(qt), b1 = lds_tr16(qt + 4 * IS * ROWB);
+                    half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: D rows = m (8*(r>>2) + 4*hk + (r&3)), cols = c (lane&31) ----------------------
+    const int c = c0 + (lane & 31);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = wave + 4 * ti;
+        if (tap < p.taps.ntaps) {
+            float* panel = p.dwp + (long)p.taps.slot[tap] * p.Mpad * p.Cpad;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
+                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First layer (C == 1): DWP[0][m][tap] += sum_l dy[l, m] * x[l + tap - 1]     (tap padded to 32)
+// A = dy^T by transpose reads, B[voxel][tap] gathered from a single-channel LDS tile.
+// ------------------------------------------------------------------------------------------------
+template <int TZ, int TY>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
+    constexpr int TX = 8, TV = TZ * TY * TX, PZ = TZ + 2, PY = TY + 2, PX = TX + 2, P = PZ * PY * PX;
+    constexpr int ROWB = 80;
+    __shared__ __attribute__((aligned(16))) char pl[TV * ROWB];
+    __shared__ half_t xl[P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 32;
+    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
+    const int p_lane = (8 * hk + sj) * ROWB + (cb + 4 * sq) * 2;
+    const int tapn = lane & 31;
+    const int toff = tapn < 27 ? ((tapn / 9) * PY + (tapn / 3) % 3) * PX + tapn % 3 : 0;
+    floatx16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int tz = t % p.tiles_z; t /= p.tiles_z;
+        const int n = t;
+        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+        __syncthreads();
+        const long qbase = (long)n * p.Qd * p.Qh * p.Qw;
+        for (int pos = tid; pos < P; pos += 256) {
+            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+            const int iz = lz0 + pz - 1, iy = ly0 + py - 1, ix = lx0 + px - 1;
+            half_t val = 0;
+            if ((unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw)
+                val = p.q[qbase + ((long)iz * p.Qh + iy) * p.Qw + ix];
+            xl[pos] = val;
+        }
+        const long pbase = (long)n * p.Ld * p.Lh * p.Lw;
+        for (int idx = tid; idx < TV * 4; idx += 256) {
+            const int vox = idx >> 2, c8 = idx & 3;
+            const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
+            const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
+            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M)
+                val = *reinterpret_cast<const half8*>(p.p + (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8);
+            *reinterpret_cast<half8*>(pl + vox * ROWB + c8 * 16) = val;
+        }
+        __syncthreads();
+        // each wave takes chunks wave, wave+4, ...
+        for (int ch = wave; ch < TV / 16; ch += 4) {
+            const char* pa = pl + ch * 16 * ROWB + p_lane;
+            half4 a0 = lds_tr16(pa), a1 = lds_tr16(pa + 4 * ROWB);
+            half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            // B: lane = tap n, k-slot (hk, r, j) <-> voxel u = 8*hk + 4*r + j of the chunk (same map as A)
+            const int row = 2 * ch + hk, z = row / TY, y = row % TY;
+            const int base = (z * PY + y) * PX + toff;
+            half8 b;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) b[u] = xl[base + u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+    }
+    if (tapn < 27) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
+            atomicAdd(p.dwp + (long)m * 32 + tapn, acc[r]);
+        }
+    }
+}
+
+template <int IS, int EXT, int TZ, int TY, int TPW>
+int launch_wgrad(hipStream_t s, WgradParams& p, const char* name) {
+    constexpr int TX = 8, TV = TZ * TY * TX;
+    constexpr int PZ = IS * (TZ - 1) + EXT, PY = IS * (TY - 1) + EXT, PX = IS * (TX - 1) + EXT, P = PZ * PY * PX;
+    p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
+    p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
+    const int panels = (p.Mpad / 32) * (p.Cpad / 32);
+    // enough blocks to fill the chip ~4x over, but at least a few tiles per block to amortise the atomics
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, 1024);
+    if (tpb < 1) tpb = 1;
+    if (tpb > 32) tpb = 32;
+    p.tiles_per_block = tpb;
+    const size_t lds = (size_t)(P + TV) * 80;
+    auto kern = igemm_wgrad_kernel<IS, EXT, TZ, TY, TPW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
+
+int check_act_w(const void* ptr, int ld, int C, const char* what) {
+    LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
+    LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
+    LNN_REQUIRE(C > 0 && C % 8 == 0, "%s: channel count %d must be a positive multiple of 8", what, C);
+    LNN_REQUIRE(ld >= C && ld % 8 == 0, "%s: ld %d must be >= C (%d) and a multiple of 8", what, ld, C);
+    return LNN_OK;
+}
+
+}  // namespace
+
+namespace {
+__global__ void tr16_probe_kernel(float* out) {
+    __shared__ __attribute__((aligned(16))) half_t img[256];
+    for (int i = threadIdx.x; i < 256; i += 64) img[i] = (half_t)(float)i;
+    __syncthreads();
+    const half4 r = lds_tr16(reinterpret_cast<const char*>(img) + threadIdx.x * 8);
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (float)r[j];
+}
+}  // namespace
+
+extern "C" int lnn_debug_tr16_probe(lnn_stream_t s_, float* out256) {
+    LNN_REQUIRE(out256 != nullptr, "lnn_debug_tr16_probe: null pointer");
+    hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)s_, out256);
+    LNN_CHECK_LAUNCH("lnn_debug_tr16_probe");
+    return LNN_OK;
+}
+
+extern "C" size_t lnn_wgrad_panel_elems(int ntaps, int M, int KC) {
+    return (size_t)ntaps * lnn_round_up(M, 32) * lnn_round_up(KC, 32);
+}
+
+extern "C" int lnn_conv3d_wgrad(lnn_stream_t s_, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N,
+                                int Di, int Hi, int Wi, int C, int K, int stride) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_wgrad: stride %d unsupported", stride);
+    LNN_REQUIRE(dwp != nullptr, "lnn_conv3d_wgrad: null panel");
+    if (int e = check_act_w(dy, ld_dy, K, "lnn_conv3d_wgrad(dy)")) return e;
+    WgradParams p{};
+    p.p = (const half_t*)dy; p.q = (const half_t*)x; p.dwp = dwp; p.ld_p = ld_dy; p.ld_q = ld_x;
+    p.N = N; p.Qd = Di; p.Qh = Hi; p.Qw = Wi;
+    p.Ld = (Di - 1) / stride + 1; p.Lh = (Hi - 1) / stride + 1; p.Lw = (Wi - 1) / stride + 1;
+    p.M = K; p.C = C; p.Mpad = lnn_round_up(K, 32); p.Cpad = lnn_round_up(C, 32); p.pad_lo = 1;
+    if (C == 1) {
+        LNN_REQUIRE(stride == 1 && x != nullptr, "lnn_conv3d_wgrad: C == 1 path needs stride 1");
+        constexpr int TZ = 4, TY = 8;
+        p.Cpad = 32;
+        p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, 8);
+        p.tiles_total = N * p.tiles_z * p.tiles_y * p.tiles_x;
+        int tpb = lnn_cdiv(p.tiles_total, 2048);
+        if (tpb < 1) tpb = 1;
+        p.tiles_per_block = tpb;
+        dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)(p.Mpad / 32));
+        hipLaunchKernelGGL((wgrad_c1_kernel<TZ, TY>), grid, dim3(256), 0, s, p);
+        LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(C=1)");
+        return LNN_OK;
+    }
+    if (int e = check_act_w(x, ld_x, C, "lnn_conv3d_wgrad(x)")) return e;
+    p.taps.ntaps = 27;
+    if (stride == 1) {
+        constexpr int PY = 10, PX = 10;
+        for (int t = 0; t < 27; ++t) {
+            p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
+            p.taps.slot[t] = (unsigned char)t;
+        }
+        return launch_wgrad<1, 3, 4, 8, 7>(s, p, "lnn_conv3d_wgrad(s1)");
+    }
+    constexpr int PY = 2 * 3 + 3, PX = 2 * 7 + 3;  // IS=2, TZ=2, TY=4, TX=8
+    for (int t = 0; t < 27; ++t) {
+        p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
+        p.taps.slot[t] = (unsigned char)t;
+    }
+    return launch_wgrad<2, 3, 2, 4, 7>(s, p, "lnn_conv3d_wgrad(s2)");
+}
+
+extern "C" int lnn_convT3d_k2s2_wgrad(lnn_stream_t s_, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp,
+                                      int N, int D, int H, int W, int C, int K) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(dwp != nullptr, "lnn_convT3d_k2s2_wgrad: null panel");
+    if (int e = check_act_w(x, ld_x, C, "lnn_convT3d_k2s2_wgrad(x)")) return e;
+    if (int e = check_act_w(dy, ld_dy, K, "lnn_convT3d_k2s2_wgrad(dy)")) return e;
+    WgradParams p{};
+    // dW[c,k,d] = sum_l x[l,c] dy[2l+d,k]:  P = x (rows c), Q = dy gathered with stride 2 (cols k)
+    p.p = (const half_t*)x; p.q = (const half_t*)dy; p.dwp = dwp; p.ld_p = ld_x; p.ld_q = ld_dy;
+    p.N = N; p.Ld = D; p.Lh = H; p.Lw = W; p.Qd = 2 * D; p.Qh = 2 * H; p.Qw = 2 * W;
+    p.M = C; p.C = K; p.Mpad = lnn_round_up(C, 32); p.Cpad = lnn_round_up(K, 32); p.pad_lo = 0;
+    constexpr int PY = 2 * 3 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=4
+    p.taps.ntaps = 8;
+    for (int t = 0; t < 8; ++t) {
+        p.taps.pos_off[t] = (unsigned short)(((t >> 2) * PY + ((t >> 1) & 1)) * PX + (t & 1));
+        p.taps.slot[t] = (unsigned char)t;
+    }
+    return launch_wgrad<2, 2, 2, 4, 2>(s, p, "lnn_convT3d_k2s2_wgrad");
+}

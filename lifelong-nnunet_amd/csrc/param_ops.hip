@@ -1,0 +1,222 @@
+// Flat-arena parameter kernels (fp32, HBM-bound, one pass each): weight panel packing / gradient panel
+// unpacking, EWC penalty forward + backward, Fisher extraction, gradient norm, fused SGD-Nesterov.
+// Plus the library-wide error string and device query.
+#include "lnn_common.h"
+#include <cstring>
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void lnn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* lnn_last_error(void) { return g_err; }
+extern "C" int lnn_version(void) { return 100; }
+extern "C" int lnn_device_info(int* cu_count, int* clock_khz, char* name, int name_len) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { lnn_set_error("lnn_device_info: no device"); return LNN_ERR_LAUNCH; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { lnn_set_error("lnn_device_info: query failed"); return LNN_ERR_LAUNCH; }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (name && name_len > 0) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    return LNN_OK;
+}
+
+namespace {
+constexpr int NT = 256;
+
+int flat_blocks(long n, int per_thread) {
+    long b = (n + (long)NT * per_thread - 1) / ((long)NT * per_thread);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int ntaps, int M, int KC, int Mpad,
+                                    int KCpad, long sm, long skc, long st) {
+    const long total = (long)ntaps * Mpad * KCpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % KCpad), m = (int)((i / KCpad) % Mpad), t = (int)(i / ((long)KCpad * Mpad));
+        float v = 0.f;
+        if (m < M && kc < KC) v = src[m * sm + kc * skc + t * st];
+        dst[i] = (half_t)v;
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dst, int ntaps, int M, int KC, int Mpad,
+                                    int KCpad, long sm, long skc, long st, float scale, int accumulate) {
+    const long total = (long)ntaps * M * KC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // iterate in DESTINATION-friendly order: t fastest (conv weights have taps contiguous)
+        const int t = (int)(i % ntaps), kc = (int)((i / ntaps) % KC), m = (int)(i / ((long)ntaps * KC));
+        const float v = scale * dwp[((long)t * Mpad + m) * KCpad + kc];
+        float* d = dst + m * sm + kc * skc + t * st;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void ewc_fwd_kernel(const float* __restrict__ th, const float* __restrict__ ts,
+                                                     const float* __restrict__ f, long n, double* ws) {
+    __shared__ float sm[NT / 64];
+    float acc[1] = {0.f};
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        const floatx4 a = reinterpret_cast<const floatx4*>(th)[i], b = reinterpret_cast<const floatx4*>(ts)[i],
+                      c = reinterpret_cast<const floatx4*>(f)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = a[e] - b[e]; acc[0] += c[e] * d * d; }
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float d = th[i] - ts[i];
+        acc[0] += f[i] * d * d;
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(ws, (double)acc[0]);
+}
+__global__ void ewc_finalize_kernel(const double* ws, float lambda, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(0.5 * (double)lambda * ws[0]);
+}
+__global__ __launch_bounds__(NT) void ewc_bwd_kernel(const float* __restrict__ th, const float* __restrict__ ts,
+                                                     const float* __restrict__ f, long n, float coef, float* __restrict__ g) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) g[i] += coef * f[i] * (th[i] - ts[i]);
+}
+
+template <int MODE>  // 0 square, 1 accumulate, 2 ema
+__global__ __launch_bounds__(NT) void fisher_kernel(const float* __restrict__ g, float* __restrict__ f, long n, float unscale,
+                                                    float a) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float x = g[i] * unscale, sq = x * x;
+        if (MODE == 0) f[i] = sq;
+        else if (MODE == 1) f[i] += a * sq;
+        else f[i] = a * sq + (1.f - a) * f[i];
+    }
+}
+
+__global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ g, long n, float unscale, double* out2) {
+    __shared__ float sm[2 * (NT / 64)];
+    float acc[2] = {0.f, 0.f};
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float x = g[i] * unscale;
+        if (!isfinite(x)) acc[1] += 1.f; else acc[0] += x * x;
+    }
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { atomicAdd(out2, (double)acc[0]); atomicAdd(out2 + 1, (double)acc[1]); }
+}
+
+// torch.optim.SGD(nesterov=True, dampening=0): g += wd*theta; buf = g (first) | mu*buf + g; theta -= lr*(g + mu*buf)
+__global__ __launch_bounds__(NT) void sgd_kernel(float* __restrict__ th, float* __restrict__ buf, const float* __restrict__ g,
+                                                 long n, float lr, float mu, float wd, float gs, int first) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float t = th[i];
+        const float d = g[i] * gs + wd * t;
+        const float b = first ? d : mu * buf[i] + d;
+        buf[i] = b;
+        th[i] = t - lr * (d + mu * b);
+    }
+}
+
+__global__ __launch_bounds__(NT) void cast_kernel(const float* __restrict__ s, half_t* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) d[i] = (half_t)s[i];
+}
+}  // namespace
+
+extern "C" size_t lnn_packed_weight_elems(int ntaps, int M, int KC) {
+    return (size_t)ntaps * lnn_round_up(M, 32) * lnn_round_up(KC, 16);
+}
+
+extern "C" int lnn_pack_weights(lnn_stream_t s_, const float* src, void* dst, int ntaps, int M, int KC, long sm, long skc,
+                                long st) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(src && dst && lnn_aligned16(dst), "lnn_pack_weights: null/misaligned pointer");
+    LNN_REQUIRE(ntaps > 0 && M > 0 && KC > 0, "lnn_pack_weights: bad dims");
+    const int Mpad = lnn_round_up(M, 32), KCpad = lnn_round_up(KC, 16);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(flat_blocks((long)ntaps * Mpad * KCpad, 4)), dim3(NT), 0, s, src,
+                       (half_t*)dst, ntaps, M, KC, Mpad, KCpad, sm, skc, st);
+    LNN_CHECK_LAUNCH("lnn_pack_weights");
+    return LNN_OK;
+}
+
+extern "C" int lnn_unpack_wgrad(lnn_stream_t s_, const float* dwp, float* dst, int ntaps, int M, int KC, long sm, long skc,
+                                long st, float scale, int accumulate) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(dwp && dst, "lnn_unpack_wgrad: null pointer");
+    const int Mpad = lnn_round_up(M, 32), KCpad = lnn_round_up(KC, 32);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(flat_blocks((long)ntaps * M * KC, 4)), dim3(NT), 0, s, dwp, dst, ntaps, M,
+                       KC, Mpad, KCpad, sm, skc, st, scale, accumulate);
+    LNN_CHECK_LAUNCH("lnn_unpack_wgrad");
+    return LNN_OK;
+}
+
+extern "C" int lnn_ewc_penalty_fwd(lnn_stream_t s_, const float* theta, const float* theta_star, const float* fisher, long n,
+                                   float lambda, float* out, double* ws) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(theta && theta_star && fisher && out && ws, "lnn_ewc_penalty_fwd: null pointer");
+    LNN_REQUIRE(lnn_aligned16(theta) && lnn_aligned16(theta_star) && lnn_aligned16(fisher), "lnn_ewc_penalty_fwd: arenas must be 16-byte aligned");
+    hipMemsetAsync(ws, 0, sizeof(double), s);
+    hipLaunchKernelGGL(ewc_fwd_kernel, dim3(flat_blocks(n, 16)), dim3(NT), 0, s, theta, theta_star, fisher, n, ws);
+    LNN_CHECK_LAUNCH("lnn_ewc_penalty_fwd");
+    hipLaunchKernelGGL(ewc_finalize_kernel, dim3(1), dim3(64), 0, s, ws, lambda, out);
+    LNN_CHECK_LAUNCH("lnn_ewc_penalty_fwd(finalize)");
+    return LNN_OK;
+}
+
+extern "C" int lnn_ewc_penalty_bwd(lnn_stream_t s_, const float* theta, const float* theta_star, const float* fisher, long n,
+                                   float lambda, float gscale, float* grad) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(theta && theta_star && fisher && grad, "lnn_ewc_penalty_bwd: null pointer");
+    hipLaunchKernelGGL(ewc_bwd_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, theta_star, fisher, n, lambda * gscale, grad);
+    LNN_CHECK_LAUNCH("lnn_ewc_penalty_bwd");
+    return LNN_OK;
+}
+
+extern "C" int lnn_fisher_square(lnn_stream_t s_, const float* grad, float* fisher, long n, float unscale) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(grad && fisher, "lnn_fisher_square: null pointer");
+    hipLaunchKernelGGL((fisher_kernel<0>), dim3(flat_blocks(n, 8)), dim3(NT), 0, s, grad, fisher, n, unscale, 0.f);
+    LNN_CHECK_LAUNCH("lnn_fisher_square");
+    return LNN_OK;
+}
+extern "C" int lnn_fisher_accumulate(lnn_stream_t s_, const float* grad, float* fisher, long n, float unscale, float weight) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(grad && fisher, "lnn_fisher_accumulate: null pointer");
+    hipLaunchKernelGGL((fisher_kernel<1>), dim3(flat_blocks(n, 8)), dim3(NT), 0, s, grad, fisher, n, unscale, weight);
+    LNN_CHECK_LAUNCH("lnn_fisher_accumulate");
+    return LNN_OK;
+}
+extern "C" int lnn_fisher_ema(lnn_stream_t s_, const float* grad, float* fisher, long n, float unscale, float alpha) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(grad && fisher, "lnn_fisher_ema: null pointer");
+    hipLaunchKernelGGL((fisher_kernel<2>), dim3(flat_blocks(n, 8)), dim3(NT), 0, s, grad, fisher, n, unscale, alpha);
+    LNN_CHECK_LAUNCH("lnn_fisher_ema");
+    return LNN_OK;
+}
+
+extern "C" int lnn_gradnorm_sumsq(lnn_stream_t s_, const float* grad, long n, float unscale, double* out2) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(grad && out2, "lnn_gradnorm_sumsq: null pointer");
+    hipMemsetAsync(out2, 0, 2 * sizeof(double), s);
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(flat_blocks(n, 16)), dim3(NT), 0, s, grad, n, unscale, out2);
+    LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq");
+    return LNN_OK;
+}
+
+extern "C" int lnn_sgd_nesterov_step(lnn_stream_t s_, float* theta, float* buf, const float* grad, long n, float lr,
+                                     float momentum, float weight_decay, float grad_scale, int first_step) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(theta && buf && grad, "lnn_sgd_nesterov_step: null pointer");
+    hipLaunchKernelGGL(sgd_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, buf, grad, n, lr, momentum, weight_decay,
+                       grad_scale, first_step);
+    LNN_CHECK_LAUNCH("lnn_sgd_nesterov_step");
+    return LNN_OK;
+}
+
+extern "C" int lnn_cast_f32_to_h(lnn_stream_t s_, const float* src, void* dst, long n) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(src && dst, "lnn_cast_f32_to_h: null pointer");
+    hipLaunchKernelGGL(cast_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, src, (half_t*)dst, n);
+    LNN_CHECK_LAUNCH("lnn_cast_f32_to_h");
+    return LNN_OK;
+}

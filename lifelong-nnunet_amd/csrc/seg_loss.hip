@@ -1,0 +1,387 @@
+// Segmentation head (1x1x1 conv) and the loss-side reductions: fused softmax + soft-Dice + CE for one
+// deep-supervision level (forward statistics, backward dlogits), hard Dice counts, LwF distillation KL.
+// All HBM-bound: one pass over the logits per kernel, fp32 math, fp64 cross-block accumulation.
+#include "lnn_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int KMAX = 8;  // logit channels held in registers
+
+// ---------------------------------------------------------------------------------------- seg 1x1x1
+__global__ __launch_bounds__(NT) void seg_fwd_kernel(const half_t* __restrict__ z, int ld_z, const float* __restrict__ w,
+                                                     float* __restrict__ logits, long V, int C, int K) {
+    extern __shared__ float wl[];  // [K][C]
+    for (int i = threadIdx.x; i < K * C; i += NT) wl[i] = w[i];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const half_t* zn = z + (long)n * V * ld_z;
+    float* ln = logits + (long)n * K * V;
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        float acc[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+        for (int c = 0; c < C; c += 8) {
+            const half8 x = *reinterpret_cast<const half8*>(zn + v * ld_z + c);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[k] += (float)x[e] * wl[k * C + c + e];
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) ln[(long)k * V + v] = acc[k];
+    }
+}
+
+// thread = (voxel lane, channel octet): dz = sum_k dl[k] w[k][c]; dw[k][c] partials in registers.
+template <int KG>
+__global__ __launch_bounds__(NT) void seg_bwd_kernel(const half_t* __restrict__ z, int ld_z, const float* __restrict__ w,
+                                                     const float* __restrict__ dl, half_t* __restrict__ dz, int ld_dz,
+                                                     float* __restrict__ dw, long V, int C, int K, int k0, int write_dz,
+                                                     int accumulate_dz, float unscale) {
+    __shared__ float red[NT * (KG * 8 + 1)];
+    const int C8 = C >> 3, VPB = NT / C8, c8 = threadIdx.x % C8, vl = threadIdx.x / C8;
+    const bool active = vl < VPB;
+    const int n = blockIdx.y;
+    float part[KG][8];
+#pragma unroll
+    for (int k = 0; k < KG; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[k][e] = 0.f;
+    if (active) {
+        float wr[KMAX][8];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wr[k][e] = k < K ? w[k * C + c8 * 8 + e] : 0.f;
+        const half_t* zn = z + (long)n * V * ld_z;
+        half_t* dzn = dz + (long)n * V * ld_dz;
+        const float* dln = dl + (long)n * K * V;
+        for (long v = (long)blockIdx.x * VPB + vl; v < V; v += (long)gridDim.x * VPB) {
+            float d[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) d[k] = k < K ? dln[(long)k * V + v] : 0.f;
+            const half8 x = *reinterpret_cast<const half8*>(zn + v * ld_z + c8 * 8);
+#pragma unroll
+            for (int k = 0; k < KG; ++k)
+                if (k0 + k < K) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) part[k][e] += d[k0 + k] * (float)x[e];
+                }
+            if (write_dz) {
+                half8* dst = reinterpret_cast<half8*>(dzn + v * ld_dz + c8 * 8);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) o[e] += d[k] * wr[k][e];
+                }
+                if (accumulate_dz) {
+                    const half8 old = *dst;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += (float)old[e];
+                }
+                half8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (half_t)o[e];
+                *dst = ov;
+            }
+        }
+    }
+    constexpr int W = KG * 8 + 1;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < KG; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x * W + k * 8 + e] = part[k][e];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < KG * C; o += NT) {
+        const int k = o / C, c = o % C;
+        if (k0 + k >= K) continue;
+        float s = 0.f;
+        for (int l = 0; l < VPB; ++l) s += red[(l * C8 + (c >> 3)) * W + k * 8 + (c & 7)];
+        atomicAdd(dw + (long)(k0 + k) * C + c, s * unscale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- Dice + CE
+__device__ __forceinline__ void softmax_k(const float* __restrict__ ln, long V, long v, int K, float inv_t, float (&p)[KMAX],
+                                          float& lse, float (&x)[KMAX]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+            x[k] = ln[(long)k * V + v] * inv_t;
+            mx = fmaxf(mx, x[k]);
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+            p[k] = expf(x[k] - mx);
+            s += p[k];
+        }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) p[k] *= inv;
+    lse = mx + logf(s);
+}
+
+// ws: [N][K][3] (tp, fp, fn) then [1] ce sum
+__global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                         int K, long V, double* ws, int N) {
+    __shared__ float sm[(3 * KMAX + 1) * (NT / 64)];
+    const int n = blockIdx.y;
+    const float* ln = logits + (long)n * K * V;
+    const float* yn = labels + (long)n * V;
+    float acc[3 * KMAX + 1];
+#pragma unroll
+    for (int i = 0; i < 3 * KMAX + 1; ++i) acc[i] = 0.f;
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        float p[KMAX], x[KMAX], lse;
+        softmax_k(ln, V, v, K, 1.f, p, lse, x);
+        const int lab = (int)yn[v];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const float y = (k == lab) ? 1.f : 0.f;
+                acc[k * 3 + 0] += p[k] * y;
+                acc[k * 3 + 1] += p[k] * (1.f - y);
+                acc[k * 3 + 2] += (1.f - p[k]) * y;
+                if (k == lab) acc[3 * KMAX] += lse - x[k];
+            }
+    }
+    block_sum<3 * KMAX + 1>(acc, sm);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < 3; ++j) atomicAdd(ws + ((long)n * K + k) * 3 + j, (double)acc[k * 3 + j]);
+        atomicAdd(ws + (long)N * K * 3, (double)acc[3 * KMAX]);
+    }
+}
+
+__global__ void dice_ce_finalize_kernel(const double* ws, int N, int K, long V, int batch_dice, float smooth, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double dc_sum = 0;
+    int cnt = 0;
+    if (batch_dice) {
+        for (int k = 1; k < K; ++k) {
+            double tp = 0, fp = 0, fn = 0;
+            for (int n = 0; n < N; ++n) {
+                tp += ws[((long)n * K + k) * 3]; fp += ws[((long)n * K + k) * 3 + 1]; fn += ws[((long)n * K + k) * 3 + 2];
+            }
+            dc_sum += (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8);
+            ++cnt;
+        }
+    } else {
+        for (int n = 0; n < N; ++n)
+            for (int k = 1; k < K; ++k) {
+                const double tp = ws[((long)n * K + k) * 3], fp = ws[((long)n * K + k) * 3 + 1], fn = ws[((long)n * K + k) * 3 + 2];
+                dc_sum += (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8);
+                ++cnt;
+            }
+    }
+    const double ce = ws[(long)N * K * 3] / ((double)N * (double)V);
+    out[0] = (float)(ce - dc_sum / (cnt > 0 ? cnt : 1));
+}
+
+__global__ __launch_bounds__(NT) void dice_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                         int N, int K, long V, int batch_dice, float smooth,
+                                                         const double* __restrict__ ws, float gscale,
+                                                         float* __restrict__ dlogits) {
+    __shared__ float al[KMAX], be[KMAX];
+    const int n = blockIdx.y;
+    if (threadIdx.x < KMAX) {
+        const int k = threadIdx.x;
+        float a = 0.f, b = 0.f;
+        if (k >= 1 && k < K) {
+            double tp = 0, fp = 0, fn = 0;
+            if (batch_dice) {
+                for (int m = 0; m < N; ++m) {
+                    tp += ws[((long)m * K + k) * 3]; fp += ws[((long)m * K + k) * 3 + 1]; fn += ws[((long)m * K + k) * 3 + 2];
+                }
+            } else {
+                tp = ws[((long)n * K + k) * 3]; fp = ws[((long)n * K + k) * 3 + 1]; fn = ws[((long)n * K + k) * 3 + 2];
+            }
+            const double cnt = batch_dice ? (double)(K - 1) : (double)N * (K - 1);
+            const double num = 2 * tp + smooth, den = 2 * tp + fp + fn + smooth + 1e-8;
+            a = (float)(-2.0 / (cnt * den));
+            b = (float)(num / (cnt * den * den));
+        }
+        al[k] = a; be[k] = b;
+    }
+    __syncthreads();
+    const float* ln = logits + (long)n * K * V;
+    const float* yn = labels + (long)n * V;
+    float* dn = dlogits + (long)n * K * V;
+    const float inv_nv = 1.f / ((float)N * (float)V);
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        float p[KMAX], x[KMAX], lse;
+        softmax_k(ln, V, v, K, 1.f, p, lse, x);
+        const int lab = (int)yn[v];
+        float a[KMAX], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                a[k] = (k == lab ? al[k] : 0.f) + be[k];
+                dot += a[k] * p[k];
+            }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const float y = (k == lab) ? 1.f : 0.f;
+                dn[(long)k * V + v] = gscale * ((p[k] - y) * inv_nv + p[k] * (a[k] - dot));
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- hard Dice
+__global__ __launch_bounds__(NT) void online_dice_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                         int K, long V, float* counts) {
+    __shared__ float sm[3 * (KMAX - 1) * (NT / 64)];
+    const int n = blockIdx.y;
+    const float* ln = logits + (long)n * K * V;
+    const float* yn = labels + (long)n * V;
+    float acc[3 * (KMAX - 1)];
+#pragma unroll
+    for (int i = 0; i < 3 * (KMAX - 1); ++i) acc[i] = 0.f;
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        int best = 0;
+        float bv = ln[v];
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k)
+            if (k < K) {
+                const float x = ln[(long)k * V + v];
+                if (x > bv) { bv = x; best = k; }
+            }
+        const int lab = (int)yn[v];
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k)
+            if (k < K) {
+                acc[(k - 1) * 3 + 0] += (best == k && lab == k) ? 1.f : 0.f;
+                acc[(k - 1) * 3 + 1] += (best == k && lab != k) ? 1.f : 0.f;
+                acc[(k - 1) * 3 + 2] += (best != k && lab == k) ? 1.f : 0.f;
+            }
+    }
+    block_sum<3 * (KMAX - 1)>(acc, sm);
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 3 * (K - 1); ++i) atomicAdd(counts + (long)n * (K - 1) * 3 + i, acc[i]);
+}
+
+// ---------------------------------------------------------------------------------------- LwF KL
+__global__ __launch_bounds__(NT) void kl_logits_kernel(const float* __restrict__ pred, const float* __restrict__ teach, int K,
+                                                       long V, float inv_t, double* ws) {
+    __shared__ float sm[NT / 64];
+    const int n = blockIdx.y;
+    const float* pn = pred + (long)n * K * V;
+    const float* tn = teach + (long)n * K * V;
+    float acc[1] = {0.f};
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        float pt[KMAX], xt[KMAX], lse_t, py[KMAX], xy[KMAX], lse_y;
+        softmax_k(tn, V, v, K, inv_t, pt, lse_t, xt);
+        softmax_k(pn, V, v, K, inv_t, py, lse_y, xy);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) acc[0] += pt[k] * ((xt[k] - lse_t) - (xy[k] - lse_y));
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(ws, (double)acc[0]);
+}
+__global__ void kl_finalize_kernel(const double* ws, int N, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(ws[0] / (double)N);
+}
+
+int vox_blocks(long V) {
+    long b = (V + NT * 8 - 1) / (NT * 8);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int lnn_seg1x1_fwd(lnn_stream_t s_, const void* z, int ld_z, const float* w, float* logits, int N, long V, int C,
+                              int K) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(z && lnn_aligned16(z) && w && logits, "lnn_seg1x1_fwd: null/misaligned pointer");
+    LNN_REQUIRE(C % 8 == 0 && ld_z >= C && ld_z % 8 == 0, "lnn_seg1x1_fwd: bad channel count / ld");
+    LNN_REQUIRE(K >= 1 && K <= KMAX, "lnn_seg1x1_fwd: K=%d unsupported (max %d)", K, KMAX);
+    hipLaunchKernelGGL(seg_fwd_kernel, dim3(vox_blocks(V), N), dim3(NT), (size_t)K * C * sizeof(float), s,
+                       (const half_t*)z, ld_z, w, logits, V, C, K);
+    LNN_CHECK_LAUNCH("lnn_seg1x1_fwd");
+    return LNN_OK;
+}
+
+extern "C" int lnn_seg1x1_bwd(lnn_stream_t s_, const void* z, int ld_z, const float* w, const float* dlogits, void* dz,
+                              int ld_dz, float* dw, int N, long V, int C, int K, int accumulate_dz, float grad_unscale) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(z && lnn_aligned16(z) && w && dlogits && dz && lnn_aligned16(dz) && dw, "lnn_seg1x1_bwd: null/misaligned pointer");
+    LNN_REQUIRE(C % 8 == 0 && C <= 2048 && ld_z >= C && ld_z % 8 == 0 && ld_dz >= C && ld_dz % 8 == 0, "lnn_seg1x1_bwd: bad channel count / ld");
+    LNN_REQUIRE(K >= 1 && K <= KMAX, "lnn_seg1x1_bwd: K=%d unsupported (max %d)", K, KMAX);
+    const int vpb = NT / (C / 8);
+    long b = (V + (long)vpb * 8 - 1) / ((long)vpb * 8);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        hipLaunchKernelGGL((seg_bwd_kernel<4>), dim3((int)b, N), dim3(NT), 0, s, (const half_t*)z, ld_z, w, dlogits,
+                           (half_t*)dz, ld_dz, dw, V, C, K, k0, k0 == 0 ? 1 : 0, accumulate_dz, grad_unscale);
+        LNN_CHECK_LAUNCH("lnn_seg1x1_bwd");
+    }
+    return LNN_OK;
+}
+
+extern "C" size_t lnn_dice_ce_ws_doubles(int N, int K) { return (size_t)N * K * 3 + 2; }
+
+extern "C" int lnn_dice_ce_fwd(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
+                               int batch_dice, float smooth, float* out_loss, double* ws) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(logits && labels && out_loss && ws, "lnn_dice_ce_fwd: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
+    hipMemsetAsync(ws, 0, sizeof(double) * lnn_dice_ce_ws_doubles(N, K), s);
+    hipLaunchKernelGGL(dice_ce_fwd_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, K, V, ws, N);
+    LNN_CHECK_LAUNCH("lnn_dice_ce_fwd");
+    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(64), 0, s, ws, N, K, V, batch_dice, smooth, out_loss);
+    LNN_CHECK_LAUNCH("lnn_dice_ce_fwd(finalize)");
+    return LNN_OK;
+}
+
+extern "C" int lnn_dice_ce_bwd(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
+                               int batch_dice, float smooth, const double* ws, float gscale, float* dlogits) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(logits && labels && dlogits && ws, "lnn_dice_ce_bwd: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_bwd: K=%d unsupported (2..%d)", K, KMAX);
+    hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, N, K, V, batch_dice,
+                       smooth, ws, gscale, dlogits);
+    LNN_CHECK_LAUNCH("lnn_dice_ce_bwd");
+    return LNN_OK;
+}
+
+extern "C" int lnn_online_dice_counts(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
+                                      float* counts) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(logits && labels && counts, "lnn_online_dice_counts: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_online_dice_counts: K=%d unsupported (2..%d)", K, KMAX);
+    hipMemsetAsync(counts, 0, sizeof(float) * N * (K - 1) * 3, s);
+    hipLaunchKernelGGL(online_dice_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, K, V, counts);
+    LNN_CHECK_LAUNCH("lnn_online_dice_counts");
+    return LNN_OK;
+}
+
+extern "C" int lnn_kl_logits(lnn_stream_t s_, const float* pred, const float* teach, int N, int K, long V, float T,
+                             float* out, double* ws) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(pred && teach && out && ws, "lnn_kl_logits: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX && T > 0.f, "lnn_kl_logits: K=%d / T unsupported", K);
+    hipMemsetAsync(ws, 0, sizeof(double), s);
+    hipLaunchKernelGGL(kl_logits_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, pred, teach, K, V, 1.f / T, ws);
+    LNN_CHECK_LAUNCH("lnn_kl_logits");
+    hipLaunchKernelGGL(kl_finalize_kernel, dim3(1), dim3(64), 0, s, ws, N, out);
+    LNN_CHECK_LAUNCH("lnn_kl_logits(finalize)");
+    return LNN_OK;
+}

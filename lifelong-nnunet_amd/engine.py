@@ -1,0 +1,391 @@
+"""Static launch plan for the 3-D Generic_UNet training step on one MI355X.
+
+The network the reference trains (upstream ``Generic_UNet`` as configured at
+nnViTUNetTrainer.py:101-125; forward restated at generic_ViT_UNet.py:222-230,261-286) is a fixed
+sequence of ops for a fixed patch size, so the build runs it as a *plan*: a list of C-ABI launches over
+pre-allocated channels-last fp16 buffers in HBM, enqueued on one HIP stream (graph-capturable).
+
+HBM layout
+  * parameters theta, gradients G, momentum: three flat fp32 arenas, laid out in FORWARD EXECUTION order
+    (so gradient buckets complete back-to-front during backward, see parallel.py); every
+    ``nn.Parameter`` of the host module is a view into theta, every ``.grad`` a view into G.
+  * activations: NDHWC fp16.  Per ConvDropoutNormNonlin block: ``y`` (conv output, later overwritten
+    in place by dL/dy) and ``z`` (normalised + LeakyReLU output).  Skip connections and transposed-conv
+    outputs are written straight into the decoder's concat buffer (channel stride 2*C), which removes
+    ``torch.cat`` (generic_ViT_UNet.py:263) from the path.
+  * fp16 weight panels for the MFMA kernels (forward and dgrad orientation), re-packed from theta when
+    the parameters change; fp32 weight-gradient panels (one arena, zeroed once per backward).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import native as nat
+
+LRELU_SLOPE = 1e-2
+IN_EPS = 1e-5
+
+
+class Act:
+    """A channels-last fp16 activation living at a channel offset inside a (possibly wider) buffer."""
+
+    def __init__(self, buf: torch.Tensor, off: int, C: int):
+        self.buf, self.off, self.C = buf, off, C
+        self.ld = buf.shape[-1]
+        self.N = buf.shape[0]
+        self.dims = tuple(buf.shape[1:4])
+        self.V = self.dims[0] * self.dims[1] * self.dims[2]
+
+    def data_ptr(self):
+        return self.buf.data_ptr() + 2 * self.off
+
+    def tensor(self):
+        return self.buf[..., self.off:self.off + self.C]
+
+
+@dataclass
+class ParamSlot:
+    name: str
+    shape: tuple
+    offset: int = 0
+
+    @property
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+@dataclass
+class ConvBlock:
+    """conv3x3x3(+bias) -> InstanceNorm(affine) -> LeakyReLU (ConvDropoutNormNonlin, dropout p=0 omitted)."""
+    prefix: str
+    cin: int
+    cout: int
+    stride: int
+    x: Optional[Act] = None        # input activation (None -> the fp16 image, C == 1 path)
+    gx: Optional[Act] = None       # gradient wrt input (None -> not needed)
+    gx_accumulate: bool = False
+    y: Optional[torch.Tensor] = None
+    z: Optional[Act] = None
+    gz: Optional[Act] = None
+    mean: Optional[torch.Tensor] = None
+    rstd: Optional[torch.Tensor] = None
+    w: ParamSlot = None
+    b: ParamSlot = None
+    gamma: ParamSlot = None
+    beta: ParamSlot = None
+    wp_fwd: int = 0
+    wp_dgrad: int = 0
+    panel: int = 0
+    in_dims: tuple = ()
+
+
+@dataclass
+class UpBlock:
+    """ConvTranspose3d k2 s2, no bias (``tu``)."""
+    prefix: str
+    cin: int
+    cout: int
+    x: Act = None
+    gx: Act = None
+    y: Act = None
+    gy: Act = None
+    w: ParamSlot = None
+    wp_fwd: int = 0
+    wp_dgrad: int = 0
+    panel: int = 0
+
+
+@dataclass
+class SegHead:
+    prefix: str
+    cin: int
+    x: Act = None
+    gx: Act = None
+    gx_has_prior: bool = False     # a transposed-conv dgrad already wrote gx -> accumulate
+    w: ParamSlot = None
+
+
+@dataclass
+class Plan:
+    fwd: List[object] = field(default_factory=list)
+
+
+def _cl(N, dims, C, device):
+    return torch.zeros((N,) + tuple(dims) + (C,), dtype=torch.float16, device=device)
+
+
+class UNetEngine:
+    def __init__(self, in_channels, base_features, num_classes, num_pool, patch_size, batch_size,
+                 device="cuda", max_features=320, conv_per_stage=2):
+        assert conv_per_stage == 2, "nnUNetTrainerV2 uses conv_per_stage=2 (nnViTUNetTrainer.py:119)"
+        assert in_channels == 1, "the build's image path handles single-modality input (BASELINE configs)"
+        assert base_features % 8 == 0, "channel counts must be multiples of 8 (16-byte vectors)"
+        for p in patch_size:
+            assert p % (2 ** num_pool) == 0, "patch size must be divisible by 2^num_pool"
+        self.in_channels, self.base, self.K, self.num_pool = in_channels, base_features, num_classes, num_pool
+        self.patch, self.N, self.device = tuple(patch_size), batch_size, torch.device(device)
+        self.max_features = max_features
+        dev, N = self.device, batch_size
+
+        feats = [min(base_features * 2 ** d, max_features) for d in range(num_pool + 1)]
+        dims = [tuple(p // 2 ** d for p in patch_size) for d in range(num_pool + 1)]
+        self.feats, self.dims = feats, dims
+
+        # ---- concat buffers (one per decoder level u; level u sits at encoder depth d = num_pool-1-u)
+        self.cat, self.gcat = [], []
+        for u in range(num_pool):
+            d = num_pool - 1 - u
+            self.cat.append(_cl(N, dims[d], 2 * feats[d], dev))
+            self.gcat.append(_cl(N, dims[d], 2 * feats[d], dev))
+
+        self.image = torch.zeros((N,) + dims[0], dtype=torch.float16, device=dev)
+        self.params: List[ParamSlot] = []
+        self.blocks: List[ConvBlock] = []
+        self.ups: List[UpBlock] = []
+        self.segs: List[SegHead] = []
+        order: List[object] = []     # forward execution order
+
+        def new_block(prefix, cin, cout, stride, x, gx, gx_acc, z_target, gz_target, in_dims):
+            od = tuple((s - 1) // stride + 1 for s in in_dims)
+            blk = ConvBlock(prefix, cin, cout, stride, x=x, gx=gx, gx_accumulate=gx_acc, in_dims=in_dims)
+            blk.y = _cl(N, od, cout, dev)
+            if z_target is None:
+                zb, gzb = _cl(N, od, cout, dev), _cl(N, od, cout, dev)
+                blk.z, blk.gz = Act(zb, 0, cout), Act(gzb, 0, cout)
+            else:
+                blk.z, blk.gz = z_target, gz_target
+            blk.mean = torch.zeros(N * cout, device=dev)
+            blk.rstd = torch.zeros(N * cout, device=dev)
+            blk.w = ParamSlot(prefix + ".conv.weight", (cout, cin, 3, 3, 3))
+            blk.b = ParamSlot(prefix + ".conv.bias", (cout,))
+            blk.gamma = ParamSlot(prefix + ".instnorm.weight", (cout,))
+            blk.beta = ParamSlot(prefix + ".instnorm.bias", (cout,))
+            self.params += [blk.w, blk.b, blk.gamma, blk.beta]
+            self.blocks.append(blk)
+            order.append(blk)
+            return blk
+
+        # ---- encoder
+        x, gx = None, None
+        cin = in_channels
+        for d in range(num_pool):
+            u = num_pool - 1 - d
+            skip = Act(self.cat[u], feats[d], feats[d])
+            gskip = Act(self.gcat[u], feats[d], feats[d])
+            in_dims = dims[d - 1] if d > 0 else dims[0]
+            b0 = new_block(f"conv_blocks_context.{d}.blocks.0", cin, feats[d], 2 if d > 0 else 1,
+                           x, gx, d > 0, None, None, in_dims)
+            b1 = new_block(f"conv_blocks_context.{d}.blocks.1", feats[d], feats[d], 1, b0.z, b0.gz, False,
+                           skip, gskip, dims[d])
+            x, gx, cin = b1.z, b1.gz, feats[d]
+        # ---- bottleneck: Sequential(Stacked(1 strided conv), Stacked(1 conv))  (test_MultiHead_Module.py:394-415)
+        nb = num_pool
+        b0 = new_block(f"conv_blocks_context.{nb}.0.blocks.0", cin, feats[nb], 2, x, gx, True, None, None, dims[nb - 1])
+        b1 = new_block(f"conv_blocks_context.{nb}.1.blocks.0", feats[nb], feats[nb], 1, b0.z, b0.gz, False, None, None,
+                       dims[nb])
+        x, gx, cdown = b1.z, b1.gz, feats[nb]
+        # ---- decoder
+        for u in range(num_pool):
+            d = num_pool - 1 - u
+            cs = feats[d]
+            up = UpBlock(f"tu.{u}", cdown, cs, x=x, gx=gx, y=Act(self.cat[u], 0, cs), gy=Act(self.gcat[u], 0, cs))
+            up.w = ParamSlot(f"tu.{u}.weight", (cdown, cs, 2, 2, 2))
+            self.params.append(up.w)
+            self.ups.append(up)
+            order.append(up)
+            cat_act, gcat_act = Act(self.cat[u], 0, 2 * cs), Act(self.gcat[u], 0, 2 * cs)
+            b0 = new_block(f"conv_blocks_localization.{u}.0.blocks.0", 2 * cs, cs, 1, cat_act, gcat_act, False,
+                           None, None, dims[d])
+            b1 = new_block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, 1, b0.z, b0.gz, False, None, None, dims[d])
+            seg = SegHead(f"seg_outputs.{u}", cs, x=b1.z, gx=b1.gz, gx_has_prior=(u < num_pool - 1))
+            seg.w = ParamSlot(f"seg_outputs.{u}.weight", (num_classes, cs, 1, 1, 1))
+            self.params.append(seg.w)
+            self.segs.append(seg)
+            order.append(seg)
+            x, gx, cdown = b1.z, b1.gz, cs
+        self.order = order
+
+        # ---- flat arenas (16-byte aligned slots)
+        off = 0
+        for p in self.params:
+            p.offset = off
+            off += (p.numel + 3) // 4 * 4
+        self.n_params_padded = off
+        self.theta = torch.zeros(off, device=dev)
+        self.grad = torch.zeros(off, device=dev)
+        self.momentum = torch.zeros(off, device=dev)
+        self.slot = {p.name: p for p in self.params}
+
+        # ---- fp16 weight panels + fp32 wgrad panels
+        wp_off, pn_off = 0, 0
+        for item in order:
+            if isinstance(item, ConvBlock):
+                if item.cin == 1:
+                    item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 1, item.cout, 27)
+                    item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", 1, item.cout, 27)
+                else:
+                    item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 27, item.cout, item.cin)
+                    item.wp_dgrad = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 27, item.cin, item.cout)
+                    item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", 27, item.cout, item.cin)
+            elif isinstance(item, UpBlock):
+                item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 8, item.cout, item.cin)
+                item.wp_dgrad = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 8, item.cin, item.cout)
+                item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", 8, item.cin, item.cout)
+            wp_off = (wp_off + 7) // 8 * 8
+            pn_off = (pn_off + 3) // 4 * 4
+        self.wpanels = torch.zeros(wp_off, dtype=torch.float16, device=dev)
+        self.gpanels = torch.zeros(pn_off, device=dev)
+        cmax = max(2 * f for f in feats)
+        self.ws = torch.zeros(max(nat.query("lnn_instnorm_ws_doubles", N, cmax), 64), dtype=torch.float64, device=dev)
+        self.packed = False
+        self.frozen_prefixes: tuple = ()
+
+    # ------------------------------------------------------------------------------------------ views
+    def pview(self, slot: ParamSlot, arena=None):
+        a = self.theta if arena is None else arena
+        return a[slot.offset:slot.offset + slot.numel].view(slot.shape)
+
+    def _wp(self, off):
+        return _Ptr(self.wpanels, off)
+
+    def _pn(self, off):
+        return _Ptr(self.gpanels, off)
+
+    # ------------------------------------------------------------------------------------------ pack
+    def pack_weights(self):
+        for item in self.order:
+            if isinstance(item, ConvBlock):
+                w = self.pview(item.w)
+                K, C = item.cout, item.cin
+                if C == 1:
+                    nat.call("lnn_pack_weights", w, self._wp(item.wp_fwd), 1, K, 27, 27, 1, 0)
+                else:
+                    nat.call("lnn_pack_weights", w, self._wp(item.wp_fwd), 27, K, C, C * 27, 27, 1)
+                    nat.call("lnn_pack_weights", w, self._wp(item.wp_dgrad), 27, C, K, 27, C * 27, 1)
+            elif isinstance(item, UpBlock):
+                w = self.pview(item.w)
+                C, K = item.cin, item.cout
+                nat.call("lnn_pack_weights", w, self._wp(item.wp_fwd), 8, K, C, 8, K * 8, 1)
+                nat.call("lnn_pack_weights", w, self._wp(item.wp_dgrad), 8, C, K, K * 8, 8, 1)
+        self.packed = True
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, seg_weights: Optional[List[torch.Tensor]] = None, body: bool = True):
+        """x: (N,1,D,H,W) float32 on the device.  Returns logits per decoder level u (low-res first, as
+        ``seg_outputs`` is indexed upstream), fp32 (N,K,d,h,w).  ``seg_weights`` overrides the seg-head
+        parameters (used to evaluate several heads on one body pass); ``body=False`` reuses the stored
+        body activations."""
+        N = self.N
+        assert tuple(x.shape) == (N, 1) + self.patch, f"engine built for {(N, 1) + self.patch}, got {tuple(x.shape)}"
+        if not self.packed:
+            self.pack_weights()
+        logits = []
+        if body:
+            nat.call("lnn_cast_f32_to_h", x.contiguous(), self.image, x.numel())
+        for item in self.order:
+            if isinstance(item, ConvBlock):
+                if not body:
+                    continue
+                D, H, W = item.in_dims
+                xin = self.image if item.x is None else item.x
+                ldx = 1 if item.x is None else item.x.ld
+                nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), item.y, item.cout,
+                         N, D, H, W, item.cin, item.cout, item.stride)
+                V = item.z.V
+                nat.call("lnn_instnorm_stats", item.y, N, V, item.cout, IN_EPS, item.mean, item.rstd, self.ws)
+                nat.call("lnn_instnorm_lrelu_fwd", item.y, item.z, item.z.ld, N, V, item.cout, item.mean, item.rstd,
+                         self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE)
+            elif isinstance(item, UpBlock):
+                if not body:
+                    continue
+                D, H, W = item.x.dims
+                nat.call("lnn_convT3d_k2s2_fwd", item.x, item.x.ld, self._wp(item.wp_fwd), item.y, item.y.ld,
+                         N, D, H, W, item.cin, item.cout)
+            else:
+                u = len(logits)
+                w = self.pview(item.w) if seg_weights is None else seg_weights[u]
+                out = torch.empty((N, self.K) + item.x.dims, device=self.device)
+                nat.call("lnn_seg1x1_fwd", item.x, item.x.ld, w.contiguous(), out, N, item.x.V, item.cin, self.K)
+                logits.append(out)
+        return logits
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, dlogits: List[Optional[torch.Tensor]], skip_body: bool = False):
+        """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.
+        Accumulates parameter gradients into the flat arena ``self.grad`` (scaled like dlogits)."""
+        N = self.N
+        self.gpanels.zero_()
+        seg_u = len(self.segs)
+        for item in reversed(self.order):
+            if isinstance(item, SegHead):
+                seg_u -= 1
+                dl = dlogits[seg_u]
+                if dl is None:
+                    if not item.gx_has_prior:
+                        item.gx.buf.zero_()
+                    continue
+                gw = self.pview(item.w, self.grad).view(self.K, item.cin)
+                nat.call("lnn_seg1x1_bwd", item.x, item.x.ld, self.pview(item.w), dl.contiguous(), item.gx, item.gx.ld,
+                         gw, N, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0)
+            elif skip_body:
+                continue
+            elif isinstance(item, ConvBlock):
+                V = item.z.V
+                nat.call("lnn_instnorm_lrelu_bwd", item.y, item.gz, item.gz.ld, N, V, item.cout, item.mean, item.rstd,
+                         self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                         self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
+                         self.pview(item.b, self.grad), 1.0, self.ws)
+                D, H, W = item.in_dims
+                xin = self.image if item.x is None else item.x
+                ldx = 1 if item.x is None else item.x.ld
+                K, C = item.cout, item.cin
+                nat.call("lnn_conv3d_wgrad", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K, item.stride)
+                gw = self.pview(item.w, self.grad)
+                if C == 1:
+                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 1, K, 27, 27, 1, 0, 1.0, 1)
+                else:
+                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 27, K, C, C * 27, 27, 1, 1.0, 1)
+                    if item.gx is not None:
+                        nat.call("lnn_conv3d_dgrad", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld, N, D, H, W,
+                                 C, K, item.stride, 1 if item.gx_accumulate else 0)
+            else:  # UpBlock
+                D, H, W = item.x.dims
+                C, K = item.cin, item.cout
+                nat.call("lnn_convT3d_k2s2_wgrad", item.x, item.x.ld, item.gy, item.gy.ld, self._pn(item.panel),
+                         N, D, H, W, C, K)
+                nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), 8, C, K, K * 8, 8, 1, 1.0, 1)
+                nat.call("lnn_convT3d_k2s2_dgrad", item.gy, item.gy.ld, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
+                         N, D, H, W, C, K, 0)
+
+    # ------------------------------------------------------------------------------------------ stats
+    def flops_per_patch(self):
+        """Algorithmic conv-stack FLOPs of one training patch: 6*MAC_fwd - 2*MAC(first layer)."""
+        mac = 0
+        first = 0
+        for item in self.order:
+            if isinstance(item, ConvBlock):
+                m = item.z.V * item.cin * item.cout * 27
+                mac += m
+                if item.x is None:
+                    first = m
+            elif isinstance(item, UpBlock):
+                mac += item.x.V * item.cin * item.cout * 8
+            else:
+                mac += item.x.V * item.cin * self.K
+        return 6 * mac - 2 * first, mac
+
+
+class _Ptr:
+    """Element-offset pointer into a flat tensor (for the ctypes layer)."""
+
+    def __init__(self, t, off):
+        self.t, self.off = t, off
+
+    def data_ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()

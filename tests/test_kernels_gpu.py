@@ -1,0 +1,286 @@
+"""Kernel-level parity tests (-m gpu): every C-ABI entry of liblnn_hip.so against the plain PyTorch
+CPU fp32 op the reference reaches.  Inputs are pre-rounded to fp16
+so the only differences are accumulation order (fp32) and the fp16 rounding of the stored output;
+tolerances below are stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_utils import (DEV, View, from_cl_h, pack_conv_dgrad, pack_conv_fwd, pack_convT_dgrad,  # noqa: E402
+                             pack_convT_fwd, q16, rel_err, to_cl_h)
+from lifelong_nnunet_amd import native as nat  # noqa: E402
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return q16(torch.randn(shape, generator=g) * scale)
+
+
+def test_tr16_lane_mapping():
+    """ds_read_b64_tr_b16 with lane-linear addresses: within each 16-lane group the 16x4 block is
+    transposed: lane i receives elements {i + 16 j} of the group's 64-half block (j = 0..3)."""
+    out = torch.zeros(256, device=DEV)
+    nat.call("lnn_debug_tr16_probe", out)
+    got = out.cpu().view(64, 4)
+    exp = torch.zeros(64, 4)
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        for j in range(4):
+            exp[lane, j] = g * 64 + i + 16 * j
+    print("tr16 probe rows 0..17:\n", got[:18])
+    assert torch.equal(got, exp)
+
+
+CONV_CASES = [
+    # N, C, K, D, H, W, stride
+    (2, 32, 32, 8, 16, 8, 1),
+    (1, 16, 64, 5, 9, 11, 1),
+    (1, 8, 8, 4, 8, 8, 1),
+    (1, 64, 32, 6, 10, 9, 1),
+    (1, 48, 96, 4, 8, 8, 1),
+    (2, 32, 64, 8, 16, 8, 2),
+    (1, 16, 32, 7, 9, 11, 2),
+    (1, 64, 128, 6, 6, 6, 2),
+]
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W,s", CONV_CASES)
+def test_conv3d_fwd(N, C, K, D, H, W, s):
+    x = _rand((N, C, D, H, W), 1)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3))
+    ref = F.conv3d(x, w, b, stride=s, padding=1)
+    xb, xv = to_cl_h(x, ld=C + 8, offset=8)
+    Do, Ho, Wo = ref.shape[2:]
+    yb = torch.full((N, Do, Ho, Wo, K + 16), 7.0, dtype=torch.float16, device=DEV)
+    wp = pack_conv_fwd(w.to(DEV))
+    nat.call("lnn_conv3d_fwd", View(xb, 8), C + 8, wp, b.to(DEV), View(yb, 16), K + 16, N, D, H, W, C, K, s)
+    got = from_cl_h(yb, K, 16)
+    assert rel_err(got, ref) < 2e-3          # fp16 output rounding (2^-11) + fp32 accumulation order
+    assert torch.all(yb[..., :16] == 7.0)    # channel-offset view untouched outside [16, 16+K)
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W,s", CONV_CASES)
+@pytest.mark.parametrize("acc", [0, 1])
+def test_conv3d_dgrad(N, C, K, D, H, W, s, acc):
+    x = _rand((N, C, D, H, W), 1).requires_grad_(True)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1)
+    y = F.conv3d(x, w, None, stride=s, padding=1)
+    dy = _rand(y.shape, 4)
+    y.backward(dy)
+    ref = x.grad
+    dyb, _ = to_cl_h(dy)
+    base = _rand((N, C, D, H, W), 5)
+    dxb, _ = to_cl_h(base, ld=C + 8)
+    wp = pack_conv_dgrad(w.to(DEV))
+    nat.call("lnn_conv3d_dgrad", dyb, K, wp, dxb, C + 8, N, D, H, W, C, K, s, acc)
+    got = from_cl_h(dxb, C)
+    exp = ref + base if acc else ref
+    assert rel_err(got, exp) < 3e-3
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W,s", CONV_CASES)
+def test_conv3d_wgrad(N, C, K, D, H, W, s):
+    x = _rand((N, C, D, H, W), 1)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1).requires_grad_(True)
+    y = F.conv3d(x, w, None, stride=s, padding=1)
+    dy = _rand(y.shape, 4)
+    y.backward(dy)
+    xb, _ = to_cl_h(x)
+    dyb, _ = to_cl_h(dy)
+    panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 27, K, C), device=DEV)
+    nat.call("lnn_conv3d_wgrad", xb, C, dyb, K, panel, N, D, H, W, C, K, s)
+    dw = torch.full((K, C, 3, 3, 3), 1.0, device=DEV)
+    nat.call("lnn_unpack_wgrad", panel, dw, 27, K, C, C * 27, 27, 1, 0.5, 1)
+    assert rel_err(dw.cpu(), 1.0 + 0.5 * w.grad) < 1e-3   # fp32 accumulate of fp16 products
+
+
+@pytest.mark.parametrize("N,K,D,H,W", [(2, 32, 8, 16, 8), (1, 8, 5, 9, 11), (1, 64, 4, 8, 8)])
+def test_conv3d_first_layer(N, K, D, H, W):
+    x = _rand((N, 1, D, H, W), 1)
+    w = _rand((K, 1, 3, 3, 3), 2, 0.3).requires_grad_(True)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3))
+    ref = F.conv3d(x, w, b, padding=1)
+    dy = _rand(ref.shape, 4)
+    ref.backward(dy)
+    xh = x[:, 0].to(DEV).half().contiguous()
+    yb = torch.zeros((N, D, H, W, K), dtype=torch.float16, device=DEV)
+    wp = torch.zeros(nat.query("lnn_packed_weight_elems", 1, K, 27), dtype=torch.float16, device=DEV)
+    nat.call("lnn_pack_weights", w.detach().to(DEV), wp, 1, K, 27, 27, 1, 0)
+    nat.call("lnn_conv3d_fwd", xh, 1, wp, b.to(DEV), yb, K, N, D, H, W, 1, K, 1)
+    assert rel_err(from_cl_h(yb, K), ref.detach()) < 2e-3
+    dyb, _ = to_cl_h(dy)
+    panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 1, K, 27), device=DEV)
+    nat.call("lnn_conv3d_wgrad", xh, 1, dyb, K, panel, N, D, H, W, 1, K, 1)
+    dw = torch.zeros((K, 1, 3, 3, 3), device=DEV)
+    nat.call("lnn_unpack_wgrad", panel, dw, 1, K, 27, 27, 1, 0, 1.0, 0)
+    assert rel_err(dw.cpu(), w.grad) < 1e-3
+
+
+CONVT_CASES = [(2, 64, 32, 4, 8, 4), (1, 16, 8, 3, 5, 6), (1, 320, 320, 2, 3, 2), (1, 32, 64, 4, 8, 8)]
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W", CONVT_CASES)
+def test_convT_fwd_dgrad_wgrad(N, C, K, D, H, W):
+    x = _rand((N, C, D, H, W), 1).requires_grad_(True)
+    w = _rand((C, K, 2, 2, 2), 2, 0.1).requires_grad_(True)
+    ref = F.conv_transpose3d(x, w, None, stride=2)
+    dy = _rand(ref.shape, 4)
+    ref.backward(dy)
+    xb, _ = to_cl_h(x.detach())
+    wd = w.detach().to(DEV)
+    yb = torch.zeros((N, 2 * D, 2 * H, 2 * W, 2 * K), dtype=torch.float16, device=DEV)
+    nat.call("lnn_convT3d_k2s2_fwd", xb, C, pack_convT_fwd(wd), yb, 2 * K, N, D, H, W, C, K)
+    assert rel_err(from_cl_h(yb, K), ref.detach()) < 2e-3
+    assert torch.all(yb[..., K:] == 0)
+    dyb, _ = to_cl_h(dy)
+    dxb = torch.zeros((N, D, H, W, C), dtype=torch.float16, device=DEV)
+    nat.call("lnn_convT3d_k2s2_dgrad", dyb, K, pack_convT_dgrad(wd), dxb, C, N, D, H, W, C, K, 0)
+    assert rel_err(from_cl_h(dxb, C), x.grad) < 3e-3
+    panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 8, C, K), device=DEV)
+    nat.call("lnn_convT3d_k2s2_wgrad", xb, C, dyb, K, panel, N, D, H, W, C, K)
+    dw = torch.zeros((C, K, 2, 2, 2), device=DEV)
+    nat.call("lnn_unpack_wgrad", panel, dw, 8, C, K, K * 8, 8, 1, 1.0, 0)
+    assert rel_err(dw.cpu(), w.grad) < 1e-3
+
+
+@pytest.mark.parametrize("N,C,D,H,W", [(2, 32, 8, 16, 8), (1, 8, 5, 9, 11), (2, 320, 3, 4, 3), (1, 64, 16, 16, 16)])
+def test_instnorm_lrelu_fwd_bwd(N, C, D, H, W):
+    y = _rand((N, C, D, H, W), 1) * 2 + 0.5
+    y = q16(y).requires_grad_(True)
+    g = torch.Generator().manual_seed(9)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    z = F.leaky_relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    dz = _rand(z.shape, 4)
+    z.backward(dz)
+    V = D * H * W
+    yb, _ = to_cl_h(y.detach())
+    mean = torch.empty(N * C, device=DEV); rstd = torch.empty(N * C, device=DEV)
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, C), dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", yb, N, V, C, 1e-5, mean, rstd, ws)
+    yf = y.detach()
+    assert rel_err(mean.cpu().view(N, C), yf.mean((2, 3, 4))) < 1e-5
+    assert rel_err(rstd.cpu().view(N, C), 1 / torch.sqrt(yf.var((2, 3, 4), unbiased=False) + 1e-5)) < 1e-5
+    zb = torch.zeros((N, D, H, W, C + 8), dtype=torch.float16, device=DEV)
+    nat.call("lnn_instnorm_lrelu_fwd", yb, zb, C + 8, N, V, C, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV), 0.01)
+    assert rel_err(from_cl_h(zb, C), z.detach()) < 2e-3
+    dzb, _ = to_cl_h(dz, ld=C + 8)
+    dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV); dbias = torch.zeros(C, device=DEV)
+    nat.call("lnn_instnorm_lrelu_bwd", yb, dzb, C + 8, N, V, C, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV),
+             0.01, dg, db, dbias, 0.5, ws)
+    assert rel_err(from_cl_h(yb, C), y.grad) < 3e-3          # dy written in place over y
+    assert rel_err(dg.cpu(), 0.5 * gamma.grad) < 1e-3
+    assert rel_err(db.cpu(), 0.5 * beta.grad) < 1e-3
+    # conv-bias gradient = sum_v dy (~0 analytically after IN backward; only fp16 rounding remains)
+    assert float(dbias.abs().max()) <= 2e-3 * float(y.grad.abs().sum((0, 2, 3, 4)).max())
+
+
+@pytest.mark.parametrize("N,C,K,V3", [(2, 32, 3, (8, 16, 8)), (1, 8, 2, (5, 9, 11)), (1, 320, 3, (3, 4, 3)), (1, 64, 5, (4, 8, 8))])
+def test_seg1x1_fwd_bwd(N, C, K, V3):
+    z = _rand((N, C) + V3, 1).requires_grad_(True)
+    w = (torch.randn((K, C, 1, 1, 1), generator=torch.Generator().manual_seed(2)) * 0.2).requires_grad_(True)
+    ref = F.conv3d(z, w)
+    dl = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+    ref.backward(dl)
+    V = V3[0] * V3[1] * V3[2]
+    zb, _ = to_cl_h(z.detach())
+    wd = w.detach().view(K, C).contiguous().to(DEV)
+    logits = torch.zeros((N, K) + V3, device=DEV)
+    nat.call("lnn_seg1x1_fwd", zb, C, wd, logits, N, V, C, K)
+    assert rel_err(logits.cpu(), ref.detach()) < 1e-5
+    base = _rand((N, C) + V3, 7)
+    dzb, _ = to_cl_h(base)
+    dw = torch.zeros((K, C), device=DEV)
+    nat.call("lnn_seg1x1_bwd", zb, C, wd, dl.to(DEV), dzb, C, dw, N, V, C, K, 1, 2.0)
+    assert rel_err(from_cl_h(dzb, C), z.grad + base) < 3e-3
+    assert rel_err(dw.cpu(), 2.0 * w.grad.view(K, C)) < 1e-4
+
+
+@pytest.mark.parametrize("batch_dice", [0, 1])
+@pytest.mark.parametrize("N,K,V3", [(2, 3, (8, 16, 8)), (3, 2, (5, 9, 11)), (1, 5, (4, 8, 8))])
+def test_dice_ce_fwd_bwd(N, K, V3, batch_dice):
+    from oracle import losses
+    g = torch.Generator().manual_seed(1)
+    logits = (torch.randn((N, K) + V3, generator=g) * 2).requires_grad_(True)
+    labels = torch.randint(0, K, (N, 1) + V3, generator=g).float()
+    if K > 2:
+        labels[0][labels[0] == K - 1] = 0      # an empty foreground class in sample 0
+    ref = losses.dc_and_ce_loss(logits, labels, bool(batch_dice))
+    ref.backward()
+    V = V3[0] * V3[1] * V3[2]
+    lg, lb = logits.detach().to(DEV), labels.to(DEV)
+    ws = torch.zeros(nat.query("lnn_dice_ce_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    out = torch.zeros(1, device=DEV)
+    nat.call("lnn_dice_ce_fwd", lg, lb, N, K, V, batch_dice, 1e-5, out, ws)
+    assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))       # north_star: 1e-4 relative loss
+    dl = torch.zeros_like(lg)
+    nat.call("lnn_dice_ce_bwd", lg, lb, N, K, V, batch_dice, 1e-5, ws, 3.0, dl)
+    assert rel_err(dl.cpu(), 3.0 * logits.grad) < 1e-4
+
+
+def test_dice_ce_golden(golden_dir):
+    d = np.load(golden_dir + "/dice_ce.npz")
+    lg = torch.from_numpy(d["logits"]).to(DEV); lb = torch.from_numpy(d["target"]).to(DEV)
+    N, K = lg.shape[:2]; V = lg[0, 0].numel()
+    ws = torch.zeros(nat.query("lnn_dice_ce_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    out = torch.zeros(1, device=DEV)
+    for bd, key in ((0, "loss_sample_dice"), (1, "loss_batch_dice")):
+        nat.call("lnn_dice_ce_fwd", lg, lb, N, K, V, bd, 1e-5, out, ws)
+        assert abs(float(out) - float(d[key])) <= 1e-5 * abs(float(d[key]))
+    counts = torch.zeros((N, K - 1, 3), device=DEV)
+    nat.call("lnn_online_dice_counts", lg, lb, N, K, V, counts)
+    c = counts.cpu().numpy()
+    assert np.array_equal(c[:, :, 0], d["tp"]) and np.array_equal(c[:, :, 1], d["fp"]) and np.array_equal(c[:, :, 2], d["fn"])
+
+
+def test_kl_logits_golden(golden_dir):
+    d = np.load(golden_dir + "/lwf_reference.npz")
+    for T in (1, 2):
+        for i in range(2):
+            p = torch.from_numpy(d[f"pred_{i}"]).to(DEV); t = torch.from_numpy(d[f"teach_{i}"]).to(DEV)
+            N, K = p.shape[:2]; V = p[0, 0].numel()
+            out = torch.zeros(1, device=DEV); ws = torch.zeros(1, dtype=torch.float64, device=DEV)
+            nat.call("lnn_kl_logits", p, t, N, K, V, float(T), out, ws)
+            exp = float(d[f"kl{i}_T{T}"])
+            assert abs(float(out) - exp) <= 1e-5 * abs(exp)
+
+
+def test_param_kernels():
+    n = 1_000_003
+    g = torch.Generator().manual_seed(1)
+    th, ts, f, gr = (torch.randn(n, generator=g) for _ in range(4))
+    f = f.abs()
+    thd, tsd, fd, grd = th.to(DEV), ts.to(DEV), f.to(DEV), gr.to(DEV)
+    out = torch.zeros(1, device=DEV); ws = torch.zeros(2, dtype=torch.float64, device=DEV)
+    nat.call("lnn_ewc_penalty_fwd", thd, tsd, fd, n, 0.4, out, ws)
+    exp = 0.2 * (f.double() * (th.double() - ts.double()) ** 2).sum()
+    assert abs(float(out) - float(exp)) <= 1e-6 * float(exp)
+    g2 = grd.clone()
+    nat.call("lnn_ewc_penalty_bwd", thd, tsd, fd, n, 0.4, 2.0, g2)
+    assert rel_err(g2.cpu(), gr + 2.0 * 0.4 * f * (th - ts)) < 1e-6
+    fo = torch.zeros(n, device=DEV)
+    nat.call("lnn_fisher_square", grd, fo, n, 0.5)
+    assert rel_err(fo.cpu(), (0.5 * gr) ** 2) < 1e-6
+    nat.call("lnn_fisher_accumulate", grd, fo, n, 1.0, 0.25)
+    assert rel_err(fo.cpu(), (0.5 * gr) ** 2 + 0.25 * gr ** 2) < 1e-6
+    nat.call("lnn_fisher_ema", grd, fo, n, 1.0, 0.1)
+    assert rel_err(fo.cpu(), 0.1 * gr ** 2 + 0.9 * ((0.5 * gr) ** 2 + 0.25 * gr ** 2)) < 1e-6
+    nat.call("lnn_gradnorm_sumsq", grd, n, 0.5, ws)
+    assert abs(float(ws[0]) - float((0.5 * gr.double()).pow(2).sum())) <= 1e-6 * float(ws[0])
+    assert float(ws[1]) == 0
+    bad = grd.clone(); bad[5] = float("inf"); bad[7] = float("nan")
+    nat.call("lnn_gradnorm_sumsq", bad, n, 1.0, ws)
+    assert float(ws[1]) == 2
+    # two SGD-Nesterov steps against torch.optim.SGD
+    p = torch.nn.Parameter(th.clone())
+    opt = torch.optim.SGD([p], 1e-2, momentum=0.99, nesterov=True, weight_decay=3e-5)
+    buf = torch.zeros(n, device=DEV); thg = thd.clone()
+    for step in range(2):
+        p.grad = gr * (step + 1)
+        opt.step()
+        nat.call("lnn_sgd_nesterov_step", thg, buf, grd * (step + 1) * 4.0, n, 1e-2, 0.99, 3e-5, 0.25, 1 if step == 0 else 0)
+    assert rel_err(thg.cpu(), p.detach()) < 1e-6
