@@ -132,7 +132,8 @@ int lnn_seg1x1_bwd(lnn_stream_t s, const void* z_h, int ld_z, const float* w, co
 int lnn_dice_ce_fwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
                     int batch_dice, float smooth, float* out_loss, double* ws);
 int lnn_dice_ce_bwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
-                    int batch_dice, float smooth, const double* ws, float gscale, float* dlogits);
+                    int batch_dice, float smooth, const double* ws, float gscale, const float* gscale_dev,
+                    float* dlogits);  /* gscale_dev (may be NULL): one device float multiplied into gscale */
 size_t lnn_dice_ce_ws_doubles(int N, int K);
 
 /* argmax + per-sample hard TP/FP/FN for the foreground classes (nnUNetTrainerMultiHead.py:938-951).
@@ -159,12 +160,13 @@ int lnn_kl_logits(lnn_stream_t s, const float* pred, const float* teach, int N, 
 int lnn_ewc_penalty_fwd(lnn_stream_t s, const float* theta, const float* theta_star, const float* fisher,
                         long n, float lambda, float* out, double* ws);
 int lnn_ewc_penalty_bwd(lnn_stream_t s, const float* theta, const float* theta_star, const float* fisher,
-                        long n, float lambda, float gscale, float* grad);
+                        long n, float lambda, float gscale, const float* gscale_dev, float* grad);
 int lnn_fisher_square(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale);
 int lnn_fisher_accumulate(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale, float weight);
 int lnn_fisher_ema(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale, float alpha);
-/* out[0] = sum (g*unscale)^2 (double), out[1] = number of non-finite elements (double) ; ws >= 2 doubles */
-int lnn_gradnorm_sumsq(lnn_stream_t s, const float* grad, long n, float unscale, double* out2);
+/* out2[0] += sum (g*unscale)^2 (double), out2[1] += number of non-finite elements (double);
+ * zero_first != 0 clears out2 before (several arena ranges can accumulate into one pair) */
+int lnn_gradnorm_sumsq(lnn_stream_t s, const float* grad, long n, float unscale, double* out2, int zero_first);
 int lnn_sgd_nesterov_step(lnn_stream_t s, float* theta, float* momentum_buf, const float* grad, long n,
                           float lr, float momentum, float weight_decay, float grad_scale, int first_step);
 
@@ -172,6 +174,13 @@ int lnn_sgd_nesterov_step(lnn_stream_t s, float* theta, float* momentum_buf, con
  * holding its own half-index; out[lane*4+j] (float) = value received.  Used by tests to pin the
  * hardware transpose-read lane mapping the wgrad kernels rely on. */
 int lnn_debug_tr16_probe(lnn_stream_t s, float* out256);
+
+/* as above with the unscale / clip coefficient / inf-skip decision taken ON DEVICE from ctrl = out2 of
+ * lnn_gradnorm_sumsq: coef = min(1, max_norm/(sqrt(ctrl[0])+1e-6)); ctrl[1] > 0 skips the step
+ * (GradScaler.step + clip_grad_norm_, nnUNetTrainerMultiHead.py:627-631).  momentum_buf must start zeroed. */
+int lnn_sgd_nesterov_step_clipped(lnn_stream_t s, float* theta, float* momentum_buf, const float* grad, long n,
+                                  float lr, float momentum, float weight_decay, float inv_scale, float max_norm,
+                                  const double* ctrl);
 
 /* fp32 <-> fp16 helpers for the image input (N,1,D,H,W f32 -> fp16, same memory order when C == 1) */
 int lnn_cast_f32_to_h(lnn_stream_t s, const float* src, void* dst_h, long n);

@@ -5,3 +5,18 @@ on PyTorch-ROCm (device memory, streams, torch.distributed) calling hand-written
 through the C-ABI library declared in ``include/lnn_hip.h``.
 """
 __version__ = "0.1.0"
+
+# plugin surface: same class names / module layout as nnunet_ext/training/network_training/<ext>/ (run_training.py:18-28)
+TRAINER_MAP = {
+    "multihead": "lifelong_nnunet_amd.training.network_training.multihead.nnUNetTrainerMultiHead:nnUNetTrainerMultiHead",
+    "sequential": "lifelong_nnunet_amd.training.network_training.sequential.nnUNetTrainerSequential:nnUNetTrainerSequential",
+    "ewc": "lifelong_nnunet_amd.training.network_training.ewc.nnUNetTrainerEWC:nnUNetTrainerEWC",
+    "lwf": "lifelong_nnunet_amd.training.network_training.lwf.nnUNetTrainerLWF:nnUNetTrainerLWF",
+    "rehearsal": "lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal:nnUNetTrainerRehearsal",
+}
+
+
+def get_trainer_class(extension):
+    import importlib
+    mod, cls = TRAINER_MAP[extension].split(":")
+    return getattr(importlib.import_module(mod), cls)

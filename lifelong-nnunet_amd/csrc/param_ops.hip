@@ -80,7 +80,9 @@ __global__ void ewc_finalize_kernel(const double* ws, float lambda, float* out) 
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(0.5 * (double)lambda * ws[0]);
 }
 __global__ __launch_bounds__(NT) void ewc_bwd_kernel(const float* __restrict__ th, const float* __restrict__ ts,
-                                                     const float* __restrict__ f, long n, float coef, float* __restrict__ g) {
+                                                     const float* __restrict__ f, long n, float coef,
+                                                     const float* __restrict__ coef_dev, float* __restrict__ g) {
+    if (coef_dev) coef *= coef_dev[0];
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) g[i] += coef * f[i] * (th[i] - ts[i]);
 }
 
@@ -113,6 +115,28 @@ __global__ __launch_bounds__(NT) void sgd_kernel(float* __restrict__ th, float* 
         const float t = th[i];
         const float d = g[i] * gs + wd * t;
         const float b = first ? d : mu * buf[i] + d;
+        buf[i] = b;
+        th[i] = t - lr * (d + mu * b);
+    }
+}
+
+// Same update, but unscale / clip factor / skip decision come from device memory (no host sync):
+//   ctrl[0] = sum (g*inv_scale)^2, ctrl[1] = #non-finite  (lnn_gradnorm_sumsq)
+//   coef = min(1, max_norm / (sqrt(ctrl[0]) + 1e-6))   (torch.nn.utils.clip_grad_norm_, MH.py:629)
+//   any non-finite gradient -> the whole step is skipped (GradScaler.step semantics, MH.py:630)
+__global__ __launch_bounds__(NT) void sgd_clipped_kernel(float* __restrict__ th, float* __restrict__ buf,
+                                                         const float* __restrict__ g, long n, float lr, float mu, float wd,
+                                                         float inv_scale, float max_norm, const double* __restrict__ ctrl) {
+    if (ctrl[1] > 0.0) return;
+    float gs = inv_scale;
+    if (max_norm > 0.f) {
+        const float coef = max_norm / ((float)sqrt(ctrl[0]) + 1e-6f);
+        if (coef < 1.f) gs *= coef;
+    }
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float t = th[i];
+        const float d = g[i] * gs + wd * t;
+        const float b = mu * buf[i] + d;
         buf[i] = b;
         th[i] = t - lr * (d + mu * b);
     }
@@ -164,10 +188,11 @@ extern "C" int lnn_ewc_penalty_fwd(lnn_stream_t s_, const float* theta, const fl
 }
 
 extern "C" int lnn_ewc_penalty_bwd(lnn_stream_t s_, const float* theta, const float* theta_star, const float* fisher, long n,
-                                   float lambda, float gscale, float* grad) {
+                                   float lambda, float gscale, const float* gscale_dev, float* grad) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(theta && theta_star && fisher && grad, "lnn_ewc_penalty_bwd: null pointer");
-    hipLaunchKernelGGL(ewc_bwd_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, theta_star, fisher, n, lambda * gscale, grad);
+    hipLaunchKernelGGL(ewc_bwd_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, theta_star, fisher, n, lambda * gscale,
+                       gscale_dev, grad);
     LNN_CHECK_LAUNCH("lnn_ewc_penalty_bwd");
     return LNN_OK;
 }
@@ -194,10 +219,10 @@ extern "C" int lnn_fisher_ema(lnn_stream_t s_, const float* grad, float* fisher,
     return LNN_OK;
 }
 
-extern "C" int lnn_gradnorm_sumsq(lnn_stream_t s_, const float* grad, long n, float unscale, double* out2) {
+extern "C" int lnn_gradnorm_sumsq(lnn_stream_t s_, const float* grad, long n, float unscale, double* out2, int zero_first) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(grad && out2, "lnn_gradnorm_sumsq: null pointer");
-    hipMemsetAsync(out2, 0, 2 * sizeof(double), s);
+    if (zero_first) hipMemsetAsync(out2, 0, 2 * sizeof(double), s);
     hipLaunchKernelGGL(gradnorm_kernel, dim3(flat_blocks(n, 16)), dim3(NT), 0, s, grad, n, unscale, out2);
     LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq");
     return LNN_OK;
@@ -210,6 +235,17 @@ extern "C" int lnn_sgd_nesterov_step(lnn_stream_t s_, float* theta, float* buf, 
     hipLaunchKernelGGL(sgd_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, buf, grad, n, lr, momentum, weight_decay,
                        grad_scale, first_step);
     LNN_CHECK_LAUNCH("lnn_sgd_nesterov_step");
+    return LNN_OK;
+}
+
+extern "C" int lnn_sgd_nesterov_step_clipped(lnn_stream_t s_, float* theta, float* buf, const float* grad, long n, float lr,
+                                             float momentum, float weight_decay, float inv_scale, float max_norm,
+                                             const double* ctrl) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(theta && buf && grad && ctrl, "lnn_sgd_nesterov_step_clipped: null pointer");
+    hipLaunchKernelGGL(sgd_clipped_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, buf, grad, n, lr, momentum,
+                       weight_decay, inv_scale, max_norm, ctrl);
+    LNN_CHECK_LAUNCH("lnn_sgd_nesterov_step_clipped");
     return LNN_OK;
 }
 

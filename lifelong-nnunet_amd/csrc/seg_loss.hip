@@ -194,8 +194,10 @@ __global__ void dice_ce_finalize_kernel(const double* ws, int N, int K, long V, 
 __global__ __launch_bounds__(NT) void dice_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                          int N, int K, long V, int batch_dice, float smooth,
                                                          const double* __restrict__ ws, float gscale,
+                                                         const float* __restrict__ gscale_dev,
                                                          float* __restrict__ dlogits) {
     __shared__ float al[KMAX], be[KMAX];
+    if (gscale_dev) gscale *= gscale_dev[0];
     const int n = blockIdx.y;
     if (threadIdx.x < KMAX) {
         const int k = threadIdx.x;
@@ -352,12 +354,13 @@ extern "C" int lnn_dice_ce_fwd(lnn_stream_t s_, const float* logits, const float
 }
 
 extern "C" int lnn_dice_ce_bwd(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
-                               int batch_dice, float smooth, const double* ws, float gscale, float* dlogits) {
+                               int batch_dice, float smooth, const double* ws, float gscale, const float* gscale_dev,
+                               float* dlogits) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(logits && labels && dlogits && ws, "lnn_dice_ce_bwd: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_bwd: K=%d unsupported (2..%d)", K, KMAX);
     hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, N, K, V, batch_dice,
-                       smooth, ws, gscale, dlogits);
+                       smooth, ws, gscale, gscale_dev, dlogits);
     LNN_CHECK_LAUNCH("lnn_dice_ce_bwd");
     return LNN_OK;
 }

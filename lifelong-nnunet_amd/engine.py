@@ -120,12 +120,61 @@ def _cl(N, dims, C, device):
     return torch.zeros((N,) + tuple(dims) + (C,), dtype=torch.float16, device=device)
 
 
+class ParamArena:
+    """Flat fp32 parameter / gradient / momentum arenas, slots in forward execution order."""
+
+    def __init__(self, slots: List[ParamSlot], device):
+        off = 0
+        for p in slots:
+            p.offset = off
+            off += (p.numel + 3) // 4 * 4          # 16-byte aligned slots
+        self.slots = slots
+        self.by_name = {p.name: p for p in slots}
+        self.size = off
+        self.theta = torch.zeros(off, device=device)
+        self.grad = torch.zeros(off, device=device)
+        self.momentum = torch.zeros(off, device=device)
+        self.version = 0                            # bumped whenever theta changes (re-pack trigger)
+
+    def view(self, name_or_slot, which="theta"):
+        s = self.by_name[name_or_slot] if isinstance(name_or_slot, str) else name_or_slot
+        return getattr(self, which)[s.offset:s.offset + s.numel].view(s.shape)
+
+
+def param_slots(in_channels, base_features, num_classes, num_pool, max_features=320) -> List[ParamSlot]:
+    """Parameter tensors of Generic_UNet in FORWARD EXECUTION order (names as test_MultiHead_Module.py:282-431)."""
+    feats = [min(base_features * 2 ** d, max_features) for d in range(num_pool + 1)]
+    out = []
+
+    def block(prefix, cin, cout):
+        out.extend([ParamSlot(prefix + ".conv.weight", (cout, cin, 3, 3, 3)), ParamSlot(prefix + ".conv.bias", (cout,)),
+                    ParamSlot(prefix + ".instnorm.weight", (cout,)), ParamSlot(prefix + ".instnorm.bias", (cout,))])
+
+    cin = in_channels
+    for d in range(num_pool):
+        block(f"conv_blocks_context.{d}.blocks.0", cin, feats[d])
+        block(f"conv_blocks_context.{d}.blocks.1", feats[d], feats[d])
+        cin = feats[d]
+    block(f"conv_blocks_context.{num_pool}.0.blocks.0", cin, feats[num_pool])
+    block(f"conv_blocks_context.{num_pool}.1.blocks.0", feats[num_pool], feats[num_pool])
+    cdown = feats[num_pool]
+    for u in range(num_pool):
+        cs = feats[num_pool - 1 - u]
+        out.append(ParamSlot(f"tu.{u}.weight", (cdown, cs, 2, 2, 2)))
+        block(f"conv_blocks_localization.{u}.0.blocks.0", 2 * cs, cs)
+        block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs)
+        out.append(ParamSlot(f"seg_outputs.{u}.weight", (num_classes, cs, 1, 1, 1)))
+        cdown = cs
+    return out
+
+
 class UNetEngine:
-    def __init__(self, in_channels, base_features, num_classes, num_pool, patch_size, batch_size,
+    def __init__(self, arena: ParamArena, in_channels, base_features, num_classes, num_pool, patch_size, batch_size,
                  device="cuda", max_features=320, conv_per_stage=2):
         assert conv_per_stage == 2, "nnUNetTrainerV2 uses conv_per_stage=2 (nnViTUNetTrainer.py:119)"
         assert in_channels == 1, "the build's image path handles single-modality input (BASELINE configs)"
         assert base_features % 8 == 0, "channel counts must be multiples of 8 (16-byte vectors)"
+        self.arena = arena
         for p in patch_size:
             assert p % (2 ** num_pool) == 0, "patch size must be divisible by 2^num_pool"
         self.in_channels, self.base, self.K, self.num_pool = in_channels, base_features, num_classes, num_pool
@@ -145,7 +194,6 @@ class UNetEngine:
             self.gcat.append(_cl(N, dims[d], 2 * feats[d], dev))
 
         self.image = torch.zeros((N,) + dims[0], dtype=torch.float16, device=dev)
-        self.params: List[ParamSlot] = []
         self.blocks: List[ConvBlock] = []
         self.ups: List[UpBlock] = []
         self.segs: List[SegHead] = []
@@ -162,11 +210,11 @@ class UNetEngine:
                 blk.z, blk.gz = z_target, gz_target
             blk.mean = torch.zeros(N * cout, device=dev)
             blk.rstd = torch.zeros(N * cout, device=dev)
-            blk.w = ParamSlot(prefix + ".conv.weight", (cout, cin, 3, 3, 3))
-            blk.b = ParamSlot(prefix + ".conv.bias", (cout,))
-            blk.gamma = ParamSlot(prefix + ".instnorm.weight", (cout,))
-            blk.beta = ParamSlot(prefix + ".instnorm.bias", (cout,))
-            self.params += [blk.w, blk.b, blk.gamma, blk.beta]
+            blk.w = arena.by_name[prefix + ".conv.weight"]
+            blk.b = arena.by_name[prefix + ".conv.bias"]
+            blk.gamma = arena.by_name[prefix + ".instnorm.weight"]
+            blk.beta = arena.by_name[prefix + ".instnorm.bias"]
+            assert blk.w.shape == (cout, cin, 3, 3, 3)
             self.blocks.append(blk)
             order.append(blk)
             return blk
@@ -195,8 +243,7 @@ class UNetEngine:
             d = num_pool - 1 - u
             cs = feats[d]
             up = UpBlock(f"tu.{u}", cdown, cs, x=x, gx=gx, y=Act(self.cat[u], 0, cs), gy=Act(self.gcat[u], 0, cs))
-            up.w = ParamSlot(f"tu.{u}.weight", (cdown, cs, 2, 2, 2))
-            self.params.append(up.w)
+            up.w = arena.by_name[f"tu.{u}.weight"]
             self.ups.append(up)
             order.append(up)
             cat_act, gcat_act = Act(self.cat[u], 0, 2 * cs), Act(self.gcat[u], 0, 2 * cs)
@@ -204,23 +251,13 @@ class UNetEngine:
                            None, None, dims[d])
             b1 = new_block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, 1, b0.z, b0.gz, False, None, None, dims[d])
             seg = SegHead(f"seg_outputs.{u}", cs, x=b1.z, gx=b1.gz, gx_has_prior=(u < num_pool - 1))
-            seg.w = ParamSlot(f"seg_outputs.{u}.weight", (num_classes, cs, 1, 1, 1))
-            self.params.append(seg.w)
+            seg.w = arena.by_name[f"seg_outputs.{u}.weight"]
             self.segs.append(seg)
             order.append(seg)
             x, gx, cdown = b1.z, b1.gz, cs
         self.order = order
 
-        # ---- flat arenas (16-byte aligned slots)
-        off = 0
-        for p in self.params:
-            p.offset = off
-            off += (p.numel + 3) // 4 * 4
-        self.n_params_padded = off
-        self.theta = torch.zeros(off, device=dev)
-        self.grad = torch.zeros(off, device=dev)
-        self.momentum = torch.zeros(off, device=dev)
-        self.slot = {p.name: p for p in self.params}
+        self.theta, self.grad = arena.theta, arena.grad
 
         # ---- fp16 weight panels + fp32 wgrad panels
         wp_off, pn_off = 0, 0
@@ -243,8 +280,13 @@ class UNetEngine:
         self.gpanels = torch.zeros(pn_off, device=dev)
         cmax = max(2 * f for f in feats)
         self.ws = torch.zeros(max(nat.query("lnn_instnorm_ws_doubles", N, cmax), 64), dtype=torch.float64, device=dev)
-        self.packed = False
-        self.frozen_prefixes: tuple = ()
+        self.packed_version = -1
+        self.unused_heads: List[str] = []
+        # arena offset right after each item's parameter slots (= start of the next item's slots)
+        self._watermark = {}
+        for item in order:
+            slots = [s for s in (getattr(item, a, None) for a in ("w", "b", "gamma", "beta")) if s is not None]
+            self._watermark[id(item)] = max(s.offset + (s.numel + 3) // 4 * 4 for s in slots)
 
     # ------------------------------------------------------------------------------------------ views
     def pview(self, slot: ParamSlot, arena=None):
@@ -273,7 +315,7 @@ class UNetEngine:
                 C, K = item.cin, item.cout
                 nat.call("lnn_pack_weights", w, self._wp(item.wp_fwd), 8, K, C, 8, K * 8, 1)
                 nat.call("lnn_pack_weights", w, self._wp(item.wp_dgrad), 8, C, K, K * 8, 8, 1)
-        self.packed = True
+        self.packed_version = self.arena.version
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, seg_weights: Optional[List[torch.Tensor]] = None, body: bool = True):
@@ -283,7 +325,7 @@ class UNetEngine:
         body activations."""
         N = self.N
         assert tuple(x.shape) == (N, 1) + self.patch, f"engine built for {(N, 1) + self.patch}, got {tuple(x.shape)}"
-        if not self.packed:
+        if self.packed_version != self.arena.version:
             self.pack_weights()
         logits = []
         if body:
@@ -316,17 +358,21 @@ class UNetEngine:
         return logits
 
     # ------------------------------------------------------------------------------------------ backward
-    def backward(self, dlogits: List[Optional[torch.Tensor]], skip_body: bool = False):
+    def backward(self, dlogits: List[Optional[torch.Tensor]], skip_body: bool = False, progress=None):
         """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.
         Accumulates parameter gradients into the flat arena ``self.grad`` (scaled like dlogits)."""
         N = self.N
         self.gpanels.zero_()
+        self.unused_heads = []
         seg_u = len(self.segs)
         for item in reversed(self.order):
+            if progress is not None and item is not self.order[-1]:
+                progress(self._watermark[id(item)])   # everything after this item in the arena is final
             if isinstance(item, SegHead):
                 seg_u -= 1
                 dl = dlogits[seg_u]
                 if dl is None:
+                    self.unused_heads.append(item.w.name)
                     if not item.gx_has_prior:
                         item.gx.buf.zero_()
                     continue

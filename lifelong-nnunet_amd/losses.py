@@ -1,0 +1,205 @@
+"""Loss objects of the hot path with the reference's own interfaces, computed by the fused HIP kernels.
+
+  * ``DC_and_CE_loss``        -- upstream nnunet loss constructed at multihead/nnUNetTrainerMultiHead.py:1385
+  * ``MultipleOutputLoss2``   -- upstream deep-supervision wrapper (weights recipe MH.py:1373-1383)
+  * ``MultipleOutputLossEWC`` -- nnunet_ext/training/loss_functions/deep_supervision.py:15-83
+  * ``MultipleOutputLossLWF`` -- nnunet_ext/training/loss_functions/deep_supervision.py:138-214
+Loss contract: ``loss(x: tuple[Tensor], y: list[Tensor]) -> 0-dim Tensor`` taking part in
+autograd; mutators ``update_ewc_params``, ``update_network_params``, ``update_logits``.
+"""
+from __future__ import annotations
+
+import types
+from typing import Dict, List
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import native as nat
+
+
+def ds_loss_weights(net_numpool: int) -> np.ndarray:
+    """multihead/nnUNetTrainerMultiHead.py:1377-1383."""
+    weights = np.array([1 / (2 ** i) for i in range(net_numpool)])
+    mask = np.array([True] + [True if i < net_numpool - 1 else False for i in range(1, net_numpool)])
+    weights[~mask] = 0
+    return weights / weights.sum()
+
+
+class _DiceCEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, batch_dice, smooth):
+        logits = logits.contiguous()
+        N, K = logits.shape[:2]
+        V = logits[0, 0].numel()
+        labels = target.reshape(N, V).to(logits.device, torch.float32).contiguous()
+        ws = torch.empty(nat.query("lnn_dice_ce_ws_doubles", N, K), dtype=torch.float64, device=logits.device)
+        out = torch.empty(1, device=logits.device)
+        nat.call("lnn_dice_ce_fwd", logits, labels, N, K, V, int(batch_dice), float(smooth), out, ws)
+        ctx.save_for_backward(logits, labels, ws)
+        ctx.cfg = (N, K, V, int(batch_dice), float(smooth))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, ws = ctx.saved_tensors
+        N, K, V, bd, smooth = ctx.cfg
+        dl = torch.empty_like(logits)
+        # the upstream scalar gradient (deep-supervision weight x loss scale) rides in as gscale
+        nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, bd, smooth, ws, 1.0, g.reshape(1).float().contiguous(), dl)
+        return dl, None, None, None
+
+
+class DC_and_CE_loss(nn.Module):
+    """CE + soft Dice, both weight 1 (upstream aggregate="sum"); do_bg must be False as the trainers
+    construct it (``{'batch_dice': .., 'smooth': 1e-5, 'do_bg': False}, {}``)."""
+
+    def __init__(self, soft_dice_kwargs, ce_kwargs=None, aggregate="sum"):
+        super().__init__()
+        assert aggregate == "sum" and not soft_dice_kwargs.get("do_bg", False)
+        self.batch_dice = bool(soft_dice_kwargs.get("batch_dice", False))
+        self.smooth = float(soft_dice_kwargs.get("smooth", 1e-5))
+
+    def forward(self, net_output, target):
+        return _DiceCEFunction.apply(net_output, target, self.batch_dice, self.smooth)
+
+
+class MultipleOutputLoss2(nn.Module):
+    def __init__(self, loss, weight_factors=None):
+        super().__init__()
+        self.weight_factors = weight_factors
+        self.loss = loss
+
+    def forward(self, x, y):
+        assert isinstance(x, (tuple, list)), "x must be either tuple or list"
+        assert isinstance(y, (tuple, list)), "y must be either tuple or list"
+        weights = [1] * len(x) if self.weight_factors is None else self.weight_factors
+        l = weights[0] * self.loss(x[0], y[0])
+        for i in range(1, len(x)):
+            if weights[i] != 0:          # zero-weight levels are skipped, not multiplied
+                l = l + weights[i] * self.loss(x[i], y[i])
+        return l
+
+
+# ------------------------------------------------------------------------------------------------- EWC
+class _EWCPenaltyFunction(torch.autograd.Function):
+    """sum_tasks lambda/2 * sum F_t (theta - theta*_t)^2 over the flat arena; backward adds
+    g * lambda * F_t (theta - theta*_t) straight into the flat gradient arena."""
+
+    @staticmethod
+    def forward(ctx, anchor, arena, fishers, stars, ewc_lambda):
+        ws = torch.empty(2, dtype=torch.float64, device=arena.theta.device)
+        total = torch.zeros((), device=arena.theta.device)
+        out = torch.empty(1, device=arena.theta.device)
+        for f, s in zip(fishers, stars):
+            nat.call("lnn_ewc_penalty_fwd", arena.theta, s, f, arena.size, float(ewc_lambda), out, ws)
+            total = total + out[0]
+        ctx.arena, ctx.fishers, ctx.stars, ctx.lam = arena, fishers, stars, float(ewc_lambda)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        for f, s in zip(ctx.fishers, ctx.stars):
+            nat.call("lnn_ewc_penalty_bwd", ctx.arena.theta, s, f, ctx.arena.size, ctx.lam, 1.0,
+                     g.reshape(1).float().contiguous(), ctx.arena.grad)
+        return None, None, None, None, None
+
+
+class MultipleOutputLossEWC(MultipleOutputLoss2):
+    def __init__(self, loss, weight_factors=None, ewc_lambda=0.4, fisher=dict(), params=dict(), network_params=None,
+                 match_sth=False, match=list(), match_true=True):
+        super().__init__(loss, weight_factors)
+        self.ewc_lambda = ewc_lambda
+        self.network_params = network_params
+        self.match_case, self.match, self.match_true = match_sth, match, match_true
+        self._flat: Dict = {}
+        self.update_ewc_params(fisher, params)
+
+    def update_ewc_params(self, fisher, params):
+        self.tasks = list(fisher.keys())
+        self.fisher = fisher
+        self.params = params
+        self._flat = {}                                   # flat arenas are rebuilt lazily
+
+    def update_network_params(self, network_params):
+        self.network_params = network_params
+
+    def _selected(self, name):
+        if not self.match_case:
+            return True
+        if self.match_true:
+            return all(m in name for m in self.match)
+        return all(m not in name for m in self.match)
+
+    def _flat_for(self, task, named, arena):
+        key = (task, tuple(n for n, _ in named))
+        if key not in self._flat:
+            F = torch.zeros(arena.size, device=arena.theta.device)
+            S = torch.zeros(arena.size, device=arena.theta.device)
+            for name, p in named:
+                if not self._selected(name):
+                    continue
+                s = p._lnn_slot
+                # a Fisher of shape [1] (param.grad was None, ewc/nnUNetTrainerEWC.py:300-301) broadcasts
+                F[s.offset:s.offset + s.numel] = self.fisher[task][name].to(F.device, torch.float32).expand(s.shape).reshape(-1)
+                S[s.offset:s.offset + s.numel] = self.params[task][name].to(S.device, torch.float32).reshape(-1)
+            self._flat[key] = (F, S)
+        return self._flat[key]
+
+    def forward(self, x, y, reg=True):
+        loss = super().forward(x, y)
+        if reg and len(self.tasks) > 0 and self.network_params is not None:
+            fishers, stars, arena, anchor = [], [], None, None
+            for task in self.tasks:
+                # deep_supervision.py:65-66: the task loop is outermost and ``network_params`` is whatever the
+                # trainer handed over -- a *generator* for the base EWC trainer (ewc/nnUNetTrainerEWC.py:140,247),
+                # which is exhausted after the first task (and stays exhausted until update_network_params).
+                named = [(n, p) for n, p in self.network_params]
+                if not named:
+                    continue
+                arena = named[0][1]._lnn_net.arena
+                anchor = next((p for _, p in named if p.requires_grad), named[0][1])
+                F, S = self._flat_for(task, named, arena)
+                fishers.append(F)
+                stars.append(S)
+            if fishers:
+                loss = loss + _EWCPenaltyFunction.apply(anchor, arena, fishers, stars, self.ewc_lambda)
+        return loss
+
+
+# ------------------------------------------------------------------------------------------------- LwF
+def kl_logits(pred, teach, temperature):
+    """F.kl_div(log_softmax(pred/T,1), log_softmax(teach/T,1), 'batchmean', log_target=True)
+    (deep_supervision.py:194-196) as one fused device reduction; value only."""
+    dev = pred.device if pred.is_cuda else torch.device("cuda")
+    p = pred.detach().to(dev, torch.float32).contiguous()
+    t = teach.detach().to(dev, torch.float32).contiguous()
+    N, K = p.shape[:2]
+    V = p[0, 0].numel()
+    out = torch.empty(1, device=dev)
+    ws = torch.empty(1, dtype=torch.float64, device=dev)
+    nat.call("lnn_kl_logits", p, t, N, K, V, float(temperature), out, ws)
+    return out[0]
+
+
+class MultipleOutputLossLWF(MultipleOutputLoss2):
+    def __init__(self, loss, weight_factors=None, pred_logits=list(), target_logits=list(), lwf_temperature=2.0):
+        super().__init__(loss, weight_factors)
+        self.pred_logits, self.target_logits = pred_logits, target_logits
+        self.lwf_temperature = lwf_temperature
+        self.scale = [item.size(-1) for item in self.target_logits]   # unused by the reference too (DS.py:196)
+
+    def update_logits(self, pred_logits, target_logits):
+        self.pred_logits, self.target_logits = pred_logits, target_logits
+        self.scale = [item.size(-1) for item in self.target_logits]
+
+    def _distillation_loss(self, y, teacher_scores, scale=None):
+        return kl_logits(y, teacher_scores, self.lwf_temperature)
+
+    def forward(self, x, y):
+        loss = super().forward(x, y)
+        # one KL per OLD head: target_logits has one entry less than pred_logits (the current task)
+        for idx, t_logit in enumerate(self.target_logits):
+            loss = loss + self._distillation_loss(self.pred_logits[idx], t_logit)
+        return loss

@@ -1,0 +1,164 @@
+"""``MultiHead_Module`` with the reference's interface and state-dict naming on top of the flat arena.
+
+Mirrors nnunet_ext/network_architecture/MultiHead_Module.py:
+  constructor / split path handling :16-125, ``forward`` :127-137, ``update_after_iteration`` :139-157,
+  ``assemble_model`` :326-377, ``_set_requires_grad`` :379-395, ``add_new_task`` :435-458,
+  ``add_n_tasks_and_activate`` :460-485.
+Semantics kept: body parameters are SHARED tensors with the running model, head parameters are
+per-task copies; the head of the active task is refreshed from the running model after every training
+iteration.  What is dropped is the cost: the reference re-splits the module tree and ``deepcopy``s the
+head every iteration (MHM.py:153-157,324) and deep-copies + ``load_state_dict``s on every
+``assemble_model`` (MHM.py:343-359); here both are a handful of device-to-device copies of the head
+tensors (2 400 floats for the 5-level U-Net).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Type
+
+import torch
+from torch import nn
+
+
+def _set_nested(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            setattr(m, p, nn.Module())
+        m = getattr(m, p)
+    m.register_parameter(parts[-1], param)
+
+
+class MultiHead_Module(nn.Module):
+    def __init__(self, class_object: Type[nn.Module], split_at, task, prev_trainer=None, *args, **kwargs):
+        super().__init__()
+        self.class_object = class_object
+        if prev_trainer is None:
+            self.model = class_object(*args, **kwargs)
+        else:
+            assert isinstance(prev_trainer, class_object), \
+                "This function splits a '{}' module class object, but a '{}' module is provided.".format(
+                    class_object.__name__, type(prev_trainer))
+            assert len(list(prev_trainer.children())) > 0, \
+                "When using a prev_trainer, please ensure that it is not empty or do not specify one."
+            self.model = prev_trainer
+        assert isinstance(split_at, str), "The provided split needs to be a string.."
+        self.split = [x.strip() for x in split_at.split('.')]
+        names = [n for n, _ in self.model.named_parameters()]
+        self._check_and_simplify_split(names)
+        self.heads = nn.ModuleDict()
+        assert isinstance(task, (str, int)), "The provided task needs to be an integer (ID) or string, not {}..".format(type(task))
+        self.active_task = task
+
+        # everything at or after the split point in registration (pre-order) order is the head
+        prefix = '.'.join(self.split) + '.'
+        first = next(i for i, n in enumerate(names) if n.startswith(prefix))
+        assert first > 0, "You tried to split before the first layer, so the body would be empty --> body can never be empty.."
+        self._body_names, self._head_names = names[:first], names[first:]
+        params = dict(self.model.named_parameters())
+        self.body = nn.Module()
+        for n in self._body_names:
+            _set_nested(self.body, n, params[n])          # the SAME Parameter objects as the running model
+        init_module = self._head_from_model()
+        self.state_init = OrderedDict((k, v.clone()) for k, v in init_module.state_dict().items())
+        self.heads[str(task)] = init_module
+        self.body_freezed = True
+        self.assemble_model(task, freeze_body=False)
+        self.body_freezed = False
+
+    # ------------------------------------------------------------------------------------------ split
+    def _check_and_simplify_split(self, names):
+        def exists(path):
+            pre = '.'.join(path) + '.'
+            return any(n.startswith(pre) for n in names)
+        assert exists(self.split), "The provided split path '{}' does not exist..".format('.'.join(self.split))
+        # MHM.py:73-92: drop trailing components that name the FIRST child of their parent
+        while len(self.split) > 1:
+            parent = '.'.join(self.split[:-1]) + '.'
+            first_child = next(n for n in names if n.startswith(parent))[len(parent):].split('.')[0]
+            if self.split[-1] == first_child:
+                self.split = self.split[:-1]
+            else:
+                break
+
+    def get_split_path(self):
+        return '.'.join(self.split)
+
+    def _head_from_model(self):
+        params = dict(self.model.named_parameters())
+        head = nn.Module()
+        for n in self._head_names:
+            _set_nested(head, n, nn.Parameter(params[n].detach().clone(), requires_grad=params[n].requires_grad))
+        return head
+
+    # ------------------------------------------------------------------------------------------ API
+    def forward(self, x):
+        return self.class_object.forward(self.model, x)
+
+    def update_after_iteration(self, model=None, update_body=True):
+        """Refresh the active task's head from the running model (body tensors are shared already)."""
+        model = self.model if model is None else model
+        src = dict(model.named_parameters())
+        with torch.no_grad():
+            for n, p in self.heads[str(self.active_task)].named_parameters():
+                p.copy_(src[n])
+
+    def assemble_model(self, task, freeze_body=False):
+        if self.active_task == task and freeze_body == self.body_freezed:
+            return self.model
+        assert str(task) in self.heads.keys(), \
+            "The provided task '{}' is not a known head, so either initialize the task or provide one that already exists: {}.".format(
+                task, list(self.heads.keys()))
+        dst = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for n, p in self.heads[str(task)].named_parameters():
+                dst[n].copy_(p)
+        if hasattr(self.model, "mark_params_changed"):
+            self.model.mark_params_changed()
+        self.active_task = task
+        if freeze_body and not self.body_freezed:
+            self._set_requires_grad(False)
+            self.body_freezed = True
+        if not freeze_body and self.body_freezed:
+            self._set_requires_grad(True)
+            self.body_freezed = False
+        return self.model
+
+    def _set_requires_grad(self, requires_grad):
+        body = set(self._body_names)
+        for name, param in self.model.named_parameters():
+            if name in body:
+                param.requires_grad = requires_grad
+
+    def add_new_task(self, task, use_init, model=None):
+        if model is None:
+            last = self.heads[list(self.heads.keys())[-1]]
+            new = nn.Module()
+            for n, p in last.named_parameters():
+                _set_nested(new, n, nn.Parameter(p.detach().clone()))
+            if use_init:
+                new.load_state_dict(self.state_init)
+            self.heads[str(task)] = new
+        else:
+            new = nn.Module()
+            for n, p in model.named_parameters():
+                _set_nested(new, n, nn.Parameter(p.detach().clone()))
+            self.heads[str(task)] = new
+
+    def add_n_tasks_and_activate(self, list_of_tasks, activate_with, remove_old_tasks=True):
+        for task in list_of_tasks:
+            if str(task) not in self.heads:
+                self.add_new_task(task, use_init=True)
+        if remove_old_tasks:
+            for task in list(self.heads.keys()):
+                if task not in [str(t) for t in list_of_tasks]:
+                    del self.heads[task]
+        self.assemble_model(activate_with)
+
+    def head_weights(self, task):
+        """seg-head tensors of ``task`` in engine order (used for multi-head evaluation on one body pass)."""
+        return [p for _, p in self.heads[str(task)].named_parameters()]
+
+    def get_model_type(self):
+        return self.model.__class__.__name__

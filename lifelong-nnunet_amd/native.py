@@ -41,16 +41,17 @@ SIGNATURES = {
     "lnn_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),
     "lnn_seg1x1_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _l, _i, _i, _i, _f]),
     "lnn_dice_ce_fwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _f, _p, _p]),
-    "lnn_dice_ce_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _f, _p, _f, _p]),
+    "lnn_dice_ce_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _f, _p, _f, _p, _p]),
     "lnn_dice_ce_ws_doubles": (_sz, [_i, _i]),
     "lnn_online_dice_counts": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "lnn_kl_logits": (_i, [_p, _p, _p, _i, _i, _l, _f, _p, _p]),
     "lnn_ewc_penalty_fwd": (_i, [_p, _p, _p, _p, _l, _f, _p, _p]),
-    "lnn_ewc_penalty_bwd": (_i, [_p, _p, _p, _p, _l, _f, _f, _p]),
+    "lnn_ewc_penalty_bwd": (_i, [_p, _p, _p, _p, _l, _f, _f, _p, _p]),
     "lnn_fisher_square": (_i, [_p, _p, _p, _l, _f]),
     "lnn_fisher_accumulate": (_i, [_p, _p, _p, _l, _f, _f]),
     "lnn_fisher_ema": (_i, [_p, _p, _p, _l, _f, _f]),
-    "lnn_gradnorm_sumsq": (_i, [_p, _p, _l, _f, _p]),
+    "lnn_gradnorm_sumsq": (_i, [_p, _p, _l, _f, _p, _i]),
+    "lnn_sgd_nesterov_step_clipped": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p]),
     "lnn_sgd_nesterov_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
     "lnn_cast_f32_to_h": (_i, [_p, _p, _p, _l]),
     "lnn_debug_tr16_probe": (_i, [_p, _p]),

@@ -1,0 +1,131 @@
+"""Optimiser side of the iteration (multihead/nnUNetTrainerMultiHead.py:294-301, 626-631) on the flat arenas.
+
+The reference runs, per iteration, ``scaler.scale(l).backward(); scaler.unscale_(opt);
+clip_grad_norm_(params, 12); scaler.step(opt); scaler.update()`` -- about six foreach passes over the
+31 M parameters.  Here: ONE norm pass (sum of squares + non-finite count, fp64 accumulation) and ONE
+fused pass (unscale x clip coefficient, weight decay, Nesterov momentum, update); the clip
+coefficient and the inf-skip decision are taken on the device, so nothing synchronises before the
+step.  Only parameters with ``requires_grad`` are updated (MH.py:299), as contiguous arena ranges.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import native as nat
+
+
+def _ranges(net):
+    """Contiguous arena ranges [lo, hi) of the parameters that require grad."""
+    # torch.optim.SGD skips parameters whose .grad is None (no weight decay, no momentum): that is the case of
+    # the zero-weight deep-supervision head, which the engine reports in net.params_without_grad
+    skip = getattr(net, "params_without_grad", ())
+    spans = sorted((p._lnn_slot.offset, p._lnn_slot.offset + (p._lnn_slot.numel + 3) // 4 * 4)
+                   for n, p in net._named if p.requires_grad and n not in skip)
+    out = []
+    for lo, hi in spans:
+        if out and out[-1][1] == lo:
+            out[-1][1] = hi
+        else:
+            out.append([lo, hi])
+    return [(lo, hi) for lo, hi in out]
+
+
+class _Off:
+    def __init__(self, t, off):
+        self.t, self.off = t, off
+
+    def data_ptr(self):
+        return self.t.data_ptr() + 4 * self.off
+
+
+class GradScaler:
+    """torch.cuda.amp.GradScaler semantics (init 65536, x2 after 2000 clean steps, x0.5 + skip on inf/nan)."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self._scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self._growth_tracker = 0
+        self.enabled = enabled
+
+    def scale(self, loss):
+        return loss * self._scale if self.enabled else loss
+
+    def get_scale(self):
+        return self._scale
+
+    def update(self, found_inf: bool):
+        if not self.enabled:
+            return
+        if found_inf:
+            self._scale *= self.backoff_factor
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == self.growth_interval:
+                self._scale *= self.growth_factor
+                self._growth_tracker = 0
+
+    def state_dict(self):
+        return {"scale": self._scale, "_growth_tracker": self._growth_tracker}
+
+    def load_state_dict(self, d):
+        self._scale, self._growth_tracker = d["scale"], d["_growth_tracker"]
+
+
+class FusedSGD:
+    """SGD(momentum=0.99, nesterov=True) over the flat arena with ``torch.optim.SGD``'s surface
+    (``param_groups[0]['lr']``, ``zero_grad``, ``step``, ``state_dict``)."""
+
+    def __init__(self, net, lr, weight_decay=0.0, momentum=0.99, nesterov=True):
+        assert nesterov, "the reference uses nesterov=True (MH.py:300)"
+        self.net = net
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "momentum": momentum, "nesterov": True,
+                              "params": [p for _, p in net._named if p.requires_grad]}]
+        self.ctrl = torch.zeros(2, dtype=torch.float64, device=net.arena.theta.device)
+        self._ctrl_valid = False
+
+    def zero_grad(self, set_to_none=False):
+        self.net.arena.grad.zero_()
+        self.net.bind_grads()
+
+    def grad_norm_pass(self, inv_scale=1.0):
+        """sum of squares of the UNSCALED gradient + non-finite count -> self.ctrl (device)."""
+        a = self.net.arena
+        first = 1
+        for lo, hi in _ranges(self.net):
+            nat.call("lnn_gradnorm_sumsq", _Off(a.grad, lo), hi - lo, float(inv_scale), self.ctrl, first)
+            first = 0
+        self._ctrl_valid = True
+
+    def step(self, inv_scale=1.0, max_norm=0.0):
+        """Fused unscale + clip (``max_norm`` > 0, needs grad_norm_pass) + Nesterov update; skipped on
+        the device if a non-finite gradient was counted."""
+        a, g = self.net.arena, self.param_groups[0]
+        if not self._ctrl_valid:
+            self.ctrl.zero_()
+            max_norm = 0.0
+        for lo, hi in _ranges(self.net):
+            nat.call("lnn_sgd_nesterov_step_clipped", _Off(a.theta, lo), _Off(a.momentum, lo), _Off(a.grad, lo), hi - lo,
+                     float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(inv_scale), float(max_norm),
+                     self.ctrl)
+        self._ctrl_valid = False
+        self.net.mark_params_changed()
+
+    def read_ctrl(self):
+        """(total_norm, found_inf) -- ONE host sync; call after the loss has been fetched anyway."""
+        c = self.ctrl.cpu()
+        return float(c[0]) ** 0.5, bool(c[1] > 0)
+
+    def state_dict(self):
+        return {"momentum": self.net.arena.momentum.clone(), "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, d):
+        self.net.arena.momentum.copy_(d["momentum"])
+        self.param_groups[0]["lr"] = d["lr"]
+
+
+def clip_grad_norm_(net, max_norm, optimizer: FusedSGD, inv_scale=1.0):
+    """Deferred ``torch.nn.utils.clip_grad_norm_``: computes the norm now, the scaling is folded into
+    the following ``optimizer.step(max_norm=...)``."""
+    optimizer.grad_norm_pass(inv_scale)
+    return max_norm

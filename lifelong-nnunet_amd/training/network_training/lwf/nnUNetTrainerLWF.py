@@ -1,0 +1,116 @@
+"""``nnUNetTrainerLWF`` -- Learning without Forgetting.
+
+Mirror of nnunet_ext/training/network_training/lwf/nnUNetTrainerLWF.py: ``initialize`` :96-108,
+``run_training`` :124-296 (phase 1 head-only warm-up with frozen body and the plain loss :189-201, phase 2
+teacher logits for every head :244-251, phase 3 LwF loss :253-261), ``run_iteration`` :298-370; and of
+``calculate_target_logits`` (nnunet_ext/utilities/helpful_functions.py:207-266).
+
+Reference behaviour kept in parity mode: the distillation term enters the loss VALUE only -- predictions are
+detached (LWF.py:343), so it carries no gradient; targets are looked up by ``batch_idx % 250`` (:349).
+MI355X-first differences that do not change results:
+  * the reference runs one complete eval forward per head per iteration (deepcopy + load_state_dict of the
+    model each time, MHM.py:343-359).  InstanceNorm keeps no running statistics and dropout is p=0, so the
+    body activations of those passes equal the training pass': the old heads' 1x1x1 convs are evaluated on
+    the body activations the training forward just produced (``engine.forward(body=False)``).
+  * teacher logits and predictions stay in HBM (288 GB) instead of round-tripping through host memory
+    (``.cpu()`` at LWF.py:343, HF.py:254); the KL is one fused device reduction instead of CPU fp32 ops.
+"""
+import torch
+
+from ....losses import DC_and_CE_loss, MultipleOutputLossLWF as LwFloss
+from ..multihead.nnUNetTrainerMultiHead import nnUNetTrainerMultiHead
+
+HYPERPARAMS = {'lwf_temperature': float}
+
+
+def calculate_target_logits(mh_network, gen, num_batches_per_epoch, fp16=True, gpu_id=0):
+    """HF.py:207-266: for each head IN TURN, ``num_batches_per_epoch`` consecutive batches of ``gen`` are
+    pushed through body + that head (eval, identity nonlinearity) and the full-resolution logits are kept."""
+    target_logits = dict()
+    net = mh_network.model
+    for task in list(mh_network.heads.keys()):
+        hw = mh_network.head_weights(task)
+        target_logits[task] = list()
+        for _ in range(num_batches_per_epoch):
+            data_dict = next(gen)
+            x = torch.as_tensor(data_dict['data'])
+            target_logits[task].append(net.forward_heads(x, [hw])[0])
+    return target_logits
+
+
+class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
+    def __init__(self, split, task, *args, lwf_temperature=2.0, **kwargs):
+        kwargs.setdefault("extension", "lwf")
+        super().__init__(split, task, *args, **kwargs)
+        self.lwf_temperature = lwf_temperature
+        self.freeze_run = True
+        self.do_val = False
+        self.batch_idx = 0
+        self.target_logits = None
+
+    def initialize(self, training=True, force_load_plans=False, num_epochs=500, prev_trainer_path=None,
+                   call_for_eval=False):
+        super().initialize(training, force_load_plans, num_epochs, prev_trainer_path, call_for_eval)
+        self.loss_orig = self.loss
+        loss_base = DC_and_CE_loss({'batch_dice': self.batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})
+        self.LwFloss = LwFloss(loss_base, self.ds_loss_weights, list(), list(), self.lwf_temperature)
+
+    def run_training(self, task, output_folder=None, build_folder=True):
+        if not self.was_initialized:
+            self.initialize(True, num_epochs=self.max_num_epochs)
+        if self.task != task or self.tr_gen is None:
+            self.reinitialize(task)
+        if str(task) not in self.mh_network.heads:
+            self.mh_network.add_new_task(task, use_init=not self.transfer_heads)
+        if len(self.mh_network.heads) == 1:
+            # very first task: conventional training (LWF.py:173-184)
+            self.freeze_run = False
+            self.loss = self.loss_orig
+            self.network = self.mh_network.assemble_model(task)
+            ret = super().run_training(task, output_folder)
+            self.freeze_run = True
+            return ret
+        # ---- phase 1: head-only training, body frozen, plain loss (LWF.py:189-201)
+        self.freeze_run = True
+        self.network = self.mh_network.assemble_model(task, freeze_body=True)
+        self.loss = self.loss_orig
+        self._run_epoch_loop()
+        self.epoch = 0
+        self.all_tr_losses, self.all_val_losses = [], []
+        self.freeze_run = False
+        # ---- phase 2: teacher logits of EVERY head with the pre-LwF body (LWF.py:236-251)
+        self.network = self.mh_network.assemble_model(task, freeze_body=False)
+        self.target_logits = calculate_target_logits(self.mh_network, self.tr_gen, self.num_batches_per_epoch, self.fp16)
+        # ---- phase 3: train everything with the LwF loss (LWF.py:253-261)
+        self.network.train()
+        self.loss = self.LwFloss
+        self.batch_idx = 0
+        ret = super().run_training(task, output_folder)
+        self.freeze_run = True
+        return ret
+
+    def _lwf_active(self, do_backprop):
+        return not (self.freeze_run or self.do_val or not do_backprop or len(self.mh_network.heads) <= 1
+                    or self.loss is not self.LwFloss)
+
+    def on_forward_done(self, data, output, do_backprop):
+        """LWF.py:315-353: predictions of every head on the CURRENT batch + stored teacher logits -> loss."""
+        if not self._lwf_active(do_backprop):
+            return
+        heads = list(self.mh_network.heads.keys())
+        eng = self.network.engine_for(data)
+        all_pred_logits = []
+        with torch.no_grad():
+            for t in heads:
+                if t == str(self.mh_network.active_task):
+                    all_pred_logits.append(output[0].detach())
+                else:   # old head on the body activations the training forward just produced
+                    all_pred_logits.append(eng.forward(data, seg_weights=self.mh_network.head_weights(t), body=False)[-1])
+        all_target_logits = [self.target_logits[t][self.batch_idx % self.num_batches_per_epoch] for t in heads[:-1]]
+        self.loss.update_logits(all_pred_logits, all_target_logits)
+
+    def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, *args, **kwargs):
+        ret = super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
+        if self._lwf_active(do_backprop):
+            self.batch_idx += 1       # LWF.py:364
+        return ret

@@ -1,0 +1,294 @@
+"""``nnUNetTrainerMultiHead`` -- base trainer of every continual-learning method, hot-path part only.
+
+Host-side mirror of nnunet_ext/training/network_training/multihead/nnUNetTrainerMultiHead.py:
+  ctor kwargs :40-44, ``initialize`` :303, ``initialize_optimizer_and_scheduler`` :294-301,
+  ``reinitialize`` :458, ``run_training`` :520-596, ``run_iteration`` :598-656, ``on_epoch_end`` :658,
+  ``run_online_evaluation`` :924-961, ``finish_online_evaluation_extended`` :963-1049,
+  ``save_checkpoint`` / ``load_checkpoint_ram`` :1164-1313, ``_update_loss_after_plans_change`` :1363-1387,
+  ``reorder_UNet_components`` :1391-1408.
+Out of scope here (CLI, plans files, NIfTI I/O, progress plots): network topology comes
+from a small ``plans`` dict instead of a pickled plans file, data from a ``data_provider`` callable yielding
+the reference's data dicts ``{'data','target','keys'}`` (MH.py:606-608).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from ....losses import DC_and_CE_loss, MultipleOutputLoss2, ds_loss_weights
+from ....multihead import MultiHead_Module
+from ....network import Generic_UNet
+from ....optim import FusedSGD, GradScaler
+from ....parallel import GradAllReducer
+from ....synthetic import SyntheticPatchGenerator
+
+HYPERPARAMS = {}
+
+DEFAULT_PLANS = {  # Task004_Hippocampus 3d_fullres shaped (BASELINE.json configs[0]); B=2 for plumbing
+    "patch_size": (40, 56, 40), "batch_size": 2, "num_pool": 3, "base_num_features": 32,
+    "num_classes": 3, "num_input_channels": 1,
+}
+
+
+def default_data_provider(task, split, plans, seed=12345):
+    """Deterministic synthetic patches per (task, split); tasks differ by seed and blob scale."""
+    h = sum(ord(c) * (i + 1) for i, c in enumerate(str(task))) % 9973
+    return SyntheticPatchGenerator(plans["batch_size"], plans["patch_size"], plans["num_pool"],
+                                   plans["num_input_channels"], plans["num_classes"],
+                                   seed=seed + 17 * h + (0 if split == "train" else 500000),
+                                   period=plans.get("synthetic_period", 4),
+                                   blob_scale=1.0 + 0.5 * (h % 3), key_prefix=f"{task}_{split}")
+
+
+class nnUNetTrainerMultiHead:
+    def __init__(self, split, task, plans_file=None, fold=0, output_folder=None, dataset_directory=None,
+                 batch_dice=False, stage=None, unpack_data=True, deterministic=True, fp16=True, save_interval=5,
+                 already_trained_on=None, use_progress=True, identifier="lnn_amd", extension='multihead',
+                 tasks_list_with_char=None, mixed_precision=True, save_csv=True, del_log=False, use_vit=False,
+                 vit_type='base', version=1, split_gpu=False, transfer_heads=False, ViT_task_specific_ln=False,
+                 do_LSA=False, do_SPT=False, network=None, use_param_split=False,
+                 plans: Optional[dict] = None, data_provider: Optional[Callable] = None, device="cuda",
+                 process_group=None):
+        assert not use_vit, "Generic_ViT_UNet variants are out of scope (SURVEY.md section 2 row 8)"
+        self.split, self.task, self.fold = split, task, fold
+        self.plans = dict(DEFAULT_PLANS if plans is None else plans)
+        self.batch_dice = batch_dice          # False for single-stage 3d_fullres (run/default_configuration.py:93-100)
+        self.deterministic, self.fp16 = deterministic, fp16
+        self.save_interval, self.extension = save_interval, extension
+        self.transfer_heads = transfer_heads
+        self.device = torch.device(device)
+        self.data_provider = data_provider or default_data_provider
+        self.process_group = process_group
+        self.already_trained_on = already_trained_on or OrderedDict()
+        self.tasks_list_with_char = tasks_list_with_char
+        # upstream nnUNetTrainerV2 constants
+        self.initial_lr, self.weight_decay = 1e-2, 3e-5
+        self.max_num_epochs = 500
+        self.num_batches_per_epoch, self.num_val_batches_per_epoch = 250, 50
+        self.epoch = 0
+        self.was_initialized = False
+        self.network = self.mh_network = self.optimizer = self.loss = None
+        self.tr_gen = self.val_gen = None
+        self.trainer_model = network
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
+        self.subject_names_raw = []
+        self.all_tr_losses, self.all_val_losses = [], []
+        self.validation_results = dict()
+        self.amp_grad_scaler = None
+        self.dp: Optional[GradAllReducer] = None
+        self.last_grad_norm, self.last_found_inf = None, False
+        if deterministic:
+            torch.manual_seed(12345 + fold)      # the only seed constants the reference uses (MH.py:214,259)
+            np.random.seed(12345 + fold)
+
+    # ------------------------------------------------------------------------------------------ init
+    def initialize(self, training=True, force_load_plans=False, num_epochs=500, prev_trainer_path=None,
+                   call_for_eval=False):
+        self.max_num_epochs = num_epochs
+        self.initialize_network()
+        self._update_loss_after_plans_change(self.plans["num_pool"], self.plans["patch_size"])
+        if training:
+            self.tr_gen = self.data_provider(self.task, "train", self.plans)
+            self.val_gen = self.data_provider(self.task, "val", self.plans)
+        self.initialize_optimizer_and_scheduler()
+        self.amp_grad_scaler = GradScaler()
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size(self.process_group) > 1:
+            self.dp = GradAllReducer(self.network.arena.grad, self.process_group)
+        self.was_initialized = True
+
+    def initialize_network(self):
+        p = self.plans
+        prev = self.trainer_model
+        self.mh_network = MultiHead_Module(Generic_UNet, self.split, self.task, prev, p["num_input_channels"],
+                                           p["base_num_features"], p["num_classes"], p["num_pool"],
+                                           device=self.device)
+        self.network = self.mh_network.model
+        self.network.inference_apply_nonlin = lambda x: torch.softmax(x, 1)
+
+    def initialize_optimizer_and_scheduler(self):
+        assert self.network is not None, "self.initialize_network must be called first"
+        self.optimizer = FusedSGD(self.network, self.initial_lr, weight_decay=self.weight_decay, momentum=0.99,
+                                  nesterov=True)
+        self.lr_scheduler = None
+
+    def _update_loss_after_plans_change(self, net_num_pool_op_kernel_sizes, patch_size):
+        net_numpool = net_num_pool_op_kernel_sizes if isinstance(net_num_pool_op_kernel_sizes, int) \
+            else len(net_num_pool_op_kernel_sizes)
+        self.ds_loss_weights = ds_loss_weights(net_numpool)
+        self.loss = DC_and_CE_loss({'batch_dice': self.batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})
+        self.loss = MultipleOutputLoss2(self.loss, self.ds_loss_weights)
+
+    def reinitialize(self, task, print_loss_info=True):
+        """MH.py:458-518: new task -> new generators (the loss object is kept unless a subclass swaps it)."""
+        self.task = task
+        self.tr_gen = self.data_provider(task, "train", self.plans)
+        self.val_gen = self.data_provider(task, "val", self.plans)
+
+    def maybe_update_lr(self, epoch=None):
+        ep = self.epoch + 1 if epoch is None else epoch
+        self.optimizer.param_groups[0]['lr'] = self.initial_lr * (1 - ep / self.max_num_epochs) ** 0.9   # upstream poly_lr
+
+    # ------------------------------------------------------------------------------------------ training
+    def run_training(self, task, output_folder=None, build_folder=True):
+        """MH.py:520-596: (re)point the generators at ``task``, add / activate its head, run the epoch loop."""
+        if not self.was_initialized:
+            self.initialize(True, num_epochs=self.max_num_epochs)
+        if self.task != task or self.tr_gen is None:
+            self.reinitialize(task)
+        if str(task) not in self.mh_network.heads:
+            self.mh_network.add_new_task(task, use_init=not self.transfer_heads)
+        self.network = self.mh_network.assemble_model(task)
+        self.already_trained_on.setdefault(str(self.fold), {}).setdefault('finished_training_on', [])
+        ret = self._run_epoch_loop()
+        self.already_trained_on[str(self.fold)]['finished_training_on'].append(task)
+        self.epoch = 0
+        return ret
+
+    def _run_epoch_loop(self):
+        """upstream NetworkTrainer.run_training: per epoch 250 train iterations, 50 no-grad validation iterations."""
+        self.maybe_update_lr(self.epoch)
+        while self.epoch < self.max_num_epochs:
+            self.network.train()
+            tr = [self.run_iteration(self.tr_gen, True) for _ in range(self.num_batches_per_epoch)]
+            self.all_tr_losses.append(float(np.mean(tr)))
+            with torch.no_grad():
+                self.network.eval()
+                va = [self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)]
+                if va:
+                    self.all_val_losses.append(float(np.mean(va)))
+            self.on_epoch_end()
+            self.epoch += 1
+        return self.all_tr_losses
+
+    def on_epoch_end(self):
+        if self.online_eval_tp:
+            self.validation_results.setdefault(str(self.epoch), {})[str(self.task)] = \
+                self.finish_online_evaluation_extended(self.task)
+        self.maybe_update_lr()
+
+    def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, detach=True, no_loss=False):
+        """MH.py:598-656.  Device work is enqueued without host synchronisation; the single sync is the loss
+        fetch at the end (the reference's ``.cpu().numpy()``, MH.py:655), which also carries the gradient-norm
+        / found-inf pair the GradScaler update needs."""
+        data_dict = next(data_generator)
+        data = torch.as_tensor(data_dict['data']).to(self.device, non_blocking=True)
+        target = [torch.as_tensor(t).to(self.device, non_blocking=True) for t in data_dict['target']]
+        self.optimizer.zero_grad()
+        output = self.network(data)
+        self.on_forward_done(data, output, do_backprop)
+        l = None
+        if not no_loss:
+            l = self.loss(output, target)
+        if do_backprop:
+            scale = self.amp_grad_scaler.get_scale()
+            if self.dp is not None:
+                self.dp.begin()
+                self.network.on_grad_progress = self.dp.progress
+            self.amp_grad_scaler.scale(l).backward()
+            world_avg = 1.0
+            if self.dp is not None:
+                self.dp.finish()
+                world_avg = self.dp.averaging_factor
+            inv = world_avg / scale
+            self.optimizer.grad_norm_pass(inv)                    # unscale_ + the norm of clip_grad_norm_(…, 12)
+            self.optimizer.step(inv_scale=inv, max_norm=12.0)      # clip coefficient + inf-skip applied on device
+        if run_online_evaluation:
+            self.run_online_evaluation(output, target)
+        if do_backprop:
+            self.mh_network.update_after_iteration()
+        if no_loss:
+            return None
+        if detach:
+            if do_backprop:
+                vals = torch.cat([l.detach().double().reshape(1), self.optimizer.ctrl]).cpu().numpy()
+                self.last_grad_norm, self.last_found_inf = float(vals[1]) ** 0.5, bool(vals[2] > 0)
+                self.amp_grad_scaler.update(self.last_found_inf)
+                return np.float32(vals[0])
+            return l.detach().cpu().numpy()
+        return l
+
+    def on_forward_done(self, data, output, do_backprop):
+        """Hook between forward and loss (used by LwF to read the old heads on the fresh body activations)."""
+
+    # ------------------------------------------------------------------------------------------ evaluation
+    def run_online_evaluation(self, output, target):
+        """MH.py:924-961: argmax of the full-resolution output, per-sample hard TP/FP/FN per foreground class."""
+        from .... import native as nat
+        out = output[0] if isinstance(output, (tuple, list)) else output
+        tgt = target[0] if isinstance(target, (tuple, list)) else target
+        N, K = out.shape[:2]
+        V = out[0, 0].numel()
+        counts = torch.empty((N, K - 1, 3), device=out.device)
+        nat.call("lnn_online_dice_counts", out.contiguous(), tgt.reshape(N, V).float().contiguous(), N, K, V, counts)
+        c = counts.cpu().numpy()
+        self.online_eval_tp.append(c[:, :, 0]); self.online_eval_fp.append(c[:, :, 1]); self.online_eval_fn.append(c[:, :, 2])
+
+    def finish_online_evaluation_extended(self, task, unique_subject_names=None):
+        """MH.py:963-1049 reduced to its arithmetic: Dice = 2TP/(2TP+FP+FN), IoU = TP/(TP+FP+FN) per class,
+        NaN (0/0) entries dropped from the mean (MH.py:1015-1022)."""
+        tp = np.concatenate(self.online_eval_tp, 0); fp = np.concatenate(self.online_eval_fp, 0)
+        fn = np.concatenate(self.online_eval_fn, 0)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            dice = 2 * tp / (2 * tp + fp + fn)
+            iou = tp / (tp + fp + fn)
+        res = {"mean_dice_per_class": np.nanmean(dice, 0).tolist(), "mean_iou_per_class": np.nanmean(iou, 0).tolist(),
+               "mean_dice": float(np.nanmean(dice)), "mean_iou": float(np.nanmean(iou))}
+        self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], []
+        return res
+
+    def _perform_validation(self, use_tasks=None, num_batches=None, call_for_eval=False):
+        """MH.py:678-901 hot part: for every head, assemble it, run no-grad iterations on that task's validation
+        generator with online evaluation, collect Dice/IoU."""
+        use_tasks = use_tasks or list(self.mh_network.heads.keys())
+        num_batches = num_batches or self.num_val_batches_per_epoch
+        active = self.mh_network.active_task
+        results = {}
+        with torch.no_grad():
+            for t in use_tasks:
+                self.network = self.mh_network.assemble_model(t)
+                self.network.eval()
+                gen = self.data_provider(t, "val", self.plans)
+                for _ in range(num_batches):
+                    self.run_iteration(gen, False, True)
+                results[str(t)] = self.finish_online_evaluation_extended(t)
+        self.network = self.mh_network.assemble_model(active)
+        self.network.train()
+        return results
+
+    # ------------------------------------------------------------------------------------------ persistence
+    def save_checkpoint(self, fname=None, save_optimizer=True):
+        """MH.py:1164-1197: the whole MultiHead_Module state (model + heads + body) + optimiser + scaler."""
+        ckpt = {"state_dict": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.mh_network.state_dict().items()),
+                "heads": list(self.mh_network.heads.keys()), "active_task": self.mh_network.active_task,
+                "epoch": self.epoch, "amp_grad_scaler": self.amp_grad_scaler.state_dict() if self.amp_grad_scaler else None,
+                "optimizer_state_dict": self.optimizer.state_dict() if (save_optimizer and self.optimizer) else None}
+        if fname is not None:
+            torch.save(ckpt, fname)
+        return ckpt
+
+    def load_checkpoint_ram(self, checkpoint, train=True):
+        """MH.py:1278-1313: heads must exist before the state dict is loaded."""
+        self.mh_network.add_n_tasks_and_activate(checkpoint["heads"], checkpoint["active_task"])
+        self.mh_network.load_state_dict(checkpoint["state_dict"])
+        self.network = self.mh_network.model
+        self.network.mark_params_changed()
+        self.epoch = checkpoint.get("epoch", 0)
+        if train and checkpoint.get("optimizer_state_dict") is not None:
+            self.optimizer.load_state_dict({k: (v.to(self.device) if torch.is_tensor(v) else v)
+                                            for k, v in checkpoint["optimizer_state_dict"].items()})
+        if checkpoint.get("amp_grad_scaler") and self.amp_grad_scaler:
+            self.amp_grad_scaler.load_state_dict(checkpoint["amp_grad_scaler"])
+
+    def reorder_UNet_components(self):
+        """MH.py:1391-1408: re-register encoder -> decoder -> head; changes named_parameters() ORDER only."""
+        net = self.network
+        mods = {k: getattr(net, k) for k in ("conv_blocks_localization", "conv_blocks_context", "td", "tu", "seg_outputs")}
+        for k in mods:
+            delattr(net, k)
+        for k in ("conv_blocks_context", "td", "tu", "conv_blocks_localization", "seg_outputs"):
+            setattr(net, k, mods[k])
+        net._named = list(net.named_parameters())

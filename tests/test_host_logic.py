@@ -1,0 +1,134 @@
+"""CPU tests of the host-side mirrors (no kernel launches): C-ABI symbol coverage, MultiHead_Module semantics
+and state-dict naming against the reference-generated golden, trainer plugin surface, rehearsal sampling."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import lifelong_nnunet_amd as pkg
+from lifelong_nnunet_amd import native as nat
+from lifelong_nnunet_amd.multihead import MultiHead_Module
+from lifelong_nnunet_amd.network import Generic_UNet
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lnn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lnn_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = nat.lib()                                   # loads, no GPU needed
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/lnn_hip.h but not exported"
+        assert name in nat.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(nat.SIGNATURES) == declared
+    assert lib.lnn_version() >= 100
+
+
+def test_bad_arguments_are_reported_not_thrown():
+    lib = nat.lib()
+    rc = lib.lnn_pack_weights(None, None, None, 27, 32, 32, 1, 1, 1)
+    assert rc == -1 and b"lnn_pack_weights" in lib.lnn_last_error()
+    rc = lib.lnn_conv3d_fwd(None, None, 32, None, None, None, 32, 1, 8, 8, 8, 32, 32, 3)
+    assert rc == -1 and b"stride" in lib.lnn_last_error()
+
+
+def test_generic_unet_parameter_names_match_reference(golden_dir):
+    m = json.load(open(f"{golden_dir}/meta.json"))
+    net = Generic_UNet(*m["toy_unet"]["ctor"], device="cpu")
+    assert [n for n, _ in net.named_parameters()] == m["toy_unet"]["param_names"]
+    assert [n for n, _ in net.named_parameters()] == m["multihead"]["model_param_names"]
+    # every parameter / gradient is a view into the flat arenas
+    for n, p in net.named_parameters():
+        assert p.data_ptr() == net.arena.theta.data_ptr() + 4 * p._lnn_slot.offset
+        assert p.grad.data_ptr() == net.arena.grad.data_ptr() + 4 * p._lnn_slot.offset
+    # He init: std = sqrt(2/(1+a^2)) / sqrt(fan_in); ConvTranspose fan_in uses dim 1
+    big = Generic_UNet(1, 32, 3, 3, device="cpu")
+    sd = big.state_dict()
+    w = sd["conv_blocks_context.1.blocks.1.conv.weight"]
+    assert abs(float(w.std()) - 1.41414 / (64 * 27) ** 0.5) < 0.02 * float(w.std())
+    tu = sd["tu.0.weight"]
+    assert abs(float(tu.std()) - 1.41414 / (tu.shape[1] * 8) ** 0.5) < 0.03 * float(tu.std())
+    assert float(sd["conv_blocks_context.0.blocks.0.instnorm.weight"].min()) == 1.0
+    assert float(sd["conv_blocks_context.0.blocks.0.conv.bias"].abs().max()) == 0.0
+
+
+def test_multihead_module_matches_reference_naming_and_semantics(golden_dir):
+    m = json.load(open(f"{golden_dir}/meta.json"))["multihead"]
+    mh = MultiHead_Module(Generic_UNet, "seg_outputs", "taskA", None, *m["ctor"], device="cpu")
+    mh.add_new_task("taskB", use_init=False)
+    assert list(mh.state_dict().keys()) == m["state_dict_keys"]
+    assert [n for n, _ in mh.body.named_parameters()] == m["body_param_names"]
+    assert [n for n, _ in mh.heads["taskA"].named_parameters()] == m["head_param_names"]
+    # body tensors are SHARED with the running model, head tensors are copies
+    body = dict(mh.body.named_parameters()); model = dict(mh.model.named_parameters())
+    assert all(body[n] is model[n] for n in body)
+    hA = dict(mh.heads["taskA"].named_parameters())
+    assert all(hA[n] is not model[n] and torch.equal(hA[n], model[n]) for n in hA)
+    # training changes the running model; update_after_iteration refreshes ONLY the active head
+    with torch.no_grad():
+        for n in hA:
+            model[n].add_(1.0)
+    mh.update_after_iteration()
+    hB = dict(mh.heads["taskB"].named_parameters())
+    assert all(torch.equal(hA[n], model[n]) for n in hA)
+    assert all(not torch.equal(hB[n], model[n]) for n in hB)
+    mh.assemble_model("taskB")
+    assert mh.active_task == m["active_after_assemble"] == "taskB"
+    assert all(torch.equal(hB[n], model[n]) for n in hB)
+    mh.assemble_model("taskB", freeze_body=True)
+    assert all(not model[n].requires_grad for n in body) and all(model[n].requires_grad for n in hB)
+    mh.assemble_model("taskB", freeze_body=False)
+    assert all(model[n].requires_grad for n in body)
+    # split normalisation (MHM.py:73-92) and invalid splits (test_MultiHead_Module.py:198-270)
+    mh2 = MultiHead_Module(Generic_UNet, "seg_outputs.0", "t", None, *m["ctor"], device="cpu")
+    assert mh2.get_split_path() == "seg_outputs"
+    with pytest.raises(AssertionError):
+        MultiHead_Module(Generic_UNet, "does_not_exist", "t", None, *m["ctor"], device="cpu")
+    with pytest.raises(AssertionError):
+        MultiHead_Module(Generic_UNet, "conv_blocks_localization", "t", None, *m["ctor"], device="cpu")
+    with pytest.raises(AssertionError):
+        mh.assemble_model("unknown_task")
+    # deeper split: everything at or after the split point is head
+    mh3 = MultiHead_Module(Generic_UNet, "tu", "t", None, *m["ctor"], device="cpu")
+    assert [n for n, _ in mh3.heads["t"].named_parameters()] == ["tu.0.weight", "tu.1.weight", "seg_outputs.0.weight", "seg_outputs.1.weight"]
+
+
+def test_trainer_plugin_surface():
+    for ext, cls_name, hp in (("sequential", "nnUNetTrainerSequential", {}), ("ewc", "nnUNetTrainerEWC", {"ewc_lambda": float}),
+                              ("lwf", "nnUNetTrainerLWF", {"lwf_temperature": float}),
+                              ("rehearsal", "nnUNetTrainerRehearsal", {"samples_in_perc": float, "seed": int})):
+        cls = pkg.get_trainer_class(ext)
+        assert cls.__name__ == cls_name
+        mod = __import__(cls.__module__, fromlist=["HYPERPARAMS"])
+        assert mod.HYPERPARAMS == hp
+        for meth in ("initialize", "run_training", "run_iteration", "reinitialize", "_perform_validation",
+                     "save_checkpoint", "load_checkpoint_ram"):
+            assert callable(getattr(cls, meth))
+    import inspect
+    assert inspect.signature(pkg.get_trainer_class("ewc").__init__).parameters["ewc_lambda"].default == 0.4
+    assert inspect.signature(pkg.get_trainer_class("lwf").__init__).parameters["lwf_temperature"].default == 2.0
+    sig = inspect.signature(pkg.get_trainer_class("rehearsal").__init__).parameters
+    assert sig["samples_in_perc"].default == 0.25 and sig["seed"].default == 3299
+
+
+def test_rehearsal_sampling_semantics(golden_dir):
+    import random
+    from lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal import nnUNetTrainerRehearsal, task_cases
+
+    class _MH:
+        heads = {"taskA": None, "taskB": None, "taskC": None}
+    tr = nnUNetTrainerRehearsal("seg_outputs", "taskC", device="cpu")
+    tr.mh_network = _MH()
+    tr.tr_gen, tr.val_gen = tr.get_basic_generators()
+    random.seed(3299)
+    expA = random.sample(task_cases("taskA", 40), 10)
+    expB = random.sample(task_cases("taskB", 40), 10)
+    assert tr.sampled == {"taskA": expA, "taskB": expB}
+    assert tr.dataset_tr == task_cases("taskC", 40) + expA + expB
+    batch = next(tr.tr_gen)
+    assert tuple(batch["data"].shape) == (2, 1, 40, 56, 40) and len(batch["target"]) == 3 and len(batch["keys"]) == 2

@@ -218,7 +218,7 @@ def test_dice_ce_fwd_bwd(N, K, V3, batch_dice):
     nat.call("lnn_dice_ce_fwd", lg, lb, N, K, V, batch_dice, 1e-5, out, ws)
     assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))       # north_star: 1e-4 relative loss
     dl = torch.zeros_like(lg)
-    nat.call("lnn_dice_ce_bwd", lg, lb, N, K, V, batch_dice, 1e-5, ws, 3.0, dl)
+    nat.call("lnn_dice_ce_bwd", lg, lb, N, K, V, batch_dice, 1e-5, ws, 1.5, torch.full((1,), 2.0, device=DEV), dl)
     assert rel_err(dl.cpu(), 3.0 * logits.grad) < 1e-4
 
 
@@ -260,7 +260,7 @@ def test_param_kernels():
     exp = 0.2 * (f.double() * (th.double() - ts.double()) ** 2).sum()
     assert abs(float(out) - float(exp)) <= 1e-6 * float(exp)
     g2 = grd.clone()
-    nat.call("lnn_ewc_penalty_bwd", thd, tsd, fd, n, 0.4, 2.0, g2)
+    nat.call("lnn_ewc_penalty_bwd", thd, tsd, fd, n, 0.4, 1.0, torch.full((1,), 2.0, device=DEV), g2)
     assert rel_err(g2.cpu(), gr + 2.0 * 0.4 * f * (th - ts)) < 1e-6
     fo = torch.zeros(n, device=DEV)
     nat.call("lnn_fisher_square", grd, fo, n, 0.5)
@@ -269,11 +269,11 @@ def test_param_kernels():
     assert rel_err(fo.cpu(), (0.5 * gr) ** 2 + 0.25 * gr ** 2) < 1e-6
     nat.call("lnn_fisher_ema", grd, fo, n, 1.0, 0.1)
     assert rel_err(fo.cpu(), 0.1 * gr ** 2 + 0.9 * ((0.5 * gr) ** 2 + 0.25 * gr ** 2)) < 1e-6
-    nat.call("lnn_gradnorm_sumsq", grd, n, 0.5, ws)
+    nat.call("lnn_gradnorm_sumsq", grd, n, 0.5, ws, 1)
     assert abs(float(ws[0]) - float((0.5 * gr.double()).pow(2).sum())) <= 1e-6 * float(ws[0])
     assert float(ws[1]) == 0
     bad = grd.clone(); bad[5] = float("inf"); bad[7] = float("nan")
-    nat.call("lnn_gradnorm_sumsq", bad, n, 1.0, ws)
+    nat.call("lnn_gradnorm_sumsq", bad, n, 1.0, ws, 1)
     assert float(ws[1]) == 2
     # two SGD-Nesterov steps against torch.optim.SGD
     p = torch.nn.Parameter(th.clone())
@@ -284,3 +284,19 @@ def test_param_kernels():
         opt.step()
         nat.call("lnn_sgd_nesterov_step", thg, buf, grd * (step + 1) * 4.0, n, 1e-2, 0.99, 3e-5, 0.25, 1 if step == 0 else 0)
     assert rel_err(thg.cpu(), p.detach()) < 1e-6
+    # device-controlled clip + skip: same two steps with clip_grad_norm_(12) on a scaled gradient
+    p = torch.nn.Parameter(th.clone())
+    opt = torch.optim.SGD([p], 1e-2, momentum=0.99, nesterov=True, weight_decay=3e-5)
+    buf.zero_(); thg = thd.clone()
+    for step in range(2):
+        p.grad = gr.clone() * (step + 1)
+        torch.nn.utils.clip_grad_norm_([p], 12)
+        opt.step()
+        gs = grd * (step + 1) * 1024.0
+        nat.call("lnn_gradnorm_sumsq", gs, n, 1 / 1024.0, ws, 1)
+        nat.call("lnn_sgd_nesterov_step_clipped", thg, buf, gs, n, 1e-2, 0.99, 3e-5, 1 / 1024.0, 12.0, ws)
+    assert rel_err(thg.cpu(), p.detach()) < 1e-6
+    before = thg.clone()
+    nat.call("lnn_gradnorm_sumsq", bad, n, 1.0, ws, 1)
+    nat.call("lnn_sgd_nesterov_step_clipped", thg, buf, bad, n, 1e-2, 0.99, 3e-5, 1.0, 12.0, ws)
+    assert torch.equal(before, thg)          # non-finite gradient -> step skipped

@@ -1,0 +1,94 @@
+"""End-to-end parity (-m gpu): the HIP training step behind the reference's trainer surface vs the CPU oracle.
+
+Tolerances are north_star's: <= 1e-4 relative loss, <= 1e-3 Dice difference, >= 0.9 Dice between the GPU and the
+oracle segmentation.  Activations are stored in fp16 on the GPU (fp32 accumulate), the oracle is fp32."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import losses as olosses, train as otrain          # noqa: E402
+from oracle.unet import OracleGenericUNet                       # noqa: E402
+from lifelong_nnunet_amd.losses import DC_and_CE_loss, MultipleOutputLoss2, ds_loss_weights   # noqa: E402
+from lifelong_nnunet_amd.network import Generic_UNet            # noqa: E402
+from lifelong_nnunet_amd.optim import FusedSGD, GradScaler      # noqa: E402
+from lifelong_nnunet_amd.synthetic import make_patch_batch      # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _hip_step(net, opt, scaler, loss_fn, data, tgts):
+    opt.zero_grad()
+    out = net(data.to(DEV))
+    l = loss_fn(out, [t.to(DEV) for t in tgts])
+    scaler.scale(l).backward()
+    inv = 1.0 / scaler.get_scale()
+    opt.grad_norm_pass(inv)
+    opt.step(inv_scale=inv, max_norm=12.0)
+    norm, found_inf = opt.read_ctrl()
+    scaler.update(found_inf)
+    return float(l), out, norm
+
+
+def _dice(seg_a, seg_b, K):
+    ds = []
+    for c in range(1, K):
+        a, b = seg_a == c, seg_b == c
+        den = a.sum() + b.sum()
+        if den > 0:
+            ds.append(2.0 * float((a & b).sum()) / float(den))
+    return float(np.mean(ds))
+
+
+def test_toy_unet_step_matches_golden(golden_dir):
+    d = np.load(golden_dir + "/toy_unet_step.npz")
+    meta = json.load(open(golden_dir + "/meta.json"))["toy_unet"]
+    net = Generic_UNet(*meta["ctor"], device=DEV)
+    assert [n for n, _ in net.named_parameters()] == meta["param_names"]
+    net.load_state_dict({k[4:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w0::")})
+    w = ds_loss_weights(2)
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), w)
+    opt = FusedSGD(net, 1e-2, weight_decay=3e-5)
+    data = torch.from_numpy(d["data"]); tgts = [torch.from_numpy(d[f"target_{i}"]) for i in range(2)]
+    lval, out, norm = _hip_step(net, opt, GradScaler(), loss_fn, data, tgts)
+    assert abs(lval - float(d["loss"])) <= 1e-4 * abs(float(d["loss"]))
+    for i, o in enumerate(out):
+        ref = torch.from_numpy(d[f"logits_{i}"])
+        assert float((o.cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # updated weights after clip(12) + SGD-Nesterov vs the oracle's
+    sd = net.state_dict()
+    num = den = 0.0
+    for k in d.files:
+        if k.startswith("w1::"):
+            a, b, w0 = sd[k[4:]].cpu(), torch.from_numpy(d[k]), torch.from_numpy(d["w0::" + k[4:]])
+            num += float(((a - b) ** 2).sum()); den += float(((b - w0) ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-2       # relative error of the whole UPDATE vector (fp16 activation gradients)
+    # seg_outputs.0 has deep-supervision weight 0 -> no gradient, untouched (reference: .grad is None)
+    assert torch.equal(sd["seg_outputs.0.weight"].cpu(), torch.from_numpy(d["w0::seg_outputs.0.weight"]))
+    assert net.params_without_grad == {"seg_outputs.0.weight"}
+
+
+def test_c1_iterations_match_oracle_live():
+    """BASELINE config 1 (40x56x40, 1 channel, 3 logits, 3 poolings, base 32), B=2: two training iterations."""
+    torch.manual_seed(12345)
+    onet = OracleGenericUNet(1, 32, 3, 3)
+    net = Generic_UNet(1, 32, 3, 3, device=DEV)
+    net.load_state_dict(onet.state_dict())
+    w = ds_loss_weights(3)
+    assert np.allclose(w, olosses.ds_loss_weights(3))
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), w)
+    opt, oopt, scaler = FusedSGD(net, 1e-2, weight_decay=3e-5), otrain.make_optimizer(onet), GradScaler()
+    for it in range(2):
+        data, tgts = make_patch_batch(2, (40, 56, 40), 3, seed=100 + it)
+        ol, oout = otrain.run_iteration(onet, oopt, data, tgts, w)
+        gl, gout, _ = _hip_step(net, opt, scaler, loss_fn, data, tgts)
+        rel = abs(gl - ol) / abs(ol)
+        print(f"iter {it}: oracle {ol:.6f} hip {gl:.6f} rel {rel:.2e}")
+        assert rel <= 1e-4
+        seg_o = oout[0].detach().argmax(1).numpy(); seg_g = gout[0].detach().argmax(1).cpu().numpy()
+        lab = tgts[0][:, 0].numpy()
+        assert _dice(seg_g, seg_o, 3) >= 0.9
+        assert abs(_dice(seg_g, lab, 3) - _dice(seg_o, lab, 3)) <= 1e-3
