@@ -1,0 +1,30 @@
+// Parameter blocks shared by the implicit-GEMM convolution kernels (internal).
+#pragma once
+#include "lnn_common.h"
+
+struct TapTable {
+    int ntaps;
+    int taps_per_group;
+    unsigned short pos_off[27];  // offset (in LDS tile positions) of the tap
+    unsigned char slot[27];      // weight panel slot of the tap
+};
+
+struct ConvParams {
+    const half_t* x;
+    const half_t* wp;
+    const float* bias;
+    half_t* y;
+    int ld_x, ld_y;
+    int N, Di, Hi, Wi, Do, Ho, Wo;
+    int C, M, Mpad, KCpad;
+    int Ld, Lh, Lw;
+    int tiles_z, tiles_y, tiles_x;
+    int os, par_z, par_y, par_x;
+    int pad_lo;
+    int accumulate;
+    TapTable taps;
+};
+
+
+// v2 stride-1 3x3x3 kernel (igemm_conv_v2.hip): persistent blocks, software-pipelined staging.
+int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);

@@ -15,31 +15,10 @@
 // LDS and reused by all taps; weight panels are staged per tap group.
 // LDS rows are padded by 16 B (row pitch 16*odd) so the 16-byte fragment reads are conflict free.
 #include "lnn_common.h"
+#include "igemm_common.h"
+#include <cstdlib>
 
 namespace {
-
-struct TapTable {
-    int ntaps;
-    int taps_per_group;
-    unsigned short pos_off[27];  // offset (in LDS tile positions) of the tap
-    unsigned char slot[27];      // weight panel slot of the tap
-};
-
-struct ConvParams {
-    const half_t* x;
-    const half_t* wp;
-    const float* bias;
-    half_t* y;
-    int ld_x, ld_y;
-    int N, Di, Hi, Wi, Do, Ho, Wo;
-    int C, M, Mpad, KCpad;
-    int Ld, Lh, Lw;
-    int tiles_z, tiles_y, tiles_x;
-    int os, par_z, par_y, par_x;
-    int pad_lo;
-    int accumulate;
-    TapTable taps;
-};
 
 template <int IS, int EXT, int TZ, int TY, int CK, int MT>
 struct ConvCfg {
@@ -64,8 +43,15 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xl = smem;
     char* wl = smem + Cfg::xbytes;
+    // tap tables live in LDS: indexing the kernarg copy dynamically makes hipcc emit dependent VMEM loads
+    // (a global_load + s_waitcnt vmcnt(0) per tap in the MFMA loop, and a gather per staged weight vector)
+    // (carved from the END of the dynamic region: a static __shared__ object would shift the dynamic base off
+    // its 16-byte alignment, cdna_hip_programming.md Guideline 17)
+    int* tap_pos = reinterpret_cast<int*>(smem + Cfg::xbytes + Cfg::wbytes(p.taps.taps_per_group));
+    int* tap_slot = tap_pos + 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 27) { tap_pos[tid] = p.taps.pos_off[tid]; tap_slot[tid] = p.taps.slot[tid]; }
     // ---- tile decode -----------------------------------------------------------------------------
     int t = blockIdx.x;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -97,38 +83,65 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvParams p) {
 
     const long xbase_n = (long)n * p.Di * p.Hi * p.Wi;
     const int ntaps = p.taps.ntaps, tpg = p.taps.taps_per_group;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     for (int c0 = 0; c0 < p.C; c0 += CK) {
         __syncthreads();  // previous chunk's readers are done with xl / wl
         // ---- stage the input tile of this channel chunk ------------------------------------------
-        for (int idx = tid; idx < P * CH8; idx += 256) {
-            const int pos = idx / CH8, c8 = idx % CH8;
-            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-            const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
-                c0 + c8 * 8 < p.C) {
-                const long off = (xbase_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + c0 + c8 * 8;
-                val = *reinterpret_cast<const half8*>(p.x + off);
+        // batches of 4 UNCONDITIONAL loads (invalid lanes read element 0 and are zeroed on the LDS write)
+        for (int base = 0; base < P * CH8; base += 1024) {
+            half8 r[4];
+            unsigned ok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = min(base + i * 256 + tid, P * CH8 - 1);
+                const int pos = idx / CH8, c8 = idx % CH8;
+                const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+                const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                const bool v_ok = (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi &&
+                                  (unsigned)ix < (unsigned)p.Wi && c0 + c8 * 8 < p.C;
+                const long off = v_ok ? (xbase_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + c0 + c8 * 8 : 0;
+                r[i] = *reinterpret_cast<const half8*>(p.x + off);
+                ok |= (v_ok ? 1u : 0u) << i;
             }
-            *reinterpret_cast<half8*>(xl + pos * POSB + c8 * 16) = val;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = base + i * 256 + tid;
+                if (idx < P * CH8)
+                    *reinterpret_cast<half8*>(xl + (idx / CH8) * POSB + (idx % CH8) * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
+            }
         }
         for (int g0 = 0; g0 < ntaps; g0 += tpg) {
             const int gn = min(tpg, ntaps - g0);
             if (g0 > 0) __syncthreads();  // readers of the previous weight group are done
             // ---- stage the weight panels of this tap group ---------------------------------------
-            for (int idx = tid; idx < gn * MB * CH8; idx += 256) {
-                const int c8 = idx % CH8, r = (idx / CH8) % MB, tl = idx / (CH8 * MB);
-                const int slot = p.taps.slot[g0 + tl];
-                half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (m0 + r < p.Mpad && c0 + c8 * 8 < p.KCpad)
-                    val = *reinterpret_cast<const half8*>(p.wp + ((long)slot * p.Mpad + m0 + r) * p.KCpad + c0 + c8 * 8);
-                *reinterpret_cast<half8*>(wl + (tl * MB + r) * WROWB + c8 * 16) = val;
+            const int wtot = gn * MB * CH8;
+            for (int base = 0; base < wtot; base += 1024) {
+                half8 r[4];
+                unsigned ok = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = min(base + i * 256 + tid, wtot - 1);
+                    const int c8 = idx % CH8, rr = (idx / CH8) % MB, tl = idx / (CH8 * MB);
+                    const int slot = tap_slot[g0 + tl];
+                    const bool v_ok = m0 + rr < p.Mpad && c0 + c8 * 8 < p.KCpad;
+                    const long off = v_ok ? ((long)slot * p.Mpad + m0 + rr) * p.KCpad + c0 + c8 * 8 : 0;
+                    r[i] = *reinterpret_cast<const half8*>(p.wp + off);
+                    ok |= (v_ok ? 1u : 0u) << i;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = base + i * 256 + tid;
+                    if (idx < wtot) {
+                        const int c8 = idx % CH8, rr = (idx / CH8) % MB, tl = idx / (CH8 * MB);
+                        *reinterpret_cast<half8*>(wl + (tl * MB + rr) * WROWB + c8 * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
+                    }
+                }
             }
             __syncthreads();
             // ---- MFMA over the taps of the group -------------------------------------------------
             for (int tl = 0; tl < gn; ++tl) {
-                const int xo = (int)p.taps.pos_off[g0 + tl] * POSB;
+                const int xo = __builtin_amdgcn_readfirstlane(tap_pos[g0 + tl]) * POSB;
                 const char* wrow = wl + tl * MB * WROWB + wlane;
 #pragma unroll
                 for (int k16 = 0; k16 < CK / 16; ++k16) {
@@ -278,7 +291,7 @@ int launch_igemm(hipStream_t s, ConvParams& p, const char* name) {
     if (tpg > p.taps.ntaps) tpg = p.taps.ntaps;
     if (p.taps.ntaps == 27) tpg = tpg >= 27 ? 27 : (tpg >= 9 ? 9 : (tpg >= 3 ? 3 : 1));
     p.taps.taps_per_group = tpg;
-    const size_t lds = Cfg::xbytes + Cfg::wbytes(tpg);
+    const size_t lds = Cfg::xbytes + Cfg::wbytes(tpg) + 256;   // + tap tables
     auto kern = igemm_conv_kernel<IS, EXT, TZ, TY, CK, MT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -297,6 +310,16 @@ int dispatch_ck_mt(hipStream_t s, ConvParams& p, const char* name) {
     const bool mt2 = p.M > 32;
     if (ck32) return mt2 ? launch_igemm<IS, EXT, TZ, TY, 32, 2>(s, p, name) : launch_igemm<IS, EXT, TZ, TY, 32, 1>(s, p, name);
     return mt2 ? launch_igemm<IS, EXT, TZ, TY, 16, 2>(s, p, name) : launch_igemm<IS, EXT, TZ, TY, 16, 1>(s, p, name);
+}
+
+// LNN_CONV_V1=1 selects the non-pipelined kernel for the stride-1 convs (A/B measurements only)
+bool use_v2() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LNN_CONV_V1");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
 }
 
 int check_act(const void* ptr, int ld, int C, const char* what) {
@@ -342,6 +365,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
             p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
             p.taps.slot[t] = (unsigned char)t;
         }
+        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v2)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
     {
@@ -380,6 +404,7 @@ extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, cons
             p.taps.pos_off[t] = (unsigned short)((dz * PY + dyy) * PX + dxx);
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
+        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v2)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
     }
     // stride 2: dx[2l+par] = sum over taps d with (par - d + 1) even: dy[l + (par - d + 1)/2]

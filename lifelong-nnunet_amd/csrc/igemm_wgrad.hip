@@ -12,6 +12,7 @@
 // of TZ x TY x 8 loop voxels, accumulating in registers, and finishes with fp32 atomics into the
 // packed panel (coalesced: c is the fastest index).
 #include "lnn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -49,8 +50,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ql = smem;             // [P][ROWB]
     char* pl = smem + P * ROWB;  // [TV][ROWB]
+    // LDS copies of the tap tables (dynamic kernarg indexing becomes dependent VMEM loads); carved from the END of
+    // the dynamic region so the dynamic base keeps its 16-byte alignment
+    int* tap_pos = reinterpret_cast<int*>(smem + (P + TV) * ROWB);
+    int* tap_slot = tap_pos + 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 27) { tap_pos[tid] = p.taps.pos_off[tid]; tap_slot[tid] = p.taps.slot[tid]; }
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
 
     // transpose-read lane roles: 16-lane group g -> channel base 16*(g&1); lane s in group supplies the
@@ -67,6 +74,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
+    __syncthreads();
+    int tpos[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = wave + 4 * ti;
+        tpos[ti] = tap < 27 ? __builtin_amdgcn_readfirstlane(tap_pos[tap < 27 ? tap : 0]) : 0;
+    }
     const int t_begin = blockIdx.x * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -80,26 +94,48 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
         __syncthreads();
         // ---- stage Q tile (gathered operand, 32 channels c0..c0+31) ------------------------------
         const long qbase = (long)n * p.Qd * p.Qh * p.Qw;
-        for (int idx = tid; idx < P * 4; idx += 256) {
-            const int pos = idx >> 2, c8 = idx & 3;
-            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-            const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
-                c0 + c8 * 8 < p.C)
-                val = *reinterpret_cast<const half8*>(p.q + (qbase + ((long)iz * p.Qh + iy) * p.Qw + ix) * p.ld_q + c0 + c8 * 8);
-            *reinterpret_cast<half8*>(ql + pos * ROWB + c8 * 16) = val;
+        for (int base = 0; base < P * 4; base += 1024) {
+            half8 r[4];
+            unsigned ok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = min(base + i * 256 + tid, P * 4 - 1);
+                const int pos = idx >> 2, c8 = idx & 3;
+                const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+                const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                const bool v_ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh &&
+                                  (unsigned)ix < (unsigned)p.Qw && c0 + c8 * 8 < p.C;
+                const long off = v_ok ? (qbase + ((long)iz * p.Qh + iy) * p.Qw + ix) * p.ld_q + c0 + c8 * 8 : 0;
+                r[i] = *reinterpret_cast<const half8*>(p.q + off);
+                ok |= (v_ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = base + i * 256 + tid;
+                if (idx < P * 4) *reinterpret_cast<half8*>(ql + (idx >> 2) * ROWB + (idx & 3) * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
+            }
         }
         // ---- stage P tile (32 channels m0..m0+31 at the loop voxels) ------------------------------
         const long pbase = (long)n * p.Ld * p.Lh * p.Lw;
-        for (int idx = tid; idx < TV * 4; idx += 256) {
-            const int vox = idx >> 2, c8 = idx & 3;
-            const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
-            const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
-            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M)
-                val = *reinterpret_cast<const half8*>(p.p + (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8);
-            *reinterpret_cast<half8*>(pl + vox * ROWB + c8 * 16) = val;
+        for (int base = 0; base < TV * 4; base += 1024) {
+            half8 r[4];
+            unsigned ok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = min(base + i * 256 + tid, TV * 4 - 1);
+                const int vox = idx >> 2, c8 = idx & 3;
+                const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
+                const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
+                const bool v_ok = lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M;
+                const long off = v_ok ? (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8 : 0;
+                r[i] = *reinterpret_cast<const half8*>(p.p + off);
+                ok |= (v_ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = base + i * 256 + tid;
+                if (idx < TV * 4) *reinterpret_cast<half8*>(pl + (idx >> 2) * ROWB + (idx & 3) * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
+            }
         }
         __syncthreads();
         // ---- contraction over the tile's voxels, 16 per MFMA --------------------------------------
@@ -116,7 +152,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
             for (int ti = 0; ti < TPW; ++ti) {
                 const int tap = wave + 4 * ti;
                 if (tap < p.taps.ntaps) {
-                    const char* qt = qa + (int)p.taps.pos_off[tap] * ROWB;
+                    const char* qt = qa + tpos[ti] * ROWB;
                     half4 b0 = lds_tr16(qt), b1 = lds_tr16(qt + 4 * IS * ROWB);
                     half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                     acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
@@ -130,7 +166,145 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
     for (int ti = 0; ti < TPW; ++ti) {
         const int tap = wave + 4 * ti;
         if (tap < p.taps.ntaps) {
-            float* panel = p.dwp + (long)p.taps.slot[tap] * p.Mpad * p.Cpad;
+            float* panel = p.dwp + (long)tap_slot[tap] * p.Mpad * p.Cpad;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
+                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2 for the stride-1 3x3x3 case (2/3 of all wgrad FLOPs sit in the two highest resolutions): same MFMA /
+// transpose-read mapping, but (a) unpadded 64-byte LDS rows with the 16-byte-slot XOR swizzle of
+// igemm_conv_v2 (4 consecutive rows x 64 B = one conflict-free 256-byte bank row per 32 lanes),
+// (b) double-buffered LDS: the next tile's global loads are issued before the MFMAs of the current tile,
+// parked in registers and written to the other buffer afterwards -- one barrier per tile.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wswz(int row, int byte_in_row) {
+    return row * 64 + ((((byte_in_row >> 4) ^ ((row >> 2) & 3)) << 4) | (byte_in_row & 15));
+}
+
+__global__ __launch_bounds__(256, 1) void igemm_wgrad_s1_v2_kernel(const WgradParams p) {
+    constexpr int TZ = 4, TY = 8, TX = 8, TV = TZ * TY * TX, PZ = 6, PY = 10, PX = 10, P = PZ * PY * PX, TPW = 7;
+    constexpr int QB = P * 64, PB = TV * 64, STAGE = QB + PB;
+    constexpr int QN = (P * 4 + 255) / 256, PN = TV * 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
+    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
+    const int chb = (cb + 4 * sq) * 2;                 // byte offset of this lane's 4 channels inside a row
+    const int p_row = 8 * hk + sj;                     // + 16*ch (+4 for the second read)
+    const int q_row = hk * PX + sj;                    // + tile-row offset + tap offset (+4 for the second read)
+
+    floatx16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
+    if (t_begin >= t_end) return;
+
+    // unconditional loads + validity masks (see igemm_conv_v2.hip: predicated loads get serialised by hipcc)
+    half8 qr[QN], pr[PN];
+    unsigned qok = 0, pok = 0;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int tz = t % p.tiles_z; t /= p.tiles_z;
+        const int n = t;
+        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+        const long qbase = (long)n * p.Qd * p.Qh * p.Qw;
+        qok = 0; pok = 0;
+#pragma unroll
+        for (int i = 0; i < QN; ++i) {
+            const int idx = min(i * 256 + tid, P * 4 - 1);
+            const int pos = idx >> 2, c8 = idx & 3;
+            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+            const int iz = lz0 - 1 + pz, iy = ly0 - 1 + py, ix = lx0 - 1 + px;
+            const bool ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
+                            c0 + c8 * 8 < p.C;
+            const long off = ok ? (qbase + ((long)iz * p.Qh + iy) * p.Qw + ix) * p.ld_q + c0 + c8 * 8 : 0;
+            qr[i] = *reinterpret_cast<const half8*>(p.q + off);
+            qok |= (ok ? 1u : 0u) << i;
+        }
+        const long pbase = (long)n * p.Ld * p.Lh * p.Lw;
+#pragma unroll
+        for (int i = 0; i < PN; ++i) {
+            const int idx = i * 256 + tid;
+            const int vox = idx >> 2, c8 = idx & 3;
+            const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
+            const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
+            const bool ok = lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M;
+            const long off = ok ? (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8 : 0;
+            pr[i] = *reinterpret_cast<const half8*>(p.p + off);
+            pok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto store_tile = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < QN; ++i) {
+            const int idx = i * 256 + tid;
+            if (idx < P * 4) *reinterpret_cast<half8*>(stage + wswz(idx >> 2, (idx & 3) << 4)) = ((qok >> i) & 1u) ? qr[i] : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < PN; ++i) {
+            const int idx = i * 256 + tid;
+            *reinterpret_cast<half8*>(stage + QB + wswz(idx >> 2, (idx & 3) << 4)) = ((pok >> i) & 1u) ? pr[i] : zero8;
+        }
+    };
+
+    int tapoff[TPW];   // halo-tile offset of this wave's taps, computed arithmetically (no table gather in the loop)
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = __builtin_amdgcn_readfirstlane(wave) + 4 * ti;
+        tapoff[ti] = ((tap / 9) * PY + (tap / 3) % 3) * PX + tap % 3;
+    }
+    load_tile(t_begin);
+    store_tile(smem);
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool more = tile + 1 < t_end;
+        if (more) load_tile(tile + 1);
+        const char* ql = smem + buf * STAGE;
+        const char* pl = ql + QB;
+#pragma unroll 2
+        for (int ch = 0; ch < TV / 16; ++ch) {
+            const int row = 2 * ch, z = row / TY, y = row % TY;
+            const int pr0 = ch * 16 + p_row;
+            const half4 a0 = lds_tr16(pl + wswz(pr0, chb)), a1 = lds_tr16(pl + wswz(pr0 + 4, chb));
+            const half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const int qbase_row = (z * PY + y) * PX + q_row;
+#pragma unroll
+            for (int ti = 0; ti < TPW; ++ti) {
+                const int tap = wave + 4 * ti;
+                if (tap < 27) {
+                    const int qr0 = qbase_row + tapoff[ti];
+                    const half4 b0 = lds_tr16(ql + wswz(qr0, chb)), b1 = lds_tr16(ql + wswz(qr0 + 4, chb));
+                    const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_tile(smem + (buf ^ 1) * STAGE);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int c = c0 + (lane & 31);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = wave + 4 * ti;
+        if (tap < 27) {
+            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
@@ -224,7 +398,7 @@ int launch_wgrad(hipStream_t s, WgradParams& p, const char* name) {
     if (tpb < 1) tpb = 1;
     if (tpb > 32) tpb = 32;
     p.tiles_per_block = tpb;
-    const size_t lds = (size_t)(P + TV) * 80;
+    const size_t lds = (size_t)(P + TV) * 80 + 256;   // + tap tables
     auto kern = igemm_wgrad_kernel<IS, EXT, TZ, TY, TPW>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -234,6 +408,28 @@ int launch_wgrad(hipStream_t s, WgradParams& p, const char* name) {
     dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
+
+int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
+    constexpr int TZ = 4, TY = 8, TX = 8;
+    p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
+    p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
+    const int panels = (p.Mpad / 32) * (p.Cpad / 32);
+    // one block per CU (109 KB LDS): spread tiles x panels over ~256 blocks, >= 1 tile per block
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, 256);
+    if (tpb < 1) tpb = 1;
+    if (tpb > p.tiles_total) tpb = p.tiles_total;
+    p.tiles_per_block = tpb;
+    const size_t lds = 2 * (size_t)(600 + 256) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    hipLaunchKernelGGL(igemm_wgrad_s1_v2_kernel, grid, dim3(256), lds, s, p);
+    LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v2)");
     return LNN_OK;
 }
 
@@ -301,7 +497,10 @@ extern "C" int lnn_conv3d_wgrad(lnn_stream_t s_, const void* x, int ld_x, const 
             p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
             p.taps.slot[t] = (unsigned char)t;
         }
-        return launch_wgrad<1, 3, 4, 8, 7>(s, p, "lnn_conv3d_wgrad(s1)");
+        static int use_v1 = -1;
+        if (use_v1 < 0) { const char* e = getenv("LNN_CONV_V1"); use_v1 = (e && e[0] == '1') ? 1 : 0; }
+        if (use_v1) return launch_wgrad<1, 3, 4, 8, 7>(s, p, "lnn_conv3d_wgrad(s1)");
+        return launch_wgrad_s1_v2(s, p);
     }
     constexpr int PY = 2 * 3 + 3, PX = 2 * 7 + 3;  // IS=2, TZ=2, TY=4, TX=8
     for (int t = 0; t < 27; ++t) {

@@ -83,8 +83,9 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
             last = b == n - 1
             if self.fisher_mode != "accumulate" and not last:
                 next(self.tr_gen)                           # discarded pass of the reference
-                if b == 0:
-                    list(self.loss.network_params)          # ... which would have exhausted the generator
+                if b == 0 and len(self.loss.tasks) > 0:
+                    list(self.loss.network_params)          # ... which would have exhausted the generator (the task
+                                                            # loop of DS.py:65-66 only runs when previous tasks exist)
                 continue
             self.optimizer.zero_grad()
             data_dict = next(self.tr_gen)

@@ -1,0 +1,195 @@
+"""Continual-learning parity (-m gpu): the fused EWC / LwF loss classes against values produced by the REFERENCE's
+own classes (tests/golden/*_reference.npz), and the EWC / LwF / Sequential trainer flows against the CPU oracle."""
+import json
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import losses as olosses, train as otrain          # noqa: E402
+from oracle.unet import OracleGenericUNet                       # noqa: E402
+from lifelong_nnunet_amd import get_trainer_class               # noqa: E402
+from lifelong_nnunet_amd.engine import ParamArena, ParamSlot    # noqa: E402
+from lifelong_nnunet_amd.losses import (DC_and_CE_loss, MultipleOutputLossEWC, MultipleOutputLossLWF,   # noqa: E402
+                                        ds_loss_weights)
+from lifelong_nnunet_amd.training.network_training.multihead.nnUNetTrainerMultiHead import default_data_provider  # noqa: E402
+
+DEV = "cuda:0"
+TOY = {"patch_size": (16, 16, 16), "batch_size": 2, "num_pool": 2, "base_num_features": 8, "num_classes": 3,
+       "num_input_channels": 1, "synthetic_period": 4}
+
+
+def _base():
+    return DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {})
+
+
+def test_ewc_loss_class_matches_reference_values(golden_dir):
+    d = np.load(golden_dir + "/ewc_reference.npz")
+    names = json.load(open(golden_dir + "/meta.json"))["ewc"]["names"]
+    slots = [ParamSlot(n, tuple(d[f"theta_{i}"].shape)) for i, n in enumerate(names)]
+    arena = ParamArena(slots, DEV)
+    fake_net = types.SimpleNamespace(arena=arena)
+    params = []
+    for i, s in enumerate(slots):
+        p = torch.nn.Parameter(arena.view(s))
+        p._lnn_net, p._lnn_slot = fake_net, s
+        with torch.no_grad():
+            p.copy_(torch.from_numpy(d[f"theta_{i}"]))
+        p.grad = arena.view(s, "grad")
+        params.append((s.name, p))
+    fisher = {t: {n: torch.from_numpy(d[f"fisher_{t}_{i}"]) for i, n in enumerate(names)} for t in ("taskA", "taskB")}
+    star = {t: {n: torch.from_numpy(d[f"star_{t}_{i}"]) for i, n in enumerate(names)} for t in ("taskA", "taskB")}
+    xs = tuple(torch.from_numpy(d[f"logits_{i}"]).to(DEV) for i in range(2))
+    ys = [torch.from_numpy(d[f"target_{i}"]).to(DEV) for i in range(2)]
+    lam = float(d["lambda"])
+    # generator semantics (what nnUNetTrainerEWC hands over): first task only
+    loss = MultipleOutputLossEWC(_base(), d["ds_weights"], lam, fisher, star, iter(params))
+    v = loss(xs, ys)
+    assert abs(float(v) - float(d["ref_value_generator"])) <= 1e-5 * abs(float(d["ref_value_generator"]))
+    arena.grad.zero_()
+    v.backward()
+    for i, (n, p) in enumerate(params):
+        assert torch.allclose(p.grad.cpu(), torch.from_numpy(d[f"grad_generator_{i}"]), rtol=1e-4, atol=1e-6)
+    # the generator is now exhausted: no penalty until update_network_params (EWC.py:247)
+    v2 = loss(xs, ys)
+    assert abs(float(v2) - float(d["base_loss"])) <= 1e-5 * abs(float(d["base_loss"]))
+    loss.update_network_params(iter(params))
+    assert abs(float(loss(xs, ys)) - float(d["ref_value_generator"])) <= 1e-5 * abs(float(d["ref_value_generator"]))
+    # list semantics (ewc_unet variants): every task
+    loss.update_network_params(list(params))
+    assert abs(float(loss(xs, ys)) - float(d["ref_value_list"])) <= 1e-5 * abs(float(d["ref_value_list"]))
+    assert abs(float(loss(xs, ys, reg=False)) - float(d["base_loss"])) <= 1e-5 * abs(float(d["base_loss"]))
+
+
+def test_lwf_loss_class_matches_reference_values(golden_dir):
+    d = np.load(golden_dir + "/lwf_reference.npz")
+    xs = tuple(torch.from_numpy(d[f"logits_{i}"]).to(DEV).requires_grad_(True) for i in range(2))
+    ys = [torch.from_numpy(d[f"target_{i}"]).to(DEV) for i in range(2)]
+    preds = [torch.from_numpy(d[f"pred_{i}"]).to(DEV) for i in range(3)]
+    teach = [torch.from_numpy(d[f"teach_{i}"]) for i in range(2)]        # the reference keeps targets on the CPU
+    w = ds_loss_weights(2)
+    for T in (1, 2):
+        loss = MultipleOutputLossLWF(_base(), w, list(), list(), float(T))
+        loss.update_logits(preds, teach)
+        v = loss(xs, ys)
+        assert abs(float(v) - float(d[f"ref_value_T{T}"])) <= 1e-5 * abs(float(d[f"ref_value_T{T}"]))
+    # the distillation term carries NO gradient (LWF.py:343): d(loss)/d(logits) == d(base)/d(logits)
+    g = torch.autograd.grad(v, xs[0])[0].cpu()
+    xo = torch.from_numpy(d["logits_0"]).requires_grad_(True)
+    ob = olosses.multiple_output_loss([xo, torch.from_numpy(d["logits_1"])], [t.cpu() for t in ys], w)
+    go = torch.autograd.grad(ob, xo)[0]
+    assert float((g - go).abs().max()) <= 1e-4 * float(go.abs().max())
+
+
+def _make_trainer(ext, task, **kw):
+    tr = get_trainer_class(ext)("seg_outputs", task, plans=dict(TOY), device=DEV, **kw)
+    tr.initialize(True, num_epochs=1)
+    tr.num_batches_per_epoch, tr.num_val_batches_per_epoch = 3, 1
+    return tr
+
+
+def _flat(dct, names):
+    return torch.cat([dct[n].detach().float().cpu().reshape(-1) for n in names])
+
+
+def test_ewc_trainer_flow_matches_oracle():
+    torch.manual_seed(12345)
+    onet = OracleGenericUNet(1, 8, 3, 2)
+    tr = _make_trainer("ewc", "taskA")
+    tr.network.load_state_dict(onet.state_dict())
+    tr.mh_network.update_after_iteration()
+    w = olosses.ds_loss_weights(2)
+    oopt = otrain.make_optimizer(onet, lr=tr.optimizer.param_groups[0]['lr'])
+    # ---- task A on both sides: 3 training iterations, then after_train on the next 3 batches
+    tr.run_training("taskA")
+    gen = default_data_provider("taskA", "train", TOY)
+    olosses_a = []
+    for _ in range(3):
+        b = next(gen)
+        oopt.param_groups[0]['lr'] = 1e-2 * (1 - 0 / 1) ** 0.9
+        olosses_a.append(otrain.run_iteration(onet, oopt, b['data'], b['target'], w)[0])
+    assert abs(tr.all_tr_losses[0] - np.mean(olosses_a)) <= 1e-4 * abs(np.mean(olosses_a))
+    batches = [(b['data'], b['target']) for b in (next(gen) for _ in range(3))]
+    ofisher, oparams = otrain.ewc_after_train(onet, oopt, batches, w)
+    names = [n for n, _ in onet.named_parameters()]
+    assert list(tr.fisher["taskA"].keys()) == names
+    # zero-weight deep-supervision head: Fisher = tensor([1]) on both sides (EWC.py:300-301)
+    assert tuple(tr.fisher["taskA"]["seg_outputs.0.weight"].shape) == (1,) == tuple(ofisher["seg_outputs.0.weight"].shape)
+    real = [n for n in names if n != "seg_outputs.0.weight"]
+    fg, fo = _flat(tr.fisher["taskA"], real), _flat(ofisher, real)
+    rel_f = float((fg - fo).norm() / fo.norm())
+    pg, po = _flat(tr.params["taskA"], names), _flat(oparams, names)
+    rel_p = float((pg - po).norm() / po.norm())
+    print(f"fisher rel err {rel_f:.3e}  theta* rel err {rel_p:.3e}")
+    assert rel_f < 5e-2 and rel_p < 1e-3
+    # ---- task B, first iteration: sync the oracle to the GPU state, compare base + EWC penalty
+    onet.load_state_dict(tr.network.state_dict())
+    of = {"taskA": {n: tr.fisher["taskA"][n].cpu() for n in names}}
+    op = {"taskA": {n: tr.params["taskA"][n].cpu() for n in names}}
+    tr.reinitialize("taskB")
+    tr.mh_network.add_new_task("taskB", use_init=True)
+    tr.network = tr.mh_network.assemble_model("taskB")
+    onet.load_state_dict(tr.network.state_dict())
+    b = next(default_data_provider("taskB", "train", TOY))
+    out = onet(b['data'])
+    o_total = olosses.multiple_output_loss(out, b['target'], w) + olosses.ewc_penalty(onet.named_parameters(), of, op, 0.4)
+    g_total = tr.run_iteration(tr.tr_gen, True)
+    print(f"task B iter 0: oracle {float(o_total):.6f} hip {float(g_total):.6f}")
+    assert abs(float(g_total) - float(o_total)) <= 1e-4 * abs(float(o_total))
+    pen = float(olosses.ewc_penalty(onet.named_parameters(), of, op, 0.4))
+    assert pen > 0          # the new head differs from theta* of the old head -> the penalty is live
+
+
+def test_lwf_trainer_flow():
+    tr = _make_trainer("lwf", "taskA")
+    tr.run_training("taskA")
+    body0 = {n: p.detach().clone() for n, p in tr.mh_network.body.named_parameters()}
+    seen = {}
+    orig = tr._run_epoch_loop
+
+    def spy():
+        if tr.freeze_run and "frozen" not in seen:
+            r = orig()
+            seen["frozen"] = all(torch.equal(body0[n], p) for n, p in tr.mh_network.body.named_parameters())
+            seen["head_moved"] = not torch.equal(tr.mh_network.heads["taskB"].seg_outputs._modules["1"].weight,
+                                                 tr.mh_network.heads["taskA"].seg_outputs._modules["1"].weight)
+            return r
+        return orig()
+    tr._run_epoch_loop = spy
+    tr.run_training("taskB")
+    assert seen["frozen"] and seen["head_moved"]               # phase 1: body frozen, new head trained
+    assert set(tr.target_logits.keys()) == {"taskA", "taskB"} and all(len(v) == 3 for v in tr.target_logits.values())
+    assert tr.batch_idx == 3
+    # phase 3 value = base + KL(old head on the current body || stored teacher), recomputed with the oracle
+    loss = tr.LwFloss
+    assert len(loss.target_logits) == 1 and len(loss.pred_logits) == 2
+    kl_o = float(olosses.lwf_distillation(loss.pred_logits[0].cpu(), loss.target_logits[0].cpu(), 2.0))
+    from lifelong_nnunet_amd.losses import kl_logits
+    assert abs(float(kl_logits(loss.pred_logits[0], loss.target_logits[0], 2.0)) - kl_o) <= 1e-4 * abs(kl_o) + 1e-9
+    assert not all(torch.equal(body0[n], p) for n, p in tr.mh_network.body.named_parameters())   # phase 3 trains the body
+
+
+def test_sequential_trainer_heads_and_checkpoint():
+    """What the reference's integration test asserts (test_multi_head_trainer.py:336,366-411), on synthetic tasks."""
+    tr = _make_trainer("sequential", "taskA")
+    assert [n.split('.')[0] for n, _ in tr.network.named_parameters()][0] == "conv_blocks_context"   # reordered (SEQ.py:65)
+    h0 = tr.mh_network.heads["taskA"].seg_outputs._modules["1"].weight.detach().clone()
+    tr.run_training("taskA")
+    hA = tr.mh_network.heads["taskA"].seg_outputs._modules["1"].weight.detach().clone()
+    assert not torch.equal(h0, hA)                                            # head weights changed after training
+    ck = tr.save_checkpoint()
+    tr.run_training("taskB")
+    assert tr.mh_network.active_task == "taskB"
+    assert torch.equal(tr.mh_network.heads["taskA"].seg_outputs._modules["1"].weight, hA)   # previous head untouched
+    assert not torch.equal(tr.mh_network.heads["taskB"].seg_outputs._modules["1"].weight, hA)  # transferred, then trained
+    sd = tr.mh_network.state_dict()
+    assert all(torch.equal(sd["model." + n], sd["heads.taskB." + n]) for n in ("seg_outputs.0.weight", "seg_outputs.1.weight"))
+    res = tr._perform_validation(num_batches=1)
+    assert set(res.keys()) == {"taskA", "taskB"} and all(0.0 <= r["mean_dice"] <= 1.0 for r in res.values())
+    tr2 = _make_trainer("sequential", "taskA")
+    tr2.load_checkpoint_ram(ck)
+    sd2 = tr2.mh_network.state_dict()
+    assert all(torch.equal(sd2[k].cpu(), v) for k, v in ck["state_dict"].items())
