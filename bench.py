@@ -141,9 +141,12 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("LNN_FORCE_DP", "0") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from lifelong_nnunet_amd import get_trainer_class, native as nat
     plans = dict(WORKLOADS[args.workload])
@@ -213,7 +216,7 @@ def main():
         info = nat.device_info()
         out["device"] = info
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

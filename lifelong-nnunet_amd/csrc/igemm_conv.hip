@@ -284,8 +284,9 @@ template <int IS, int EXT, int TZ, int TY, int CK, int MT>
 int launch_igemm(hipStream_t s, ConvParams& p, const char* name) {
     using Cfg = ConvCfg<IS, EXT, TZ, TY, CK, MT>;
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, Cfg::TX);
-    // weight taps per group: as many as fit next to the input tile in <= 64 KB total (2 blocks / CU)
-    const int budget = 64 * 1024 - Cfg::xbytes;
+    // weight taps per group: as many as fit next to the input tile in <= 64 KB total (2 blocks / CU); the
+    // input-stride-2 tiles are large (69 KB), there one block per CU with all taps resident beats 27 regroupings
+    const int budget = (IS == 2 ? 150 : 64) * 1024 - Cfg::xbytes;
     int tpg = budget / (Cfg::MB * Cfg::WROWB);
     if (tpg < 1) tpg = 1;
     if (tpg > p.taps.ntaps) tpg = p.taps.ntaps;

@@ -4,13 +4,14 @@
 // data gradient).  Same GEMM mapping as igemm_conv.hip (MFMA rows = output channels, columns = 32 voxels,
 // v_mfma_f32_32x32x16_f16) but the staging is restructured around the LDS capacity of a gfx950 CU:
 //
-//   * one block (4 waves) per CU walks a contiguous range of work units (spatial tile x 32*MT output
-//     channels); the pipeline runs ACROSS unit boundaries, so there is no per-tile ramp-up;
+//   * TWO blocks (4 waves each) per CU, each walking a contiguous range of work units (spatial tile x 32*MT
+//     output channels); the pipeline runs ACROSS unit boundaries, so there is no per-tile ramp-up, and the
+//     co-resident block's MFMAs cover this block's LDS / VALU / barrier latencies;
 //   * a step = (input-channel chunk of 32, dz plane of 3x3 taps).  While the MFMAs of step s run, the global
-//     loads of step s+1 (9 weight panels + one third of the next halo tile) are in flight into registers;
-//     they are written to the OTHER LDS buffer after the MFMAs, followed by the step's single barrier;
+//     loads of step s+1 (9 weight panels) and one third of the NEXT halo tile are in flight into registers;
+//     weights are written to LDS between two barriers after the MFMAs, the halo tile when its pair ends;
 //   * LDS rows are 64 B (32 channels) with an XOR swizzle of the 16-B slot ((row >> 2) & 3) instead of
-//     padding: conflict-free ds_read_b128 fragment reads and 2 x (37.5 KB halo + 18 KB*MT weights) <= 149 KB.
+//     padding: conflict-free ds_read_b128 fragment reads, 37.5 KB halo + 18 KB*MT weights <= 73.5 KB / block.
 #include "igemm_common.h"
 
 namespace {
@@ -29,13 +30,13 @@ struct Pair {   // one (work unit, channel chunk)
 };
 
 template <int MT>
-__global__ __launch_bounds__(256, 1) void igemm_conv_s1_v2_kernel(const ConvParams p, int units_total, int mblocks,
+__global__ __launch_bounds__(256, 2) void igemm_conv_s1_v2_kernel(const ConvParams p, int units_total, int mblocks,
                                                                   int units_per_block) {
     constexpr int VT = 2, MB = 32 * MT;
     constexpr int WBYTES = 9 * MB * 64, WCHUNKS = 9 * MB * 4, WN = (WCHUNKS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto xb = [&](int i) { return smem + (i & 1) * XBYTES; };
-    auto wb = [&](int i) { return smem + 2 * XBYTES + (i & 1) * WBYTES; };
+    char* const xb = smem;
+    char* const wb = smem + XBYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = lane & 31, hk = lane >> 5;
@@ -65,13 +66,13 @@ __global__ __launch_bounds__(256, 1) void igemm_conv_s1_v2_kernel(const ConvPara
     // Prefetch registers.  The global loads are UNCONDITIONAL (out-of-range lanes read element 0 of the tensor
     // and are zeroed when the value is written to LDS): a predicated load makes hipcc wrap each one in an
     // exec-mask branch with s_waitcnt vmcnt(0) in front, which serialises the whole prefetch.
-    half8 xr[XN], wr[WN];
-    unsigned xok = 0, wok = 0;
+    half8 xr[3][XN], wr[WN];
+    unsigned xok[3] = {0, 0, 0}, wok = 0;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    auto load_x = [&](const Pair& t, int j) {
+    auto load_x = [&](const Pair& t, int j, half8 (&dst)[XN], unsigned& okmask) {
         const long base_n = (long)t.n * p.Di * p.Hi * p.Wi;
-        xok = 0;
+        unsigned xok = 0;
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
             const int li = min(i * 256 + tid, XTHIRD - 1);
@@ -82,17 +83,18 @@ __global__ __launch_bounds__(256, 1) void igemm_conv_s1_v2_kernel(const ConvPara
             const bool ok = (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
                             t.c0 + c4 * 8 < p.C;
             const long off = ok ? (base_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + t.c0 + c4 * 8 : 0;
-            xr[i] = *reinterpret_cast<const half8*>(p.x + off);
+            dst[i] = *reinterpret_cast<const half8*>(p.x + off);
             xok |= (ok ? 1u : 0u) << i;
         }
+        okmask = xok;
     };
-    auto store_x = [&](char* buf, int j) {
+    auto store_x = [&](char* buf, int j, const half8 (&src)[XN], unsigned xok) {
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
             const int li = i * 256 + tid;
             if (li < XTHIRD) {
                 const int idx = j * XTHIRD + li;
-                *reinterpret_cast<half8*>(buf + swz(idx >> 2, idx & 3)) = ((xok >> i) & 1u) ? xr[i] : zero8;
+                *reinterpret_cast<half8*>(buf + swz(idx >> 2, idx & 3)) = ((xok >> i) & 1u) ? src[i] : zero8;
             }
         }
     };
@@ -132,16 +134,15 @@ __global__ __launch_bounds__(256, 1) void igemm_conv_s1_v2_kernel(const ConvPara
 
     // ---- prologue: first halo tile + first weight group, synchronously --------------------------------
     Pair cur = decode(0);
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-        load_x(cur, j);
-        store_x(xb(0), j);
+        load_x(cur, j, xr[j], xok[j]);
+        store_x(xb, j, xr[j], xok[j]);
     }
     load_w(cur, 0);
-    store_w(wb(0));
+    store_w(wb);
     __syncthreads();
 
-    int step = 0;
 #pragma unroll 1
     for (int q = 0; q < nq; ++q) {
         const Pair nxt = decode(q + 1);
@@ -153,21 +154,24 @@ __global__ __launch_bounds__(256, 1) void igemm_conv_s1_v2_kernel(const ConvPara
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
         }
-        const char* xl = xb(q);
-#pragma unroll 1
+        const char* xl = xb;
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             const bool more = !(q == nq - 1 && j == 2);
             // ---- issue next step's global loads (in flight during the MFMAs below) ----
-            if (nxt.valid) load_x(nxt, j);
+            if (nxt.valid) load_x(nxt, j, xr[j], xok[j]);
             if (more) {
                 if (j < 2) load_w(cur, j + 1); else load_w(nxt, 0);
             }
             // ---- MFMAs of this step: 9 taps x 2 k-slices ----
-            const char* wl = wb(step);
+            const char* wl = wb;
             const int joff = j * PY * PX;
+#pragma unroll 1
+            for (int dyy = 0; dyy < 3; ++dyy)
 #pragma unroll
-            for (int tl = 0; tl < 9; ++tl) {
-                const int toff = joff + (tl / 3) * PX + tl % 3;     // compile-time (dy, dx): no table lookup in the hot loop
+            for (int dxx = 0; dxx < 3; ++dxx) {
+                const int tl = dyy * 3 + dxx;
+                const int toff = joff + dyy * PX + dxx;              // arithmetic: no table lookup in the hot loop
                 int bpos[VT];
 #pragma unroll
                 for (int vt = 0; vt < VT; ++vt) bpos[vt] = basepos[vt] + toff;
@@ -187,11 +191,14 @@ __global__ __launch_bounds__(256, 1) void igemm_conv_s1_v2_kernel(const ConvPara
                             acc[mt][vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[vt], acc[mt][vt], 0, 0, 0);
                 }
             }
-            // ---- land the prefetched data in the other buffers, one barrier per step ----
-            if (nxt.valid) store_x(xb(q + 1), j);
-            if (more) store_w(wb(step + 1));
+            // ---- land the prefetched data: barrier (readers done) -> LDS writes -> barrier ----
             __syncthreads();
-            ++step;
+            if (more) store_w(wb);
+            if (j == 2 && nxt.valid) {
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) store_x(xb, jj, xr[jj], xok[jj]);
+            }
+            __syncthreads();
         }
         if (cur.last_chunk) {
             // ---- epilogue: lane holds voxel (lane&31) x channels {8*q + 4*hk + 0..3} per accumulator quad ----
@@ -243,10 +250,10 @@ int launch(hipStream_t s, ConvParams& p, const char* name) {
         else cached_cu = 256;
     }
     num_cu = cached_cu;
-    int upb = lnn_cdiv(units, num_cu);
+    int upb = lnn_cdiv(units, 2 * num_cu);     // two resident blocks per CU
     if (upb < 1) upb = 1;
     const int grid = lnn_cdiv(units, upb);
-    const size_t lds = 2 * XBYTES + 2 * (size_t)(9 * MB * 64);
+    const size_t lds = XBYTES + (size_t)(9 * MB * 64);
     auto kern = igemm_conv_s1_v2_kernel<MT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -261,5 +268,7 @@ int launch(hipStream_t s, ConvParams& p, const char* name) {
 }  // namespace
 
 int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name) {
-    return p.M > 32 ? launch<2>(s, p, name) : launch<1>(s, p, name);
+    // MT = 1 everywhere: with two resident blocks per CU (<= 256 VGPRs per lane) the MT = 2 instance spills its
+    // prefetch registers; output channels beyond 32 become additional work units instead (halo tile re-read from L2).
+    return launch<1>(s, p, name);
 }

@@ -180,14 +180,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
 // v2 for the stride-1 3x3x3 case (2/3 of all wgrad FLOPs sit in the two highest resolutions): same MFMA /
 // transpose-read mapping, but (a) unpadded 64-byte LDS rows with the 16-byte-slot XOR swizzle of
 // igemm_conv_v2 (4 consecutive rows x 64 B = one conflict-free 256-byte bank row per 32 lanes),
-// (b) double-buffered LDS: the next tile's global loads are issued before the MFMAs of the current tile,
-// parked in registers and written to the other buffer afterwards -- one barrier per tile.
+// (b) register prefetch: the next tile's global loads are issued before the MFMAs of the current tile, parked
+// in registers and written to LDS between two barriers afterwards; 54 KB LDS / block -> two blocks per CU,
+// so one block's staging and barriers are covered by the other block's MFMAs.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wswz(int row, int byte_in_row) {
     return row * 64 + ((((byte_in_row >> 4) ^ ((row >> 2) & 3)) << 4) | (byte_in_row & 15));
 }
 
-__global__ __launch_bounds__(256, 1) void igemm_wgrad_s1_v2_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradParams p) {
     constexpr int TZ = 4, TY = 8, TX = 8, TV = TZ * TY * TX, PZ = 6, PY = 10, PX = 10, P = PZ * PY * PX, TPW = 7;
     constexpr int QB = P * 64, PB = TV * 64, STAGE = QB + PB;
     constexpr int QN = (P * 4 + 255) / 256, PN = TV * 4 / 256;
@@ -270,12 +271,11 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_s1_v2_kernel(const WgradPa
     load_tile(t_begin);
     store_tile(smem);
     __syncthreads();
-    int buf = 0;
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
         const bool more = tile + 1 < t_end;
         if (more) load_tile(tile + 1);
-        const char* ql = smem + buf * STAGE;
+        const char* ql = smem;
         const char* pl = ql + QB;
 #pragma unroll 2
         for (int ch = 0; ch < TV / 16; ++ch) {
@@ -295,9 +295,9 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_s1_v2_kernel(const WgradPa
                 }
             }
         }
-        if (more) store_tile(smem + (buf ^ 1) * STAGE);
+        __syncthreads();                 // every wave is done reading this tile
+        if (more) store_tile(smem);
         __syncthreads();
-        buf ^= 1;
     }
     const int c = c0 + (lane & 31);
 #pragma unroll
@@ -416,12 +416,12 @@ int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
     p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
     const int panels = (p.Mpad / 32) * (p.Cpad / 32);
-    // one block per CU (109 KB LDS): spread tiles x panels over ~256 blocks, >= 1 tile per block
-    int tpb = lnn_cdiv((long)p.tiles_total * panels, 256);
+    // two blocks per CU (54 KB LDS each): spread tiles x panels over ~512 blocks, >= 1 tile per block
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, 512);
     if (tpb < 1) tpb = 1;
     if (tpb > p.tiles_total) tpb = p.tiles_total;
     p.tiles_per_block = tpb;
-    const size_t lds = 2 * (size_t)(600 + 256) * 64;
+    const size_t lds = (size_t)(600 + 256) * 64;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -29,10 +29,12 @@ def make_buckets(size: int, bucket_elems: int) -> List[Tuple[int, int]]:
 
 
 class GradAllReducer:
-    def __init__(self, grad: torch.Tensor, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True):
+    def __init__(self, grad: torch.Tensor, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True,
+                 force: bool = False):
         self.grad = grad
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or force)   # force: exercise the path on one rank
         self.buckets = make_buckets(grad.numel(), max(1, bucket_bytes // grad.element_size()))
         self.overlap = overlap and grad.is_cuda
         self.stream = torch.cuda.Stream() if grad.is_cuda else None
@@ -47,7 +49,7 @@ class GradAllReducer:
         self.next = 0
 
     def _launch(self, lo, hi):
-        if self.world == 1:
+        if not self.active:
             return
         view = self.grad[lo:hi]
         if self.stream is not None:
@@ -71,7 +73,7 @@ class GradAllReducer:
         while self.next < len(self.buckets):
             self._launch(*self.buckets[self.next])
             self.next += 1
-        if self.stream is not None and self.world > 1:
+        if self.stream is not None and self.active:
             torch.cuda.current_stream().wait_stream(self.stream)
 
 

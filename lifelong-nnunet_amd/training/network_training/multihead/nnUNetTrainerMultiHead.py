@@ -95,9 +95,11 @@ class nnUNetTrainerMultiHead:
             self.val_gen = self.data_provider(self.task, "val", self.plans)
         self.initialize_optimizer_and_scheduler()
         self.amp_grad_scaler = GradScaler()
+        import os
+        force_dp = os.environ.get("LNN_FORCE_DP", "0") == "1"
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size(self.process_group) > 1:
-            self.dp = GradAllReducer(self.network.arena.grad, self.process_group)
+                (torch.distributed.get_world_size(self.process_group) > 1 or force_dp):
+            self.dp = GradAllReducer(self.network.arena.grad, self.process_group, force=force_dp)
         self.was_initialized = True
 
     def initialize_network(self):
