@@ -178,28 +178,26 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // v2 for the stride-1 3x3x3 case (2/3 of all wgrad FLOPs sit in the two highest resolutions): same MFMA /
-// transpose-read mapping, but (a) unpadded 64-byte LDS rows with the 16-byte-slot XOR swizzle of
-// igemm_conv_v2 (4 consecutive rows x 64 B = one conflict-free 256-byte bank row per 32 lanes),
+// transpose-read mapping, but (a) unpadded, unswizzled 64-byte LDS rows (4 consecutive rows x 64 B = one
+// conflict-free 256-byte bank row per 32 lanes; every read address = per-lane register + immediate),
 // (b) register prefetch: the next tile's global loads are issued before the MFMAs of the current tile, parked
 // in registers and written to LDS between two barriers afterwards; 54 KB LDS / block -> two blocks per CU,
 // so one block's staging and barriers are covered by the other block's MFMAs.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wswz(int row, int byte_in_row) {
-    return row * 64 + ((((byte_in_row >> 4) ^ ((row >> 2) & 3)) << 4) | (byte_in_row & 15));
-}
-
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradParams p) {
     constexpr int TZ = 4, TY = 8, TX = 8, TV = TZ * TY * TX, PZ = 6, PY = 10, PX = 10, P = PZ * PY * PX, TPW = 7;
-    constexpr int QB = P * 64, PB = TV * 64, STAGE = QB + PB;
+    constexpr int QB = P * 64;
     constexpr int QN = (P * 4 + 255) / 256, PN = TV * 4 / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ql = smem;        // [P][64 B]   linear rows: 4 consecutive rows = one 256-byte bank row, so the
+    char* const pl = smem + QB;   // [TV][64 B]  transpose reads (4 voxels x 32 B per 16-lane group) are conflict free
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
     const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
     const int chb = (cb + 4 * sq) * 2;                 // byte offset of this lane's 4 channels inside a row
-    const int p_row = 8 * hk + sj;                     // + 16*ch (+4 for the second read)
-    const int q_row = hk * PX + sj;                    // + tile-row offset + tap offset (+4 for the second read)
+    const int p_addr = (8 * hk + sj) * 64 + chb;       // + ch*1024 (+256 for the second read)
+    const int q_lane = (hk * PX + sj) * 64 + chb;      // + chunk-row offset + tap offset (+256)
 
     floatx16 acc[TPW];
 #pragma unroll
@@ -210,6 +208,21 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
     const int t_begin = blockIdx.x * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
     if (t_begin >= t_end) return;
+
+    // per-thread staging constants (tile independent): 32-bit offsets relative to the tile origin
+    int qrel[QN], prel0;      // P-tile loads: thread i*256+tid -> plane z = i of the tile, so prel[i] = prel0 + i*plane
+#pragma unroll
+    for (int i = 0; i < QN; ++i) {
+        const int idx = min(i * 256 + tid, P * 4 - 1);
+        const int pos = idx >> 2, c8 = idx & 3;
+        const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+        qrel[i] = ((pz * p.Qh + py) * p.Qw + px) * p.ld_q + c8 * 8;
+    }
+    {
+        const int vox = tid >> 2, c8 = tid & 3;
+        prel0 = ((vox / TX) * p.Lw + vox % TX) * p.ld_p + c8 * 8;
+    }
+    const int pplane = p.Lh * p.Lw * p.ld_p;
 
     // unconditional loads + validity masks (see igemm_conv_v2.hip: predicated loads get serialised by hipcc)
     half8 qr[QN], pr[PN];
@@ -222,81 +235,88 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
         const int tz = t % p.tiles_z; t /= p.tiles_z;
         const int n = t;
         const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
-        const long qbase = (long)n * p.Qd * p.Qh * p.Qw;
-        qok = 0; pok = 0;
+        const long qbase = ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + c0;
+        const long pbase = ((((long)n * p.Ld + lz0) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
+        const bool interior = lz0 >= 1 && ly0 >= 1 && lx0 >= 1 && lz0 + TZ + 1 <= p.Qd && ly0 + TY + 1 <= p.Qh &&
+                              lx0 + TX + 1 <= p.Qw && c0 + 32 <= p.C && m0 + 32 <= p.M;
+        if (interior) {
+            const half_t* qp = p.q + qbase;
+            const half_t* pp = p.p + pbase;
 #pragma unroll
-        for (int i = 0; i < QN; ++i) {
-            const int idx = min(i * 256 + tid, P * 4 - 1);
-            const int pos = idx >> 2, c8 = idx & 3;
-            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-            const int iz = lz0 - 1 + pz, iy = ly0 - 1 + py, ix = lx0 - 1 + px;
-            const bool ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
-                            c0 + c8 * 8 < p.C;
-            const long off = ok ? (qbase + ((long)iz * p.Qh + iy) * p.Qw + ix) * p.ld_q + c0 + c8 * 8 : 0;
-            qr[i] = *reinterpret_cast<const half8*>(p.q + off);
-            qok |= (ok ? 1u : 0u) << i;
-        }
-        const long pbase = (long)n * p.Ld * p.Lh * p.Lw;
+            for (int i = 0; i < QN; ++i) qr[i] = *reinterpret_cast<const half8*>(qp + qrel[i]);
 #pragma unroll
-        for (int i = 0; i < PN; ++i) {
-            const int idx = i * 256 + tid;
-            const int vox = idx >> 2, c8 = idx & 3;
-            const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
-            const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
-            const bool ok = lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M;
-            const long off = ok ? (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8 : 0;
-            pr[i] = *reinterpret_cast<const half8*>(p.p + off);
-            pok |= (ok ? 1u : 0u) << i;
+            for (int i = 0; i < PN; ++i) pr[i] = *reinterpret_cast<const half8*>(pp + i * pplane + prel0);
+            qok = 0xFFFFu; pok = 0xFFFFu;
+        } else {
+            qok = 0; pok = 0;
+#pragma unroll
+            for (int i = 0; i < QN; ++i) {
+                const int idx = min(i * 256 + tid, P * 4 - 1);
+                const int pos = idx >> 2, c8 = idx & 3;
+                const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+                const int iz = lz0 - 1 + pz, iy = ly0 - 1 + py, ix = lx0 - 1 + px;
+                const bool ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
+                                c0 + c8 * 8 < p.C;
+                qr[i] = *reinterpret_cast<const half8*>(p.q + (ok ? qbase + qrel[i] : 0));
+                qok |= (ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < PN; ++i) {
+                const int idx = i * 256 + tid;
+                const int vox = idx >> 2, c8 = idx & 3;
+                const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
+                const bool ok = lz0 + z < p.Ld && ly0 + y < p.Lh && lx0 + x < p.Lw && m0 + c8 * 8 < p.M;
+                pr[i] = *reinterpret_cast<const half8*>(p.p + (ok ? pbase + i * pplane + prel0 : 0));
+                pok |= (ok ? 1u : 0u) << i;
+            }
         }
     };
-    auto store_tile = [&](char* stage) {
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < QN; ++i) {
             const int idx = i * 256 + tid;
-            if (idx < P * 4) *reinterpret_cast<half8*>(stage + wswz(idx >> 2, (idx & 3) << 4)) = ((qok >> i) & 1u) ? qr[i] : zero8;
+            if (idx < P * 4) *reinterpret_cast<half8*>(ql + idx * 16) = ((qok >> i) & 1u) ? qr[i] : zero8;
         }
 #pragma unroll
         for (int i = 0; i < PN; ++i) {
             const int idx = i * 256 + tid;
-            *reinterpret_cast<half8*>(stage + QB + wswz(idx >> 2, (idx & 3) << 4)) = ((pok >> i) & 1u) ? pr[i] : zero8;
+            *reinterpret_cast<half8*>(pl + idx * 16) = ((pok >> i) & 1u) ? pr[i] : zero8;
         }
     };
 
-    int tapoff[TPW];   // halo-tile offset of this wave's taps, computed arithmetically (no table gather in the loop)
+    int tapaddr[TPW];   // per-lane halo-tile byte address of this wave's taps (no table gather in the loop)
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
         const int tap = __builtin_amdgcn_readfirstlane(wave) + 4 * ti;
-        tapoff[ti] = ((tap / 9) * PY + (tap / 3) % 3) * PX + tap % 3;
+        tapaddr[ti] = q_lane + (((tap / 9) * PY + (tap / 3) % 3) * PX + tap % 3) * 64;
     }
     load_tile(t_begin);
-    store_tile(smem);
+    store_tile();
     __syncthreads();
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
         const bool more = tile + 1 < t_end;
         if (more) load_tile(tile + 1);
-        const char* ql = smem;
-        const char* pl = ql + QB;
-#pragma unroll 2
+#pragma unroll
         for (int ch = 0; ch < TV / 16; ++ch) {
-            const int row = 2 * ch, z = row / TY, y = row % TY;
-            const int pr0 = ch * 16 + p_row;
-            const half4 a0 = lds_tr16(pl + wswz(pr0, chb)), a1 = lds_tr16(pl + wswz(pr0 + 4, chb));
+            // chunk rows 2ch, 2ch+1: immediates, the per-lane part lives in p_addr / tapaddr
+            constexpr int dummy = 0; (void)dummy;
+            const int pimm = ch * 1024;
+            const int qimm = (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64;
+            const half4 a0 = lds_tr16(pl + pimm + p_addr), a1 = lds_tr16(pl + pimm + 256 + p_addr);
             const half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            const int qbase_row = (z * PY + y) * PX + q_row;
 #pragma unroll
             for (int ti = 0; ti < TPW; ++ti) {
                 const int tap = wave + 4 * ti;
                 if (tap < 27) {
-                    const int qr0 = qbase_row + tapoff[ti];
-                    const half4 b0 = lds_tr16(ql + wswz(qr0, chb)), b1 = lds_tr16(ql + wswz(qr0 + 4, chb));
+                    const half4 b0 = lds_tr16(ql + qimm + tapaddr[ti]), b1 = lds_tr16(ql + qimm + 256 + tapaddr[ti]);
                     const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                     acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
                 }
             }
         }
         __syncthreads();                 // every wave is done reading this tile
-        if (more) store_tile(smem);
+        if (more) store_tile();
         __syncthreads();
     }
     const int c = c0 + (lane & 31);

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the MFMA kernel families on single layers (HIP-event timing through the C-ABI).
+    python tools/kbench.py [--layers dec4.0,enc0.1,...] [--iters 5] [--which fwd,dgrad,wgrad]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lifelong_nnunet_amd import native as nat
+
+LAYERS = {  # name: (N, C, K, D, H, W, stride)
+    "dec4.0": (2, 64, 32, 160, 192, 160, 1), "enc0.1": (2, 32, 32, 160, 192, 160, 1),
+    "dec3.0": (2, 128, 64, 80, 96, 80, 1), "enc1.1": (2, 64, 64, 80, 96, 80, 1),
+    "dec2.0": (2, 256, 128, 40, 48, 40, 1), "enc3.1": (2, 256, 256, 20, 24, 20, 1),
+    "enc1.0s2": (2, 32, 64, 160, 192, 160, 2), "enc2.0s2": (2, 64, 128, 80, 96, 80, 2),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", default="dec4.0,enc0.1,dec3.0,enc1.1,dec2.0,enc1.0s2")
+    ap.add_argument("--which", default="fwd,dgrad,wgrad")
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    dev = "cuda:0"
+    for name in a.layers.split(","):
+        N, C, K, D, H, W, s = LAYERS[name]
+        Do, Ho, Wo = [(x - 1) // s + 1 for x in (D, H, W)]
+        x = (torch.randn((N, D, H, W, C), device=dev) * 0.5).half()
+        dy = (torch.randn((N, Do, Ho, Wo, K), device=dev) * 0.5).half()
+        y = torch.empty_like(dy)
+        dx = torch.empty_like(x)
+        w = torch.randn((K, C, 3, 3, 3), device=dev) * 0.05
+        b = torch.zeros(K, device=dev)
+        wf = torch.empty(nat.query("lnn_packed_weight_elems", 27, K, C), dtype=torch.float16, device=dev)
+        wd = torch.empty(nat.query("lnn_packed_weight_elems", 27, C, K), dtype=torch.float16, device=dev)
+        nat.call("lnn_pack_weights", w, wf, 27, K, C, C * 27, 27, 1)
+        nat.call("lnn_pack_weights", w, wd, 27, C, K, 27, C * 27, 1)
+        panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 27, K, C), device=dev)
+        flops = 2.0 * N * Do * Ho * Wo * C * K * 27
+        fns = {"fwd": lambda: nat.call("lnn_conv3d_fwd", x, C, wf, b, y, K, N, D, H, W, C, K, s),
+               "dgrad": lambda: nat.call("lnn_conv3d_dgrad", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0),
+               "wgrad": lambda: nat.call("lnn_conv3d_wgrad", x, C, dy, K, panel, N, D, H, W, C, K, s)}
+        out = []
+        for k in a.which.split(","):
+            fn = fns[k]
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / a.iters * 1e-3
+            out.append(f"{k} {t*1e3:7.3f} ms {flops/t/1e12:6.0f} TF/s")
+        print(f"{name:9s} {C:4d}->{K:<4d} @{D}x{H}x{W} s{s} : " + " | ".join(out), flush=True)
+        del x, dy, y, dx
+
+
+if __name__ == "__main__":
+    main()
