@@ -22,6 +22,7 @@ struct ConvParams {
     int os, par_z, par_y, par_x;
     int pad_lo;
     int accumulate;
+    unsigned long long* dbg;   // optional phase-cycle accumulators (LNN_DEBUG_PHASES), null in production
     TapTable taps;
 };
 

@@ -313,6 +313,10 @@ int dispatch_ck_mt(hipStream_t s, ConvParams& p, const char* name) {
     return mt2 ? launch_igemm<IS, EXT, TZ, TY, 16, 2>(s, p, name) : launch_igemm<IS, EXT, TZ, TY, 16, 1>(s, p, name);
 }
 
+// debug hook: phase-cycle accumulators for the v3 kernel (tools/kbench.py --phases)
+static unsigned long long* g_dbg = nullptr;
+extern "C" int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64) { g_dbg = (unsigned long long*)dev_ptr_6x_u64; return LNN_OK; }
+
 // LNN_CONV_V1=1 selects the non-pipelined kernel for the stride-1 convs (A/B measurements only)
 bool use_v2() {
     static int v = -1;
@@ -366,6 +370,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
             p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
             p.taps.slot[t] = (unsigned char)t;
         }
+        p.dbg = g_dbg;
         if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v2)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
@@ -405,6 +410,7 @@ extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, cons
             p.taps.pos_off[t] = (unsigned short)((dz * PY + dyy) * PX + dxx);
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
+        p.dbg = g_dbg;
         if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v2)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
     }

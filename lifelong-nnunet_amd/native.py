@@ -55,6 +55,7 @@ SIGNATURES = {
     "lnn_sgd_nesterov_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
     "lnn_cast_f32_to_h": (_i, [_p, _p, _p, _l]),
     "lnn_debug_tr16_probe": (_i, [_p, _p]),
+    "lnn_debug_set_phase_buffer": (_i, [_p]),
 }
 
 _lib = None

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--layers", default="dec4.0,enc0.1,dec3.0,enc1.1,dec2.0,enc1.0s2")
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--phases", action="store_true", help="print the v3 conv kernel's per-phase cycle split")
     a = ap.parse_args()
     dev = "cuda:0"
     for name in a.layers.split(","):
@@ -54,6 +55,16 @@ def main():
             t = e0.elapsed_time(e1) / a.iters * 1e-3
             out.append(f"{k} {t*1e3:7.3f} ms {flops/t/1e12:6.0f} TF/s")
         print(f"{name:9s} {C:4d}->{K:<4d} @{D}x{H}x{W} s{s} : " + " | ".join(out), flush=True)
+        if a.phases and s == 1:
+            dbg = torch.zeros(6, dtype=torch.int64, device=dev)
+            nat.lib().lnn_debug_set_phase_buffer(dbg.data_ptr())
+            fns["fwd"](); torch.cuda.synchronize()
+            nat.lib().lnn_debug_set_phase_buffer(None)
+            d = dbg.cpu().tolist()
+            steps = max(d[5], 1)
+            names = ["issue", "mfma", "store", "barrier"]
+            print("   phases (cycles per wave-step): " + ", ".join(f"{n} {d[i]/steps:7.0f}" for i, n in enumerate(names)) +
+                  f"  | total {sum(d[:4])/steps:7.0f}", flush=True)
         del x, dy, y, dx
 
 
