@@ -85,7 +85,7 @@ def kernel_rooflines(trainer):
 
 def cpu_baseline(plans, flops_full):
     """The oracle (pure PyTorch CPU fp32 restatement of the reference's step) on the GPU box's host cores, on a
-    bounded sample: the SAME 5-level network on a 64x64x64 sub-patch (5.3 % of the voxels), B=1, one warm-up and
+    bounded sample: the SAME 5-level network on a 128x128x128 sub-patch (43 % of the voxels), B=1, one warm-up and
     one timed iteration; converted to full-size patches/s by the voxel ratio."""
     import torch
     from oracle import losses as olosses, train as otrain
@@ -94,7 +94,7 @@ def cpu_baseline(plans, flops_full):
     cores = min(os.cpu_count() or 1, 32)     # oneDNN conv3d stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(cores)
     q = 2 ** plans["num_pool"]
-    sub = tuple(max(2 * q, min(64, (p // 2) // q * q)) for p in plans["patch_size"])      # divisible by 2^num_pool
+    sub = tuple(max(2 * q, min(128, p // q * q)) for p in plans["patch_size"])      # divisible by 2^num_pool, ~10 s of CPU work
     torch.manual_seed(0)
     net = OracleGenericUNet(1, plans["base_num_features"], plans["num_classes"], plans["num_pool"])
     opt = otrain.make_optimizer(net)
@@ -201,7 +201,7 @@ def main():
         kr = kernel_rooflines(tr)
         dom = min(kr["kernels"].items(), key=lambda kv: kv[1]["tflops"])     # the slowest family bounds the stack
         fwd = kr["kernels"]["igemm_conv_fwd"]
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_conv_kernel (fwd) on " + kr["layer"], "achieved": fwd["tflops"],
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_conv_s1_v5_kernel (stride-1 3x3x3 conv fwd) on " + kr["layer"], "achieved": fwd["tflops"],
                            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": fwd["tflops"] / PEAK_MFMA_F16_TFLOPS,
                            "traffic": None, "launch_ms": fwd["ms"], "algorithmic_gflop_per_launch": fwd["gflop"],
                            "other_kernels": {k: {"achieved": v["tflops"], "frac": v["tflops"] / PEAK_MFMA_F16_TFLOPS,

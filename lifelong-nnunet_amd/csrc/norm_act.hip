@@ -54,6 +54,7 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[0][e] = part[1][e] = 0.f;
     if (rm.active) {
+#pragma unroll 4
         for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
             const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
 #pragma unroll
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
     }
     const half_t* yn = y + (long)n * V * C;
     half_t* zn = z + (long)n * V * ld_z;
+#pragma unroll 4
     for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
         const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
         half8 o;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
         }
         const half_t* yn = y + (long)n * V * C;
         const half_t* dzn = dz + (long)n * V * ld_dz;
+#pragma unroll 4
         for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
             const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
             const half8 d = *reinterpret_cast<const half8*>(dzn + v * ld_dz + rm.c8 * 8);
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
         }
         half_t* yn = y + (long)n * V * C;
         const half_t* dzn = dz + (long)n * V * ld_dz;
+#pragma unroll 4
         for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
             half8* yp = reinterpret_cast<half8*>(yn + v * C + rm.c8 * 8);
             const half8 x = *yp;
