@@ -24,6 +24,18 @@ __device__ __forceinline__ RowMap row_map(int C) {
     return r;
 }
 
+// Each block streams ONE contiguous range of voxels (multiple of VPB).  (Measured equal to a grid-stride walk on
+// MI355X: these kernels sit at 3.5-5 TB/s either way.)
+__device__ __forceinline__ long vrange_len(long V, const RowMap& rm) {
+    const long per = (V + gridDim.x - 1) / gridDim.x;
+    return (per + rm.VPB - 1) / rm.VPB * rm.VPB;
+}
+__device__ __forceinline__ long vrange_begin(long V, const RowMap& rm) { return (long)blockIdx.x * vrange_len(V, rm); }
+__device__ __forceinline__ long vrange_end(long V, const RowMap& rm) {
+    const long e = vrange_begin(V, rm) + vrange_len(V, rm);
+    return e < V ? e : V;
+}
+
 // Sum per-thread partials part[NA][8] over the voxel lanes of the block and hand each (a, channel)
 // total to `sink(a, channel, value)`.
 template <int NA, typename Sink>
@@ -54,8 +66,7 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[0][e] = part[1][e] = 0.f;
     if (rm.active) {
-#pragma unroll 4
-        for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
+        for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
             const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -96,8 +107,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
     }
     const half_t* yn = y + (long)n * V * C;
     half_t* zn = z + (long)n * V * ld_z;
-#pragma unroll 4
-    for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
+    for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
         const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
         half8 o;
 #pragma unroll
@@ -129,8 +139,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
         }
         const half_t* yn = y + (long)n * V * C;
         const half_t* dzn = dz + (long)n * V * ld_dz;
-#pragma unroll 4
-        for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
+        for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
             const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
             const half8 d = *reinterpret_cast<const half8*>(dzn + v * ld_dz + rm.c8 * 8);
 #pragma unroll
@@ -171,8 +180,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
         }
         half_t* yn = y + (long)n * V * C;
         const half_t* dzn = dz + (long)n * V * ld_dz;
-#pragma unroll 4
-        for (long v = (long)blockIdx.x * rm.VPB + rm.vl; v < V; v += (long)gridDim.x * rm.VPB) {
+        for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
             half8* yp = reinterpret_cast<half8*>(yn + v * C + rm.c8 * 8);
             const half8 x = *yp;
             const half8 d = *reinterpret_cast<const half8*>(dzn + v * ld_dz + rm.c8 * 8);
