@@ -29,3 +29,5 @@ struct ConvParams {
 
 // v2 stride-1 3x3x3 kernel (igemm_conv_v2.hip): persistent blocks, software-pipelined staging.
 int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);
+// v6 (igemm_conv_v6.hip): two wave groups per block running half a step out of phase (compute / memory ping-pong).
+int lnn_launch_conv_s1_v6(hipStream_t s, ConvParams& p, const char* name);

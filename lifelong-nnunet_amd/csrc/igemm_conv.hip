@@ -327,6 +327,17 @@ bool use_v2() {
     return v == 1;
 }
 
+// LNN_CONV_V6=1 selects the ping-pong v6 kernel instead of v5 (A/B measurements only; v6 measured 5-15 % slower:
+// a lone wave per SIMD does not keep the matrix pipe busy through its LDS read latencies)
+bool use_v6() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LNN_CONV_V6");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 int check_act(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -371,7 +382,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
             p.taps.slot[t] = (unsigned char)t;
         }
         p.dbg = g_dbg;
-        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v2)");
+        if (use_v2()) return use_v6() ? lnn_launch_conv_s1_v6(s, p, "lnn_conv3d_fwd(s1,v6)") : lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
     {
@@ -411,7 +422,7 @@ extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, cons
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
         p.dbg = g_dbg;
-        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v2)");
+        if (use_v2()) return use_v6() ? lnn_launch_conv_s1_v6(s, p, "lnn_conv3d_dgrad(s1,v6)") : lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
     }
     // stride 2: dx[2l+par] = sum over taps d with (par - d + 1) even: dy[l + (par - d + 1)/2]
