@@ -201,9 +201,16 @@ def main():
         kr = kernel_rooflines(tr)
         dom = min(kr["kernels"].items(), key=lambda kv: kv[1]["tflops"])     # the slowest family bounds the stack
         fwd = kr["kernels"]["igemm_conv_fwd"]
+        traffic, traffic_note = None, None
+        try:      # HBM bytes per launch of the same kernel/launch from the committed PMC passes (separate rocprofv3 runs)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic, traffic_note = tj["hbm_bytes_per_launch_corrected"], "profiles/r01_pmc_traffic.json: " + tj["note"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_conv_s1_v5_kernel (stride-1 3x3x3 conv fwd) on " + kr["layer"], "achieved": fwd["tflops"],
                            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": fwd["tflops"] / PEAK_MFMA_F16_TFLOPS,
-                           "traffic": None, "launch_ms": fwd["ms"], "algorithmic_gflop_per_launch": fwd["gflop"],
+                           "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_note,
+                           "launch_ms": fwd["ms"], "algorithmic_gflop_per_launch": fwd["gflop"],
                            "other_kernels": {k: {"achieved": v["tflops"], "frac": v["tflops"] / PEAK_MFMA_F16_TFLOPS,
                                                  "launch_ms": v["ms"]} for k, v in kr["kernels"].items()},
                            "slowest_family": dom[0]}

@@ -282,6 +282,9 @@ class UNetEngine:
         self.ws = torch.zeros(max(nat.query("lnn_instnorm_ws_doubles", N, cmax), 64), dtype=torch.float64, device=dev)
         self.packed_version = -1
         self.unused_heads: List[str] = []
+        self._side = None
+        import os
+        self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # arena offset right after each item's parameter slots (= start of the next item's slots)
         self._watermark = {}
         for item in order:
@@ -365,6 +368,23 @@ class UNetEngine:
         self.gpanels.zero_()
         self.unused_heads = []
         seg_u = len(self.segs)
+        # Weight gradients are off the critical path of backward (they only have to be final before the optimiser /
+        # the all-reduce): they are enqueued on a SIDE HIP stream right after the layer's dL/dy exists, so the
+        # MFMA/LDS-bound wgrad kernels overlap the HBM-bound InstanceNorm passes and the dgrads of the layers below.
+        main = torch.cuda.current_stream()
+        # (with a data-parallel progress hook the watermark protocol needs gradients final in stream order: no overlap)
+        side = self._side_stream() if (self.overlap_wgrad and progress is None) else None
+
+        def on_side(fn):
+            if side is None:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn()
+
         for item in reversed(self.order):
             if progress is not None and item is not self.order[-1]:
                 progress(self._watermark[id(item)])   # everything after this item in the arena is final
@@ -391,23 +411,37 @@ class UNetEngine:
                 xin = self.image if item.x is None else item.x
                 ldx = 1 if item.x is None else item.x.ld
                 K, C = item.cout, item.cin
-                nat.call("lnn_conv3d_wgrad", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K, item.stride)
                 gw = self.pview(item.w, self.grad)
-                if C == 1:
-                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 1, K, 27, 27, 1, 0, 1.0, 1)
-                else:
-                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 27, K, C, C * 27, 27, 1, 1.0, 1)
+
+                def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W, gw=gw):
+                    nat.call("lnn_conv3d_wgrad", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K, item.stride)
+                    if C == 1:
+                        nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 1, K, 27, 27, 1, 0, 1.0, 1)
+                    else:
+                        nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 27, K, C, C * 27, 27, 1, 1.0, 1)
+                on_side(conv_wgrad)
+                if C != 1:
                     if item.gx is not None:
                         nat.call("lnn_conv3d_dgrad", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld, N, D, H, W,
                                  C, K, item.stride, 1 if item.gx_accumulate else 0)
             else:  # UpBlock
                 D, H, W = item.x.dims
                 C, K = item.cin, item.cout
-                nat.call("lnn_convT3d_k2s2_wgrad", item.x, item.x.ld, item.gy, item.gy.ld, self._pn(item.panel),
-                         N, D, H, W, C, K)
-                nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), 8, C, K, K * 8, 8, 1, 1.0, 1)
+
+                def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
+                    nat.call("lnn_convT3d_k2s2_wgrad", item.x, item.x.ld, item.gy, item.gy.ld, self._pn(item.panel),
+                             N, D, H, W, C, K)
+                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), 8, C, K, K * 8, 8, 1, 1.0, 1)
+                on_side(up_wgrad)
                 nat.call("lnn_convT3d_k2s2_dgrad", item.gy, item.gy.ld, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
                          N, D, H, W, C, K, 0)
+        if side is not None:
+            main.wait_stream(side)      # every weight gradient is final before anything downstream (norm, step)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # ------------------------------------------------------------------------------------------ stats
     def flops_per_patch(self):
