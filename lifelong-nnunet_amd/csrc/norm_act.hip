@@ -212,9 +212,10 @@ __global__ void in_lrelu_bwd_finalize_kernel(const double* ws, int N, int C, flo
         s2 += ws[((long)n * C + c) * 3 + 1];
         db += ws[((long)n * C + c) * 3 + 2];
     }
-    if (dgamma) dgamma[c] += (float)(s2 * unscale);
-    if (dbeta) dbeta[c] += (float)(s1 * unscale);
-    if (dbias) dbias[c] += (float)(db * unscale);
+    // atomics: two sample lanes (HIP streams) may finalise the same layer concurrently
+    if (dgamma) atomicAdd(dgamma + c, (float)(s2 * unscale));
+    if (dbeta) atomicAdd(dbeta + c, (float)(s1 * unscale));
+    if (dbias) atomicAdd(dbias + c, (float)(db * unscale));
 }
 
 int blocks_for(long V, int C) {

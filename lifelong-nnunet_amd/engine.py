@@ -283,8 +283,12 @@ class UNetEngine:
         self.packed_version = -1
         self.unused_heads: List[str] = []
         self._side = None
+        self._lstreams, self._lws = [], []
         import os
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
+        # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
+        # little room), kept because it is the natural hook for per-sample pipelining across GPUs / larger batches
+        self.sample_lanes = os.environ.get("LNN_SAMPLE_LANES", "0") == "1"
         # arena offset right after each item's parameter slots (= start of the next item's slots)
         self._watermark = {}
         for item in order:
@@ -320,6 +324,46 @@ class UNetEngine:
                 nat.call("lnn_pack_weights", w, self._wp(item.wp_dgrad), 8, C, K, K * 8, 8, 1)
         self.packed_version = self.arena.version
 
+    # ------------------------------------------------------------------------------------------ sample lanes
+    # Patches are independent through the whole network (InstanceNorm is per sample), so a batch is processed as up to
+    # two "lanes" of samples on separate HIP streams: while one lane runs an MFMA-bound convolution (one 8-wave block
+    # per CU) the other lane's HBM-bound InstanceNorm / seg / loss-side kernels find free wave slots and LDS.
+    def _lanes(self):
+        if not self.sample_lanes or self.N < 2:
+            return [(0, self.N)]
+        h = self.N // 2
+        return [(0, h), (h, self.N - h)]
+
+    def _lane_streams(self, n):
+        while len(self._lstreams) < n:
+            self._lstreams.append(torch.cuda.Stream(device=self.device))
+            self._lws.append(torch.zeros_like(self.ws))
+        return self._lstreams[:n]
+
+    @staticmethod
+    def _at(obj, n0):
+        """Pointer to sample n0 of an activation (Act) or batch-major tensor."""
+        if isinstance(obj, Act):
+            return _Ptr(obj.buf, n0 * obj.V * obj.ld + obj.off)
+        return obj[n0:]
+
+    def _fork(self, fn):
+        """Run fn(n0, nn, ws) for every lane; lanes beyond the first on their own stream, joined before returning."""
+        lanes = self._lanes()
+        if len(lanes) == 1:
+            fn(0, self.N, self.ws)
+            return
+        main = torch.cuda.current_stream()
+        streams = self._lane_streams(len(lanes))
+        ev = torch.cuda.Event()
+        ev.record(main)
+        for (n0, nn), st, ws in zip(lanes, streams, self._lws):
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                fn(n0, nn, ws)
+        for st in streams:
+            main.wait_stream(st)
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, seg_weights: Optional[List[torch.Tensor]] = None, body: bool = True):
         """x: (N,1,D,H,W) float32 on the device.  Returns logits per decoder level u (low-res first, as
@@ -330,50 +374,58 @@ class UNetEngine:
         assert tuple(x.shape) == (N, 1) + self.patch, f"engine built for {(N, 1) + self.patch}, got {tuple(x.shape)}"
         if self.packed_version != self.arena.version:
             self.pack_weights()
-        logits = []
         if body:
             nat.call("lnn_cast_f32_to_h", x.contiguous(), self.image, x.numel())
-        for item in self.order:
-            if isinstance(item, ConvBlock):
-                if not body:
-                    continue
-                D, H, W = item.in_dims
-                xin = self.image if item.x is None else item.x
-                ldx = 1 if item.x is None else item.x.ld
-                nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), item.y, item.cout,
-                         N, D, H, W, item.cin, item.cout, item.stride)
-                V = item.z.V
-                nat.call("lnn_instnorm_stats", item.y, N, V, item.cout, IN_EPS, item.mean, item.rstd, self.ws)
-                nat.call("lnn_instnorm_lrelu_fwd", item.y, item.z, item.z.ld, N, V, item.cout, item.mean, item.rstd,
-                         self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE)
-            elif isinstance(item, UpBlock):
-                if not body:
-                    continue
-                D, H, W = item.x.dims
-                nat.call("lnn_convT3d_k2s2_fwd", item.x, item.x.ld, self._wp(item.wp_fwd), item.y, item.y.ld,
-                         N, D, H, W, item.cin, item.cout)
-            else:
-                u = len(logits)
-                w = self.pview(item.w) if seg_weights is None else seg_weights[u]
-                out = torch.empty((N, self.K) + item.x.dims, device=self.device)
-                nat.call("lnn_seg1x1_fwd", item.x, item.x.ld, w.contiguous(), out, N, item.x.V, item.cin, self.K)
-                logits.append(out)
+        logits = [torch.empty((N, self.K) + seg.x.dims, device=self.device) for seg in self.segs]
+        sw = None if seg_weights is None else [w.contiguous() for w in seg_weights]
+        at = self._at
+
+        def lane(n0, nn, ws):
+            u = 0
+            for item in self.order:
+                if isinstance(item, ConvBlock):
+                    if not body:
+                        continue
+                    D, H, W = item.in_dims
+                    xin = at(self.image, n0) if item.x is None else at(item.x, n0)
+                    ldx = 1 if item.x is None else item.x.ld
+                    C = item.cout
+                    nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
+                             nn, D, H, W, item.cin, C, item.stride)
+                    V = item.z.V
+                    mean, rstd = item.mean[n0 * C:], item.rstd[n0 * C:]
+                    nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
+                    nat.call("lnn_instnorm_lrelu_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
+                             self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE)
+                elif isinstance(item, UpBlock):
+                    if not body:
+                        continue
+                    D, H, W = item.x.dims
+                    nat.call("lnn_convT3d_k2s2_fwd", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
+                             item.y.ld, nn, D, H, W, item.cin, item.cout)
+                else:
+                    w = self.pview(item.w) if sw is None else sw[u]
+                    nat.call("lnn_seg1x1_fwd", at(item.x, n0), item.x.ld, w, logits[u][n0:], nn, item.x.V, item.cin, self.K)
+                    u += 1
+
+        self._fork(lane)
         return logits
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dlogits: List[Optional[torch.Tensor]], skip_body: bool = False, progress=None):
         """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.
         Accumulates parameter gradients into the flat arena ``self.grad`` (scaled like dlogits)."""
-        N = self.N
         self.gpanels.zero_()
-        self.unused_heads = []
-        seg_u = len(self.segs)
+        self.unused_heads = [seg.w.name for seg, dl in zip(self.segs, dlogits) if dl is None]
+        dls = [None if dl is None else dl.contiguous() for dl in dlogits]
+        at = self._at
+        multi = len(self._lanes()) > 1
         # Weight gradients are off the critical path of backward (they only have to be final before the optimiser /
-        # the all-reduce): they are enqueued on a SIDE HIP stream right after the layer's dL/dy exists, so the
-        # MFMA/LDS-bound wgrad kernels overlap the HBM-bound InstanceNorm passes and the dgrads of the layers below.
+        # the all-reduce).  Single lane: they go to a SIDE HIP stream right after the layer's dL/dy exists; two lanes:
+        # each lane already overlaps the other, both accumulate into the same fp32 panels (atomics) and the panels
+        # are folded into the gradient arena once, after the lanes have joined.
         main = torch.cuda.current_stream()
-        # (with a data-parallel progress hook the watermark protocol needs gradients final in stream order: no overlap)
-        side = self._side_stream() if (self.overlap_wgrad and progress is None) else None
+        side = self._side_stream() if (self.overlap_wgrad and progress is None and not multi) else None
 
         def on_side(fn):
             if side is None:
@@ -385,58 +437,76 @@ class UNetEngine:
             with torch.cuda.stream(side):
                 fn()
 
-        for item in reversed(self.order):
-            if progress is not None and item is not self.order[-1]:
-                progress(self._watermark[id(item)])   # everything after this item in the arena is final
-            if isinstance(item, SegHead):
-                seg_u -= 1
-                dl = dlogits[seg_u]
-                if dl is None:
-                    self.unused_heads.append(item.w.name)
-                    if not item.gx_has_prior:
-                        item.gx.buf.zero_()
-                    continue
-                gw = self.pview(item.w, self.grad).view(self.K, item.cin)
-                nat.call("lnn_seg1x1_bwd", item.x, item.x.ld, self.pview(item.w), dl.contiguous(), item.gx, item.gx.ld,
-                         gw, N, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0)
-            elif skip_body:
-                continue
-            elif isinstance(item, ConvBlock):
-                V = item.z.V
-                nat.call("lnn_instnorm_lrelu_bwd", item.y, item.gz, item.gz.ld, N, V, item.cout, item.mean, item.rstd,
-                         self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
-                         self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
-                         self.pview(item.b, self.grad), 1.0, self.ws)
-                D, H, W = item.in_dims
-                xin = self.image if item.x is None else item.x
-                ldx = 1 if item.x is None else item.x.ld
+        def unpack(item):
+            if isinstance(item, ConvBlock):
                 K, C = item.cout, item.cin
                 gw = self.pview(item.w, self.grad)
-
-                def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W, gw=gw):
-                    nat.call("lnn_conv3d_wgrad", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K, item.stride)
-                    if C == 1:
-                        nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 1, K, 27, 27, 1, 0, 1.0, 1)
-                    else:
-                        nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 27, K, C, C * 27, 27, 1, 1.0, 1)
-                on_side(conv_wgrad)
-                if C != 1:
-                    if item.gx is not None:
-                        nat.call("lnn_conv3d_dgrad", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld, N, D, H, W,
-                                 C, K, item.stride, 1 if item.gx_accumulate else 0)
-            else:  # UpBlock
-                D, H, W = item.x.dims
+                if C == 1:
+                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 1, K, 27, 27, 1, 0, 1.0, 1)
+                else:
+                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 27, K, C, C * 27, 27, 1, 1.0, 1)
+            else:
                 C, K = item.cin, item.cout
+                nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), 8, C, K, K * 8, 8, 1, 1.0, 1)
 
-                def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
-                    nat.call("lnn_convT3d_k2s2_wgrad", item.x, item.x.ld, item.gy, item.gy.ld, self._pn(item.panel),
-                             N, D, H, W, C, K)
-                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), 8, C, K, K * 8, 8, 1, 1.0, 1)
-                on_side(up_wgrad)
-                nat.call("lnn_convT3d_k2s2_dgrad", item.gy, item.gy.ld, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
-                         N, D, H, W, C, K, 0)
+        def lane(n0, nn, ws):
+            seg_u = len(self.segs)
+            for item in reversed(self.order):
+                if progress is not None and not multi and item is not self.order[-1]:
+                    progress(self._watermark[id(item)])   # everything after this item in the arena is final
+                if isinstance(item, SegHead):
+                    seg_u -= 1
+                    dl = dls[seg_u]
+                    if dl is None:
+                        if not item.gx_has_prior:
+                            item.gx.buf[n0:n0 + nn].zero_()
+                        continue
+                    gw = self.pview(item.w, self.grad).view(self.K, item.cin)
+                    nat.call("lnn_seg1x1_bwd", at(item.x, n0), item.x.ld, self.pview(item.w), dl[n0:], at(item.gx, n0),
+                             item.gx.ld, gw, nn, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0)
+                elif skip_body:
+                    continue
+                elif isinstance(item, ConvBlock):
+                    V, K, C = item.z.V, item.cout, item.cin
+                    nat.call("lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
+                             item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                             self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
+                             self.pview(item.b, self.grad), 1.0, ws)
+                    D, H, W = item.in_dims
+                    xin = at(self.image, n0) if item.x is None else at(item.x, n0)
+                    ldx = 1 if item.x is None else item.x.ld
+
+                    def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
+                        nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
+                                 item.stride)
+                        if not multi:
+                            unpack(item)
+                    on_side(conv_wgrad)
+                    if C != 1 and item.gx is not None:
+                        nat.call("lnn_conv3d_dgrad", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
+                                 nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0)
+                else:  # UpBlock
+                    D, H, W = item.x.dims
+                    C, K = item.cin, item.cout
+
+                    def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
+                        nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
+                                 self._pn(item.panel), nn, D, H, W, C, K)
+                        if not multi:
+                            unpack(item)
+                    on_side(up_wgrad)
+                    nat.call("lnn_convT3d_k2s2_dgrad", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
+                             item.gx.ld, nn, D, H, W, C, K, 0)
+
+        self._fork(lane)
         if side is not None:
             main.wait_stream(side)      # every weight gradient is final before anything downstream (norm, step)
+        if multi and not skip_body:
+            for item in self.order:
+                if not isinstance(item, SegHead):
+                    unpack(item)
+        if progress is not None and multi:
+            progress(0)
 
     def _side_stream(self):
         if self._side is None:
