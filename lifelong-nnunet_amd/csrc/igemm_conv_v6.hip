@@ -203,7 +203,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v6_kernel(const ConvParam
 #pragma unroll
                         for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
                 }
-                half8 fa[3], fb[3][VT];
+                constexpr int RA = 4;                 // fragment read-ahead depth (MFMA groups)
+                half8 fa[RA + 1], fb[RA + 1][VT];
                 auto frag = [&](int tl, half8& a, half8 (&b)[VT]) {
                     const int dz = tl / 9, dy = (tl / 3) % 3, dx = tl % 3;
                     const int ximm = ((dz * PY + dy) * PX) * ROWB;
@@ -212,15 +213,15 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v6_kernel(const ConvParam
                     for (int vt = 0; vt < VT; ++vt)
                         b[vt] = *reinterpret_cast<const half8*>(xg + ximm + lterm[vt][dx][dy & 1]);
                 };
-                frag(0, fa[0], fb[0]);
-                frag(1, fa[1], fb[1]);
+#pragma unroll
+                for (int g = 0; g < RA; ++g) frag(g, fa[g], fb[g]);
 #pragma unroll
                 for (int g = 0; g < 27; ++g) {
-                    if (g + 2 < 27) frag(g + 2, fa[(g + 2) % 3], fb[(g + 2) % 3]);
+                    if (g + RA < 27) frag(g + RA, fa[(g + RA) % (RA + 1)], fb[(g + RA) % (RA + 1)]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int vt = 0; vt < VT; ++vt)
-                        acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g % 3], fb[g % 3][vt], acc[vt], 0, 0, 0);
+                        acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g % (RA + 1)], fb[g % (RA + 1)][vt], acc[vt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (cur.last_chunk) {
