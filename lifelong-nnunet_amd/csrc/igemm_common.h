@@ -31,3 +31,7 @@ struct ConvParams {
 int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);
 // v6 (igemm_conv_v6.hip): two wave groups per block running half a step out of phase (compute / memory ping-pong).
 int lnn_launch_conv_s1_v6(hipStream_t s, ConvParams& p, const char* name);
+// single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,
+// all eight output parity classes per block
+int lnn_launch_up2_dgrad(hipStream_t s, ConvParams& p, const char* name);
+int lnn_launch_up2_convT(hipStream_t s, ConvParams& p, const char* name);

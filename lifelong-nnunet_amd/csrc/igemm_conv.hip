@@ -338,6 +338,16 @@ bool use_v6() {
     return v == 1;
 }
 
+// LNN_UP2_V1=1 selects the one-launch-per-parity-class path for stride-2 dgrad / convT forward (A/B measurements only)
+bool use_up2() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LNN_UP2_V1");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int check_act(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -427,6 +437,7 @@ extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, cons
     }
     // stride 2: dx[2l+par] = sum over taps d with (par - d + 1) even: dy[l + (par - d + 1)/2]
     //   par = 0 -> d = 1 (offset 0);  par = 1 -> d = 0 (offset +1), d = 2 (offset 0)
+    if (use_up2()) return lnn_launch_up2_dgrad(s, p, "lnn_conv3d_dgrad(s2,up2)");
     int rc = LNN_OK;
     for (int cls = 0; cls < 8 && rc == LNN_OK; ++cls) {
         const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
@@ -463,6 +474,7 @@ extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s_, const void* x, int ld_x, co
     p.N = N; p.Di = D; p.Hi = H; p.Wi = W; p.Do = 2 * D; p.Ho = 2 * H; p.Wo = 2 * W;
     p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32); p.KCpad = lnn_round_up(C, 16);
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 2; p.pad_lo = 0;
+    if (use_up2()) return lnn_launch_up2_convT(s, p, "lnn_convT3d_k2s2_fwd(up2)");
     int rc = LNN_OK;
     for (int cls = 0; cls < 8 && rc == LNN_OK; ++cls) {
         ConvParams q = p;

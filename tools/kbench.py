@@ -15,6 +15,9 @@ LAYERS = {  # name: (N, C, K, D, H, W, stride)
     "dec2.0": (2, 256, 128, 40, 48, 40, 1), "enc3.1": (2, 256, 256, 20, 24, 20, 1),
     "enc1.0s2": (2, 32, 64, 160, 192, 160, 2), "enc2.0s2": (2, 64, 128, 80, 96, 80, 2),
 }
+UPS = {  # transposed conv k2s2: name: (N, C, K, D, H, W) (low-res extents)
+    "up4": (2, 64, 32, 80, 96, 80), "up3": (2, 128, 64, 40, 48, 40),
+}
 
 
 def main():
@@ -26,6 +29,23 @@ def main():
     a = ap.parse_args()
     dev = "cuda:0"
     for name in a.layers.split(","):
+        if name in UPS:
+            N, C, K, D, H, W = UPS[name]
+            x = (torch.randn((N, D, H, W, C), device=dev) * 0.5).half()
+            y = torch.empty((N, 2 * D, 2 * H, 2 * W, K), dtype=torch.float16, device=dev)
+            wf = torch.randn(nat.query("lnn_packed_weight_elems", 8, K, C), device=dev).half()
+            fn = lambda: nat.call("lnn_convT3d_k2s2_fwd", x, C, wf, y, K, N, D, H, W, C, K)
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / a.iters * 1e-3
+            gb = (x.numel() + y.numel()) * 2 / 1e9
+            print(f"{name:9s} {C:4d}->{K:<4d} convT @{D}x{H}x{W} : fwd {t*1e3:7.3f} ms  {gb/t:6.0f} GB/s algorithmic", flush=True)
+            del x, y
+            continue
         N, C, K, D, H, W, s = LAYERS[name]
         Do, Ho, Wo = [(x - 1) // s + 1 for x in (D, H, W)]
         x = (torch.randn((N, D, H, W, C), device=dev) * 0.5).half()
