@@ -49,7 +49,9 @@ int lnn_device_info(int* cu_count, int* clock_khz, char* name, int name_len);
  * Weight packing (fp32 parameter tensors -> fp16 MFMA operand panels).  No reference counterpart:
  * cuDNN does this internally for nn.Conv3d / nn.ConvTranspose3d under autocast
  * (nnUNetTrainerMultiHead.py:619-621).
- *   dst[t][m][kc] (m padded to 32, kc padded to 16, zero filled) = src[m*stride_m + kc*stride_kc + t*stride_t]
+ *   panel element (t, m, kc) (m padded to 32, kc padded to 16, zero filled) = src[m*stride_m + kc*stride_kc + t*stride_t]
+ *   stored blocked as [m/32][kc/16][t][m%32][kc%16]: the 32x16 MFMA operand tiles of all taps of one
+ *   (row block, channel chunk) are one contiguous run, which the conv kernels stage with fully coalesced loads.
  * ---------------------------------------------------------------------------------------------- */
 int lnn_pack_weights(lnn_stream_t s, const float* src, void* dst_h, int ntaps, int M, int KC,
                      long stride_m, long stride_kc, long stride_t);

@@ -17,6 +17,7 @@ struct ConvParams {
     int ld_x, ld_y;
     int N, Di, Hi, Wi, Do, Ho, Wo;
     int C, M, Mpad, KCpad;
+    int wtaps;                 // tap slots of the weight panel (27, 8 or 1)
     int Ld, Lh, Lw;
     int tiles_z, tiles_y, tiles_x;
     int os, par_z, par_y, par_x;
@@ -26,6 +27,13 @@ struct ConvParams {
     TapTable taps;
 };
 
+
+// Weight panels are blocked for the kernels' staging loads: [Mpad/32][KCpad/16][tap slot][32 rows][16 channels]
+// fp16, i.e. the (32 output channels x 16 input channels) operand tiles of ALL taps of one (row block, chunk) are one
+// contiguous run (27 x 1 KB): a wave-wide 16-byte-per-lane load covers 8 cache lines instead of 32.
+__host__ __device__ __forceinline__ long lnn_panel_off(int slot, int m, int kc, int wtaps, int KCpad) {
+    return ((((long)(m >> 5) * (KCpad >> 4) + (kc >> 4)) * wtaps + slot) * 32 + (m & 31)) * 16 + (kc & 15);
+}
 
 // v2 stride-1 3x3x3 kernel (igemm_conv_v2.hip): persistent blocks, software-pipelined staging.
 int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);

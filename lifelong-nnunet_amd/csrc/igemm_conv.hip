@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvParams p) {
                     const int c8 = idx % CH8, rr = (idx / CH8) % MB, tl = idx / (CH8 * MB);
                     const int slot = tap_slot[g0 + tl];
                     const bool v_ok = m0 + rr < p.Mpad && c0 + c8 * 8 < p.KCpad;
-                    const long off = v_ok ? ((long)slot * p.Mpad + m0 + rr) * p.KCpad + c0 + c8 * 8 : 0;
+                    const long off = v_ok ? lnn_panel_off(slot, m0 + rr, c0 + c8 * 8, p.wtaps, p.KCpad) : 0;
                     r[i] = *reinterpret_cast<const half8*>(p.wp + off);
                     ok |= (v_ok ? 1u : 0u) << i;
                 }
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const ConvParams p) {
         for (int k16 = 0; k16 < 2; ++k16) {
             const int m = m0 + mt * 32 + v;
             half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (m < p.Mpad) val = *reinterpret_cast<const half8*>(p.wp + (long)m * 32 + k16 * 16 + hk * 8);
+            if (m < p.Mpad) val = *reinterpret_cast<const half8*>(p.wp + lnn_panel_off(0, m, k16 * 16 + hk * 8, 1, 32));
             a[mt][k16] = val;
         }
     // tap offsets of this lane's 16 contraction slots
@@ -370,7 +370,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
     p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.bias = bias; p.y = (half_t*)y;
     p.ld_x = ld_x; p.ld_y = ld_y; p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
     p.Do = (Di - 1) / stride + 1; p.Ho = (Hi - 1) / stride + 1; p.Wo = (Wi - 1) / stride + 1;
-    p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32);
+    p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32); p.wtaps = C == 1 ? 1 : 27;
     p.Ld = p.Do; p.Lh = p.Ho; p.Lw = p.Wo; p.os = 1; p.pad_lo = 1; p.accumulate = 0;
     if (C == 1) {
         LNN_REQUIRE(stride == 1, "lnn_conv3d_fwd: C == 1 path supports stride 1 only");
@@ -419,7 +419,7 @@ extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, cons
     // roles: gathered input = dy (K channels), output = dx (C channels); panel wp[slot][C][K]
     p.x = (const half_t*)dy; p.wp = (const half_t*)wp; p.bias = nullptr; p.y = (half_t*)dx;
     p.ld_x = ld_dy; p.ld_y = ld_dx; p.N = N; p.Di = Do; p.Hi = Ho; p.Wi = Wo; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
-    p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16);
+    p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16); p.wtaps = 27;
     p.accumulate = accumulate;
     if (stride == 1) {
         // dx[q] = sum_d w[d]^T dy[q - d + 1]  -> tap offset d' = 2 - d uses slot d
@@ -472,7 +472,7 @@ extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s_, const void* x, int ld_x, co
     ConvParams p{};
     p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.y = (half_t*)y; p.ld_x = ld_x; p.ld_y = ld_y;
     p.N = N; p.Di = D; p.Hi = H; p.Wi = W; p.Do = 2 * D; p.Ho = 2 * H; p.Wo = 2 * W;
-    p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32); p.KCpad = lnn_round_up(C, 16);
+    p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32); p.KCpad = lnn_round_up(C, 16); p.wtaps = 8;
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 2; p.pad_lo = 0;
     if (use_up2()) return lnn_launch_up2_convT(s, p, "lnn_convT3d_k2s2_fwd(up2)");
     int rc = LNN_OK;
@@ -495,7 +495,7 @@ extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy
     // dx[l, c] = sum_d sum_k dy[2l + d, k] W[c, k, d]: gathered input = dy with stride 2, 8 taps
     p.x = (const half_t*)dy; p.wp = (const half_t*)wp; p.y = (half_t*)dx; p.ld_x = ld_dy; p.ld_y = ld_dx;
     p.N = N; p.Di = 2 * D; p.Hi = 2 * H; p.Wi = 2 * W; p.Do = D; p.Ho = H; p.Wo = W;
-    p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16);
+    p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16); p.wtaps = 8;
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 1; p.pad_lo = 0; p.accumulate = accumulate;
     constexpr int PY = 2 * 7 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=8
     p.taps.ntaps = 8;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v5_kernel(const ConvParam
     for (int i = 0; i < WN; ++i) {
         const int idx = min(i * NT + tid, WCHUNKS - 1);
         const int c2 = idx & 1, row = idx >> 1, r = row % MB, tl = row / MB;
-        wrel[i] = ((flip ? 26 - tl : tl) * p.Mpad + r) * p.KCpad + c2 * 8;
+        wrel[i] = ((flip ? 26 - tl : tl) * MB + r) * 16 + c2 * 8;   // blocked panel: one contiguous 27 KB run
         wlds[i] = waddr(row, c2);
     }
 
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v5_kernel(const ConvParam
         }
     };
     auto load_w = [&](int m0, int c0) {     // KCpad is a multiple of 16: a chunk never leaves the padded panel row
-        const half_t* bp = p.wp + (long)m0 * p.KCpad + c0;
+        const half_t* bp = p.wp + lnn_panel_off(0, m0, c0, 27, p.KCpad);
 #pragma unroll
         for (int i = 0; i < WN; ++i) wr[i] = *reinterpret_cast<const half8*>(bp + wrel[i]);
     };

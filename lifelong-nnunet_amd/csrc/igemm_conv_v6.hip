@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v6_kernel(const ConvParam
     for (int i = 0; i < WN; ++i) {
         const int idx = min(i * GT + gtid, WCHUNKS - 1);
         const int c2 = idx & 1, row = idx >> 1, r = row % MB, tl = row / MB;
-        wrel[i] = ((flip ? 26 - tl : tl) * p.Mpad + r) * p.KCpad + c2 * 8;
+        wrel[i] = ((flip ? 26 - tl : tl) * MB + r) * 16 + c2 * 8;   // blocked panel: one contiguous 27 KB run
         wlds[i] = waddr(row, c2);
     }
 
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v6_kernel(const ConvParam
         }
     };
     auto load_w = [&](int c0) {
-        const half_t* bp = p.wp + (long)m0 * p.KCpad + c0;
+        const half_t* bp = p.wp + lnn_panel_off(0, m0, c0, 27, p.KCpad);
 #pragma unroll
         for (int i = 0; i < WN; ++i) wr[i] = *reinterpret_cast<const half8*>(bp + wrel[i]);
     };

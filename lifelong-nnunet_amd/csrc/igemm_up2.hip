@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_up2_kernel(const ConvParams p, in
     for (int i = 0; i < WN; ++i) {
         const int idx = min(i * NT + tid, WCHUNKS - 1);
         const int c2 = idx & 1, row = idx >> 1, r = row % MB, tl = row / MB;
-        wrel[i] = (tl * p.Mpad + r) * p.KCpad + c2 * 8;
+        wrel[i] = (tl * MB + r) * 16 + c2 * 8;     // == idx * 8: the blocked panel chunk is one contiguous run
         wlds[i] = up_waddr(row, c2);
     }
 
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_up2_kernel(const ConvParams p, in
     unsigned xok = 0;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const long xbase = ((((long)n * p.Di + qz0) * p.Hi + qy0) * p.Wi + qx0) * p.ld_x;
-    const half_t* const wbase = p.wp + (long)m0 * p.KCpad;
+    const int nck16 = p.KCpad >> 4;
+    const half_t* const wbase = p.wp + (long)(m0 >> 5) * nck16 * Cfg::NTAP * 512;
 
     // unconditional loads + masks (a predicated load serialises the prefetch, see igemm_conv_v2.hip)
     auto load_x = [&](int c0) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_up2_kernel(const ConvParams p, in
     };
     auto load_w = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < WN; ++i) wr[i] = *reinterpret_cast<const half8*>(wbase + c0 + wrel[i]);
+        for (int i = 0; i < WN; ++i) wr[i] = *reinterpret_cast<const half8*>(wbase + (long)(c0 >> 4) * Cfg::NTAP * 512 + wrel[i]);
     };
     auto store_w = [&](char* buf) {
 #pragma unroll

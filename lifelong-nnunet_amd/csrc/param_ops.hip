@@ -38,8 +38,14 @@ int flat_blocks(long n, int per_thread) {
 __global__ void pack_weights_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int ntaps, int M, int KC, int Mpad,
                                     int KCpad, long sm, long skc, long st) {
     const long total = (long)ntaps * Mpad * KCpad;
+    const int nck = KCpad / 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int kc = (int)(i % KCpad), m = (int)((i / KCpad) % Mpad), t = (int)(i / ((long)KCpad * Mpad));
+        // blocked panel: i = (((mb * nck + ck) * ntaps + t) * 32 + row) * 16 + c16
+        const int c16 = (int)(i & 15), row = (int)((i >> 4) & 31);
+        long r = i >> 9;
+        const int t = (int)(r % ntaps); r /= ntaps;
+        const int ck = (int)(r % nck), mb = (int)(r / nck);
+        const int m = mb * 32 + row, kc = ck * 16 + c16;
         float v = 0.f;
         if (m < M && kc < KC) v = src[m * sm + kc * skc + t * st];
         dst[i] = (half_t)v;
