@@ -43,3 +43,6 @@ int lnn_launch_conv_s1_v6(hipStream_t s, ConvParams& p, const char* name);
 // all eight output parity classes per block
 int lnn_launch_up2_dgrad(hipStream_t s, ConvParams& p, const char* name);
 int lnn_launch_up2_convT(hipStream_t s, ConvParams& p, const char* name);
+// resolution-halving kernels (igemm_down2.hip): stride-2 conv forward / transposed conv k2s2 dgrad
+int lnn_launch_down2_conv(hipStream_t s, ConvParams& p, const char* name);
+int lnn_launch_down2_convT_dgrad(hipStream_t s, ConvParams& p, const char* name);

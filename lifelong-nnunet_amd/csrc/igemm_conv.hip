@@ -348,6 +348,16 @@ bool use_up2() {
     return v == 1;
 }
 
+// LNN_DOWN2_V1=1 selects the generic kernel for stride-2 forward / convT dgrad (A/B measurements only)
+bool use_down2() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LNN_DOWN2_V1");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int check_act(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -395,6 +405,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
         if (use_v2()) return use_v6() ? lnn_launch_conv_s1_v6(s, p, "lnn_conv3d_fwd(s1,v6)") : lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
+    if (use_down2()) return lnn_launch_down2_conv(s, p, "lnn_conv3d_fwd(s2,down2)");
     {
         constexpr int PY = 2 * 7 + 3, PX = 2 * 7 + 3;  // TZ=2, TY=8, TX=8
         for (int t = 0; t < 27; ++t) {
@@ -497,6 +508,7 @@ extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy
     p.N = N; p.Di = 2 * D; p.Hi = 2 * H; p.Wi = 2 * W; p.Do = D; p.Ho = H; p.Wo = W;
     p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16); p.wtaps = 8;
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 1; p.pad_lo = 0; p.accumulate = accumulate;
+    if (use_down2()) return lnn_launch_down2_convT_dgrad(s, p, "lnn_convT3d_k2s2_dgrad(down2)");
     constexpr int PY = 2 * 7 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=8
     p.taps.ntaps = 8;
     for (int t = 0; t < 8; ++t) {
