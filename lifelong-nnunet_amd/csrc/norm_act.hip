@@ -3,12 +3,17 @@
 // Thread layout: a 256-thread block covers VPB = 256 / (C/8) voxels per pass; thread = (voxel lane,
 // 8-channel vector) so that consecutive threads touch consecutive 16-byte vectors (fully coalesced)
 // and every thread keeps a FIXED channel octet -> per-channel partial sums live in registers.
-// Per-(n,c) reductions: fp32 in registers over a short strided run, fp64 atomics across blocks.
+// Per-(n,c) reductions: fp32 in registers over a short strided run, then ONE fp32 partial per (block, n, c) in the
+// workspace, summed in fp64 by a tiny finalize kernel.  (The first version used fp64 atomics across blocks: 1024
+// blocks x N x C x 2 atomics onto N*C*2 addresses serialise in L2 -- the statistics pass of a 64-channel layer took
+// 1.5x as long as the normalise pass that moves twice the bytes -- and needed a memset per call.)
 #include "lnn_common.h"
 
 namespace {
 
 constexpr int NT = 256;
+constexpr int MAX_BLOCKS = 1024;   // blocks_for() cap; the workspace holds 2 fp32 partials per (block, n, c)
+constexpr int UNR = 4;     // independent vector loads in flight per thread
 
 struct RowMap {
     int C8, VPB, c8, vl;
@@ -57,7 +62,8 @@ __device__ __forceinline__ void block_channel_reduce(const RowMap& rm, int C, fl
     }
 }
 
-__global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__ y, long V, int C, double* ws) {
+// partial sums: pws[((a * gridDim.x + block) * N + n) * C + c]
+__global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__ y, long V, int C, float* pws) {
     __shared__ float red[NT * 17];
     const RowMap rm = row_map(C);
     const int n = blockIdx.y;
@@ -66,8 +72,26 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[0][e] = part[1][e] = 0.f;
     if (rm.active) {
-        for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
-            const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
+        // UNR independent 16-byte loads in flight per thread: one load per loop trip left every wave waiting a full
+        // HBM round trip per 1 KB (the kernels sat at 3.6-4.3 TB/s = resident waves x 1 KB / latency)
+        const long end = vrange_end(V, rm), step = rm.VPB;
+        long v = vrange_begin(V, rm) + rm.vl;
+        const half_t* yp = yn + rm.c8 * 8;
+        for (; v + (UNR - 1) * step < end; v += UNR * step) {
+            half8 x[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)x[u][e];
+                    part[0][e] += f;
+                    part[1][e] += f * f;
+                }
+        }
+        for (; v < end; v += step) {
+            const half8 x = *reinterpret_cast<const half8*>(yp + v * C);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)x[e];
@@ -77,15 +101,38 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__
         }
     }
     block_channel_reduce<2>(rm, C, part, red, [&](int a, int c, float s) {
-        atomicAdd(ws + ((long)n * C + c) * 2 + a, (double)s);
+        pws[(((long)a * gridDim.x + blockIdx.x) * gridDim.y + n) * C + c] = s;
     });
 }
 
-__global__ void in_stats_finalize_kernel(const double* ws, int NC, long V, float eps, float* mean, float* rstd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NC) return;
-    const double m = ws[i * 2] / (double)V;
-    double var = ws[i * 2 + 1] / (double)V - m * m;
+// Finalize kernels: 256 threads = 16 (n,c) entries x 16 slices of the block partials; returns the fp64 total of
+// entry i = blockIdx.x * 16 + (threadIdx.x & 15) for accumulator a (valid in the threads with slice 0).
+__device__ __forceinline__ double sum_partials(const float* pws, int a, int nblk, int NC, double* red) {
+    const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + ii;
+    double s = 0;
+    if (i < NC) {
+        const float* p = pws + (long)a * nblk * NC + i;
+#pragma unroll 4
+        for (int b = sl; b < nblk; b += 16) s += (double)p[(long)b * NC];
+    }
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + ii];
+    }
+    return s;
+}
+
+__global__ void in_stats_finalize_kernel(const float* pws, int nblk, int NC, long V, float eps, float* mean, float* rstd) {
+    __shared__ double red[256];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s0 = sum_partials(pws, 0, nblk, NC, red), s1 = sum_partials(pws, 1, nblk, NC, red);
+    if (i >= NC || (threadIdx.x >> 4) != 0) return;
+    const double m = s0 / (double)V;
+    double var = s1 / (double)V - m * m;
     if (var < 0) var = 0;
     mean[i] = (float)m;
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
@@ -107,23 +154,34 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
     }
     const half_t* yn = y + (long)n * V * C;
     half_t* zn = z + (long)n * V * ld_z;
-    for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
-        const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
+    auto apply = [&](const half8& x) {
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float t = (float)x[e] * sc[e] + sh[e];
             o[e] = (half_t)(t > 0.f ? t : t * slope);
         }
-        *reinterpret_cast<half8*>(zn + v * ld_z + rm.c8 * 8) = o;
+        return o;
+    };
+    const long end = vrange_end(V, rm), step = rm.VPB;
+    long v = vrange_begin(V, rm) + rm.vl;
+    const half_t* yp = yn + rm.c8 * 8;
+    half_t* zp = zn + rm.c8 * 8;
+    for (; v + (UNR - 1) * step < end; v += UNR * step) {
+        half8 x[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) *reinterpret_cast<half8*>(zp + (v + u * step) * ld_z) = apply(x[u]);
     }
+    for (; v < end; v += step) *reinterpret_cast<half8*>(zp + v * ld_z) = apply(*reinterpret_cast<const half8*>(yp + v * C));
 }
 
 // pass 1 of backward: s1 = sum g, s2 = sum g*xhat with g = dz * lrelu'(gamma*xhat+beta)
 __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* __restrict__ y, const half_t* __restrict__ dz,
                                                                  int ld_dz, long V, int C, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float slope, double* ws) {
+                                                                 const float* __restrict__ beta, float slope, float* pws) {
     __shared__ float red[NT * 17];
     const RowMap rm = row_map(C);
     const int n = blockIdx.y;
@@ -139,9 +197,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
         }
         const half_t* yn = y + (long)n * V * C;
         const half_t* dzn = dz + (long)n * V * ld_dz;
-        for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
-            const half8 x = *reinterpret_cast<const half8*>(yn + v * C + rm.c8 * 8);
-            const half8 d = *reinterpret_cast<const half8*>(dzn + v * ld_dz + rm.c8 * 8);
+        auto accum = [&](const half8& x, const half8& d) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xh = ((float)x[e] - mu[e]) * rs[e];
@@ -150,18 +206,46 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
                 part[0][e] += g;
                 part[1][e] += g * xh;
             }
+        };
+        const long end = vrange_end(V, rm), step = rm.VPB;
+        long v = vrange_begin(V, rm) + rm.vl;
+        const half_t* yp = yn + rm.c8 * 8;
+        const half_t* dp = dzn + rm.c8 * 8;
+        constexpr int U2 = UNR / 2;
+        for (; v + (U2 - 1) * step < end; v += U2 * step) {
+            half8 x[U2], d[U2];
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+                d[u] = *reinterpret_cast<const half8*>(dp + (v + u * step) * ld_dz);
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) accum(x[u], d[u]);
         }
+        for (; v < end; v += step)
+            accum(*reinterpret_cast<const half8*>(yp + v * C), *reinterpret_cast<const half8*>(dp + v * ld_dz));
     }
     block_channel_reduce<2>(rm, C, part, red, [&](int a, int c, float s) {
-        atomicAdd(ws + ((long)n * C + c) * 3 + a, (double)s);
+        pws[(((long)a * gridDim.x + blockIdx.x) * gridDim.y + n) * C + c] = s;
     });
+}
+
+// ws[(n*C + c)*3 + {0,1}] = s1, s2 (fp64 totals of the partials)
+__global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, double* ws) {
+    __shared__ double red[256];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s0 = sum_partials(pws, 0, nblk, NC, red), s1 = sum_partials(pws, 1, nblk, NC, red);
+    if (i >= NC || (threadIdx.x >> 4) != 0) return;
+    ws[(long)i * 3 + 0] = s0;
+    ws[(long)i * 3 + 1] = s1;
 }
 
 // pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V), in place over y; db partial = sum dy
 __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restrict__ y, const half_t* __restrict__ dz, int ld_dz,
                                                                 long V, int C, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float slope, double* ws) {
+                                                                const float* __restrict__ beta, float slope, const double* ws,
+                                                                float* pws) {
     __shared__ float red[NT * 9];
     const RowMap rm = row_map(C);
     const int n = blockIdx.y;
@@ -180,10 +264,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
         }
         half_t* yn = y + (long)n * V * C;
         const half_t* dzn = dz + (long)n * V * ld_dz;
-        for (long v = vrange_begin(V, rm) + rm.vl; v < vrange_end(V, rm); v += rm.VPB) {
-            half8* yp = reinterpret_cast<half8*>(yn + v * C + rm.c8 * 8);
-            const half8 x = *yp;
-            const half8 d = *reinterpret_cast<const half8*>(dzn + v * ld_dz + rm.c8 * 8);
+        auto grad = [&](const half8& x, const half8& d) {
             half8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -194,34 +275,48 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
                 o[e] = r;
                 part[0][e] += (float)r;
             }
-            *yp = o;
+            return o;
+        };
+        const long end = vrange_end(V, rm), step = rm.VPB;
+        long v = vrange_begin(V, rm) + rm.vl;
+        half_t* yp = yn + rm.c8 * 8;
+        const half_t* dp = dzn + rm.c8 * 8;
+        constexpr int U2 = UNR / 2;
+        for (; v + (U2 - 1) * step < end; v += U2 * step) {
+            half8 x[U2], d[U2];
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+                d[u] = *reinterpret_cast<const half8*>(dp + (v + u * step) * ld_dz);
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) *reinterpret_cast<half8*>(yp + (v + u * step) * C) = grad(x[u], d[u]);
         }
+        for (; v < end; v += step)
+            *reinterpret_cast<half8*>(yp + v * C) = grad(*reinterpret_cast<const half8*>(yp + v * C), *reinterpret_cast<const half8*>(dp + v * ld_dz));
     }
     block_channel_reduce<1>(rm, C, part, red, [&](int, int c, float s) {
-        atomicAdd(ws + ((long)n * C + c) * 3 + 2, (double)s);
+        pws[((long)blockIdx.x * gridDim.y + n) * C + c] = s;
     });
 }
 
-__global__ void in_lrelu_bwd_finalize_kernel(const double* ws, int N, int C, float* dgamma, float* dbeta, float* dbias,
-                                             float unscale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0, db = 0;
-    for (int n = 0; n < N; ++n) {
-        s1 += ws[((long)n * C + c) * 3 + 0];
-        s2 += ws[((long)n * C + c) * 3 + 1];
-        db += ws[((long)n * C + c) * 3 + 2];
-    }
-    // atomics: two sample lanes (HIP streams) may finalise the same layer concurrently
-    if (dgamma) atomicAdd(dgamma + c, (float)(s2 * unscale));
-    if (dbeta) atomicAdd(dbeta + c, (float)(s1 * unscale));
+__global__ void in_lrelu_bwd_finalize_kernel(const double* ws, const float* pws, int nblk, int N, int C, float* dgamma,
+                                             float* dbeta, float* dbias, float unscale) {
+    __shared__ double red[256];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);          // (n, c) entry
+    const double db = sum_partials(pws, 0, nblk, N * C, red);
+    if (i >= N * C || (threadIdx.x >> 4) != 0) return;
+    const int c = i % C;
+    // atomics: N samples (and, with sample lanes, two HIP streams) add into the same channel
+    if (dgamma) atomicAdd(dgamma + c, (float)(ws[(long)i * 3 + 1] * unscale));
+    if (dbeta) atomicAdd(dbeta + c, (float)(ws[(long)i * 3 + 0] * unscale));
     if (dbias) atomicAdd(dbias + c, (float)(db * unscale));
 }
 
 int blocks_for(long V, int C) {
     const int vpb = NT / (C / 8);
     long b = (V + (long)vpb * 8 - 1) / ((long)vpb * 8);  // ~8 passes per block
-    if (b > 1024) b = 1024;
+    if (b > MAX_BLOCKS) b = MAX_BLOCKS;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -235,17 +330,19 @@ int check_common(const void* y, int N, long V, int C, const char* what) {
 
 }  // namespace
 
-extern "C" size_t lnn_instnorm_ws_doubles(int N, int C) { return (size_t)N * C * 3; }
+// [N*C*3 doubles: s1, s2, (unused)] [2 * MAX_BLOCKS * N * C floats: per-block partial sums]
+extern "C" size_t lnn_instnorm_ws_doubles(int N, int C) { return (size_t)N * C * 3 + (size_t)MAX_BLOCKS * N * C; }
 
 extern "C" int lnn_instnorm_stats(lnn_stream_t s_, const void* y, int N, long V, int C, float eps, float* mean, float* rstd,
                                   double* ws) {
     hipStream_t s = (hipStream_t)s_;
     if (int e = check_common(y, N, V, C, "lnn_instnorm_stats")) return e;
     LNN_REQUIRE(mean && rstd && ws, "lnn_instnorm_stats: null output/workspace");
-    hipMemsetAsync(ws, 0, sizeof(double) * 2 * N * C, s);
-    hipLaunchKernelGGL(in_stats_kernel, dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, V, C, ws);
+    float* pws = reinterpret_cast<float*>(ws + (size_t)N * C * 3);
+    const int nblk = blocks_for(V, C);
+    hipLaunchKernelGGL(in_stats_kernel, dim3(nblk, N), dim3(NT), 0, s, (const half_t*)y, V, C, pws);
     LNN_CHECK_LAUNCH("lnn_instnorm_stats");
-    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, 256)), dim3(256), 0, s, ws, N * C, V, eps, mean, rstd);
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, V, eps, mean, rstd);
     LNN_CHECK_LAUNCH("lnn_instnorm_stats(finalize)");
     return LNN_OK;
 }
@@ -271,16 +368,19 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
     if (int e = check_common(y, N, V, C, "lnn_instnorm_lrelu_bwd")) return e;
     LNN_REQUIRE(dz != nullptr && lnn_aligned16(dz) && ld_dz >= C && ld_dz % 8 == 0, "lnn_instnorm_lrelu_bwd: bad dz / ld_dz");
     LNN_REQUIRE(mean && rstd && gamma && beta && ws, "lnn_instnorm_lrelu_bwd: null parameter");
-    hipMemsetAsync(ws, 0, sizeof(double) * 3 * N * C, s);
-    const dim3 grid(blocks_for(V, C), N);
+    float* pws = reinterpret_cast<float*>(ws + (size_t)N * C * 3);
+    const int nblk = blocks_for(V, C);
+    const dim3 grid(nblk, N);
     hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, grid, dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
-                       mean, rstd, gamma, beta, slope, ws);
+                       mean, rstd, gamma, beta, slope, pws);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(reduce)");
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, ws);
+    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(sums)");
     hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
-                       rstd, gamma, beta, slope, ws);
+                       rstd, gamma, beta, slope, ws, pws);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
-    hipLaunchKernelGGL(in_lrelu_bwd_finalize_kernel, dim3(lnn_cdiv(C, 256)), dim3(256), 0, s, ws, N, C, dgamma, dbeta, dbias,
-                       grad_unscale);
+    hipLaunchKernelGGL(in_lrelu_bwd_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, ws, pws, nblk, N, C, dgamma,
+                       dbeta, dbias, grad_unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(finalize)");
     return LNN_OK;
 }
