@@ -56,6 +56,12 @@ int lnn_device_info(int* cu_count, int* clock_khz, char* name, int name_len);
 int lnn_pack_weights(lnn_stream_t s, const float* src, void* dst_h, int ntaps, int M, int KC,
                      long stride_m, long stride_kc, long stride_t);
 size_t lnn_packed_weight_elems(int ntaps, int M, int KC);
+/* All layers in ONE launch.  desc_dev: n x 9 int64 on the device, per layer
+ *   {src_off, dst_off, stride_m, stride_kc, stride_t, ntaps, M, KC, first}
+ * (element offsets relative to src_base / dst_base; first = running sum of the layers' padded panel sizes
+ * lnn_packed_weight_elems; total = their sum).  n <= 128. */
+int lnn_pack_weights_batched(lnn_stream_t s, const float* src_base, void* dst_base_h, const long* desc_dev, int n,
+                             long total);
 
 /* ------------------------------------------------------------------------------------------------
  * nn.Conv3d 3x3x3, padding 1, stride 1|2, bias  (module tree test_MultiHead_Module.py:346-415;
@@ -92,6 +98,10 @@ int lnn_convT3d_k2s2_wgrad(lnn_stream_t s, const void* x_h, int ld_x, const void
 int lnn_unpack_wgrad(lnn_stream_t s, const float* dwp, float* dst, int ntaps, int M, int KC,
                      long stride_m, long stride_kc, long stride_t, float scale, int accumulate);
 size_t lnn_wgrad_panel_elems(int ntaps, int M, int KC);
+/* Same for all layers in one launch; desc as in lnn_pack_weights_batched with src_off = panel offset, dst_off =
+ * gradient offset, first = running sum of ntaps*M*KC (unpadded), total = their sum. */
+int lnn_unpack_wgrad_batched(lnn_stream_t s, const float* panel_base, float* dst_base, const long* desc_dev, int n,
+                             long total, float scale, int accumulate);
 
 /* ------------------------------------------------------------------------------------------------
  * nn.InstanceNorm3d(eps, affine=True) + nn.LeakyReLU(slope)  (nnViTUNetTrainer.py:111-114; order

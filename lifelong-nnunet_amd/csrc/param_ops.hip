@@ -52,6 +52,59 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, half_t* __res
     }
 }
 
+// ---- batched variants: ONE launch for every layer of the network (a step needs 53 packs + 27 unpacks, each a
+// 5-20 us launch on its own).  desc[j] = {src_off, dst_off, stride_m, stride_kc, stride_t, ntaps, M, KC, first} in
+// int64 (element offsets relative to the base pointers; `first` = index of the layer's first work item).
+constexpr int DESC_W = 9, DESC_MAX = 128;
+
+__device__ __forceinline__ int find_desc(const long* firsts, int n, long i) {
+    int lo = 0, hi = n - 1;                       // last j with firsts[j] <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (firsts[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(NT) void pack_weights_batched_kernel(const float* __restrict__ src, half_t* __restrict__ dst,
+                                                                  const long* __restrict__ desc, int n, long total) {
+    __shared__ long firsts[DESC_MAX];
+    for (int j = threadIdx.x; j < n; j += NT) firsts[j] = desc[j * DESC_W + 8];
+    __syncthreads();
+    for (long g = (long)blockIdx.x * NT + threadIdx.x; g < total; g += (long)gridDim.x * NT) {
+        const long* d = desc + find_desc(firsts, n, g) * DESC_W;
+        const long i = g - d[8];
+        const int ntaps = (int)d[5], M = (int)d[6], KC = (int)d[7];
+        const int nck = (KC + 15) >> 4;
+        const int c16 = (int)(i & 15), row = (int)((i >> 4) & 31);
+        long r = i >> 9;
+        const int t = (int)(r % ntaps); r /= ntaps;
+        const int ck = (int)(r % nck), mb = (int)(r / nck);
+        const int m = mb * 32 + row, kc = ck * 16 + c16;
+        float v = 0.f;
+        if (m < M && kc < KC) v = src[d[0] + m * d[2] + kc * d[3] + t * d[4]];
+        dst[d[1] + i] = (half_t)v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void unpack_wgrad_batched_kernel(const float* __restrict__ dwp, float* __restrict__ dst,
+                                                                  const long* __restrict__ desc, int n, long total, float scale,
+                                                                  int accumulate) {
+    __shared__ long firsts[DESC_MAX];
+    for (int j = threadIdx.x; j < n; j += NT) firsts[j] = desc[j * DESC_W + 8];
+    __syncthreads();
+    for (long g = (long)blockIdx.x * NT + threadIdx.x; g < total; g += (long)gridDim.x * NT) {
+        const long* d = desc + find_desc(firsts, n, g) * DESC_W;
+        const long i = g - d[8];
+        const int ntaps = (int)d[5], M = (int)d[6], KC = (int)d[7];
+        const int Mpad = (M + 31) & ~31, KCpad = (KC + 31) & ~31;
+        const int t = (int)(i % ntaps), kc = (int)((i / ntaps) % KC), m = (int)(i / ((long)ntaps * KC));
+        const float v = scale * dwp[d[0] + ((long)t * Mpad + m) * KCpad + kc];
+        float* o = dst + d[1] + m * d[2] + kc * d[3] + t * d[4];
+        *o = accumulate ? *o + v : v;
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dst, int ntaps, int M, int KC, int Mpad,
                                     int KCpad, long sm, long skc, long st, float scale, int accumulate) {
     const long total = (long)ntaps * M * KC;
@@ -177,6 +230,28 @@ extern "C" int lnn_unpack_wgrad(lnn_stream_t s_, const float* dwp, float* dst, i
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(flat_blocks((long)ntaps * M * KC, 4)), dim3(NT), 0, s, dwp, dst, ntaps, M,
                        KC, Mpad, KCpad, sm, skc, st, scale, accumulate);
     LNN_CHECK_LAUNCH("lnn_unpack_wgrad");
+    return LNN_OK;
+}
+
+extern "C" int lnn_pack_weights_batched(lnn_stream_t s_, const float* src_base, void* dst_base, const long* desc_dev, int n,
+                                        long total) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(src_base && dst_base && desc_dev && lnn_aligned16(dst_base), "lnn_pack_weights_batched: null/misaligned pointer");
+    LNN_REQUIRE(n > 0 && n <= DESC_MAX && total > 0, "lnn_pack_weights_batched: 1..%d descriptors, total > 0", DESC_MAX);
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(flat_blocks(total, 4)), dim3(NT), 0, s, src_base, (half_t*)dst_base,
+                       desc_dev, n, total);
+    LNN_CHECK_LAUNCH("lnn_pack_weights_batched");
+    return LNN_OK;
+}
+
+extern "C" int lnn_unpack_wgrad_batched(lnn_stream_t s_, const float* panel_base, float* dst_base, const long* desc_dev, int n,
+                                        long total, float scale, int accumulate) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(panel_base && dst_base && desc_dev, "lnn_unpack_wgrad_batched: null pointer");
+    LNN_REQUIRE(n > 0 && n <= DESC_MAX && total > 0, "lnn_unpack_wgrad_batched: 1..%d descriptors, total > 0", DESC_MAX);
+    hipLaunchKernelGGL(unpack_wgrad_batched_kernel, dim3(flat_blocks(total, 4)), dim3(NT), 0, s, panel_base, dst_base, desc_dev,
+                       n, total, scale, accumulate);
+    LNN_CHECK_LAUNCH("lnn_unpack_wgrad_batched");
     return LNN_OK;
 }
 

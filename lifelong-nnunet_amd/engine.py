@@ -278,6 +278,39 @@ class UNetEngine:
             pn_off = (pn_off + 3) // 4 * 4
         self.wpanels = torch.zeros(wp_off, dtype=torch.float16, device=dev)
         self.gpanels = torch.zeros(pn_off, device=dev)
+        # descriptor tables of the batched pack / unpack launches (lnn_hip.h): one row per panel
+        #   {src_off, dst_off, stride_m, stride_kc, stride_t, ntaps, M, KC, first}
+        pk, up = [], []
+        pk_total = up_total = 0
+
+        def add_pack(w, dst, ntaps, M, KC, sm, skc, st):
+            nonlocal pk_total
+            pk.append([w.offset, dst, sm, skc, st, ntaps, M, KC, pk_total])
+            pk_total += nat.query("lnn_packed_weight_elems", ntaps, M, KC)
+
+        def add_unpack(w, panel, ntaps, M, KC, sm, skc, st):
+            nonlocal up_total
+            up.append([panel, w.offset, sm, skc, st, ntaps, M, KC, up_total])
+            up_total += ntaps * M * KC
+
+        for item in order:
+            if isinstance(item, ConvBlock):
+                K, C = item.cout, item.cin
+                if C == 1:
+                    add_pack(item.w, item.wp_fwd, 1, K, 27, 27, 1, 0)
+                    add_unpack(item.w, item.panel, 1, K, 27, 27, 1, 0)
+                else:
+                    add_pack(item.w, item.wp_fwd, 27, K, C, C * 27, 27, 1)
+                    add_pack(item.w, item.wp_dgrad, 27, C, K, 27, C * 27, 1)
+                    add_unpack(item.w, item.panel, 27, K, C, C * 27, 27, 1)
+            elif isinstance(item, UpBlock):
+                C, K = item.cin, item.cout
+                add_pack(item.w, item.wp_fwd, 8, K, C, 8, K * 8, 1)
+                add_pack(item.w, item.wp_dgrad, 8, C, K, K * 8, 8, 1)
+                add_unpack(item.w, item.panel, 8, C, K, K * 8, 8, 1)
+        self._pack_desc = torch.tensor(pk, dtype=torch.int64, device=dev)
+        self._unpack_desc = torch.tensor(up, dtype=torch.int64, device=dev)
+        self._pack_total, self._unpack_total = pk_total, up_total
         cmax = max(2 * f for f in feats)
         self.ws = torch.zeros(max(nat.query("lnn_instnorm_ws_doubles", N, cmax), 64), dtype=torch.float64, device=dev)
         self.packed_version = -1
@@ -308,21 +341,15 @@ class UNetEngine:
 
     # ------------------------------------------------------------------------------------------ pack
     def pack_weights(self):
-        for item in self.order:
-            if isinstance(item, ConvBlock):
-                w = self.pview(item.w)
-                K, C = item.cout, item.cin
-                if C == 1:
-                    nat.call("lnn_pack_weights", w, self._wp(item.wp_fwd), 1, K, 27, 27, 1, 0)
-                else:
-                    nat.call("lnn_pack_weights", w, self._wp(item.wp_fwd), 27, K, C, C * 27, 27, 1)
-                    nat.call("lnn_pack_weights", w, self._wp(item.wp_dgrad), 27, C, K, 27, C * 27, 1)
-            elif isinstance(item, UpBlock):
-                w = self.pview(item.w)
-                C, K = item.cin, item.cout
-                nat.call("lnn_pack_weights", w, self._wp(item.wp_fwd), 8, K, C, 8, K * 8, 1)
-                nat.call("lnn_pack_weights", w, self._wp(item.wp_dgrad), 8, C, K, K * 8, 8, 1)
+        """fp32 parameter arena -> fp16 MFMA panels of every layer, one launch."""
+        nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc, self._pack_desc.shape[0],
+                 self._pack_total)
         self.packed_version = self.arena.version
+
+    def unpack_wgrads(self):
+        """fp32 wgrad panels of every layer += into the gradient arena (PyTorch layouts), one launch."""
+        nat.call("lnn_unpack_wgrad_batched", self.gpanels, self.grad, self._unpack_desc, self._unpack_desc.shape[0],
+                 self._unpack_total, 1.0, 1)
 
     # ------------------------------------------------------------------------------------------ sample lanes
     # Patches are independent through the whole network (InstanceNorm is per sample), so a batch is processed as up to
@@ -437,6 +464,10 @@ class UNetEngine:
             with torch.cuda.stream(side):
                 fn()
 
+        # the DP all-reduce overlaps with backward and needs every layer's gradient final as soon as its wgrad is:
+        # per-layer unpack there; otherwise one batched unpack after the last wgrad
+        per_layer_unpack = progress is not None and not multi
+
         def unpack(item):
             if isinstance(item, ConvBlock):
                 K, C = item.cout, item.cin
@@ -479,7 +510,7 @@ class UNetEngine:
                     def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
                         nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
                                  item.stride)
-                        if not multi:
+                        if per_layer_unpack:
                             unpack(item)
                     on_side(conv_wgrad)
                     if C != 1 and item.gx is not None:
@@ -492,7 +523,7 @@ class UNetEngine:
                     def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
                         nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
                                  self._pn(item.panel), nn, D, H, W, C, K)
-                        if not multi:
+                        if per_layer_unpack:
                             unpack(item)
                     on_side(up_wgrad)
                     nat.call("lnn_convT3d_k2s2_dgrad", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
@@ -501,10 +532,8 @@ class UNetEngine:
         self._fork(lane)
         if side is not None:
             main.wait_stream(side)      # every weight gradient is final before anything downstream (norm, step)
-        if multi and not skip_body:
-            for item in self.order:
-                if not isinstance(item, SegHead):
-                    unpack(item)
+        if not per_layer_unpack and not skip_body:
+            self.unpack_wgrads()
         if progress is not None and multi:
             progress(0)
 

@@ -33,6 +33,8 @@ SIGNATURES = {
     "lnn_convT3d_k2s2_dgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
     "lnn_convT3d_k2s2_wgrad": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
     "lnn_unpack_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _f, _i]),
+    "lnn_pack_weights_batched": (_i, [_p, _p, _p, _p, _i, _l]),
+    "lnn_unpack_wgrad_batched": (_i, [_p, _p, _p, _p, _i, _l, _f, _i]),
     "lnn_wgrad_panel_elems": (_sz, [_i, _i, _i]),
     "lnn_instnorm_stats": (_i, [_p, _p, _i, _l, _i, _f, _p, _p, _p]),
     "lnn_instnorm_lrelu_fwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f]),

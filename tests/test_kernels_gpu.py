@@ -300,3 +300,38 @@ def test_param_kernels():
     nat.call("lnn_gradnorm_sumsq", bad, n, 1.0, ws, 1)
     nat.call("lnn_sgd_nesterov_step_clipped", thg, buf, bad, n, 1e-2, 0.99, 3e-5, 1.0, 12.0, ws)
     assert torch.equal(before, thg)          # non-finite gradient -> step skipped
+
+
+def test_batched_pack_unpack_match_per_layer():
+    """lnn_pack_weights_batched / lnn_unpack_wgrad_batched == the per-layer entry points, bit for bit."""
+    layers = [(27, 32, 16, 16 * 27, 27, 1), (27, 16, 32, 27, 16 * 27, 1), (8, 24, 40, 8, 24 * 8, 1), (1, 32, 27, 27, 1, 0)]
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(40000, generator=g).to(DEV)
+    desc, soff, doff, first = [], 0, 0, 0
+    per_layer = []
+    for (nt, M, KC, sm, skc, st) in layers:
+        n = nat.query("lnn_packed_weight_elems", nt, M, KC)
+        ref = torch.zeros(n, dtype=torch.float16, device=DEV)
+        nat.call("lnn_pack_weights", src[soff:], ref, nt, M, KC, sm, skc, st)
+        per_layer.append(ref)
+        desc.append([soff, doff, sm, skc, st, nt, M, KC, first])
+        soff += nt * M * KC; doff += n; first += n
+    out = torch.zeros(doff, dtype=torch.float16, device=DEV)
+    d = torch.tensor(desc, dtype=torch.int64, device=DEV)
+    nat.call("lnn_pack_weights_batched", src, out, d, len(layers), first)
+    assert torch.equal(out, torch.cat(per_layer))
+    # unpack
+    desc, poff, goff, first = [], 0, 0, 0
+    panels, refs = [], []
+    for (nt, M, KC, sm, skc, st) in layers:
+        n = nat.query("lnn_wgrad_panel_elems", nt, M, KC)
+        pan = torch.randn(n, generator=g).to(DEV)
+        ref = torch.full((nt * M * KC,), 0.5, device=DEV)
+        nat.call("lnn_unpack_wgrad", pan, ref, nt, M, KC, sm, skc, st, 2.0, 1)
+        panels.append(pan); refs.append(ref)
+        desc.append([poff, goff, sm, skc, st, nt, M, KC, first])
+        poff += n; goff += nt * M * KC; first += nt * M * KC
+    grad = torch.full((goff,), 0.5, device=DEV)
+    nat.call("lnn_unpack_wgrad_batched", torch.cat(panels), grad, torch.tensor(desc, dtype=torch.int64, device=DEV),
+             len(layers), first, 2.0, 1)
+    assert torch.equal(grad, torch.cat(refs))
