@@ -37,6 +37,8 @@ __host__ __device__ __forceinline__ long lnn_panel_off(int slot, int m, int kc, 
 
 // v2 stride-1 3x3x3 kernel (igemm_conv_v2.hip): persistent blocks, software-pipelined staging.
 int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);
+// v7 (igemm_conv_v7.hip): single-buffered, two 8-wave blocks per CU (hardware interleaves staging and MFMA phases)
+int lnn_launch_conv_s1_v7(hipStream_t s, ConvParams& p, const char* name);
 // v6 (igemm_conv_v6.hip): two wave groups per block running half a step out of phase (compute / memory ping-pong).
 int lnn_launch_conv_s1_v6(hipStream_t s, ConvParams& p, const char* name);
 // single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,

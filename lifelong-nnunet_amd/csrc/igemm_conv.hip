@@ -358,6 +358,18 @@ bool use_down2() {
     return v == 1;
 }
 
+// v7 (two single-buffered 8-wave blocks per CU) vs v5 (one double-buffered block with resident weights): measured
+// +4..18 % for layers with >= 128 input channels (weights streamed anyway, many short steps), -3..15 % below.
+// LNN_CONV_V7=1 / 0 forces / forbids v7 (A/B measurements).
+bool use_v7(int C) {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("LNN_CONV_V7");
+        v = e ? (e[0] == '1' ? 1 : 0) : -1;
+    }
+    return v < 0 ? C >= 128 : v == 1;
+}
+
 int check_act(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -402,6 +414,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
             p.taps.slot[t] = (unsigned char)t;
         }
         p.dbg = g_dbg;
+        if (use_v2() && use_v7(p.C)) return lnn_launch_conv_s1_v7(s, p, "lnn_conv3d_fwd(s1,v7)");
         if (use_v2()) return use_v6() ? lnn_launch_conv_s1_v6(s, p, "lnn_conv3d_fwd(s1,v6)") : lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
@@ -443,6 +456,7 @@ extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, cons
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
         p.dbg = g_dbg;
+        if (use_v2() && use_v7(p.C)) return lnn_launch_conv_s1_v7(s, p, "lnn_conv3d_dgrad(s1,v7)");
         if (use_v2()) return use_v6() ? lnn_launch_conv_s1_v6(s, p, "lnn_conv3d_dgrad(s1,v6)") : lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
     }
