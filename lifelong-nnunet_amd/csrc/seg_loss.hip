@@ -134,7 +134,9 @@ __device__ __forceinline__ void softmax_k(const float* __restrict__ ln, long V, 
     lse = mx + logf(s);
 }
 
-// ws: [N][K][3] (tp, fp, fn) then [1] ce sum
+// ws: [N][K][3] (tp, fp, fn) then [1] ce sum then [1] spare -- totals, written by the finalize kernel -- followed by the
+// per-block partials [N][gridDim.x][3*KMAX+1] as fp32 (no atomics: 2048 blocks adding doubles to ONE CE address were
+// most of this kernel's time, and the workspace needed a memset per call)
 __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                          int K, long V, double* ws, int N) {
     __shared__ float sm[(3 * KMAX + 1) * (NT / 64)];
@@ -160,14 +162,38 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
     }
     block_sum<3 * KMAX + 1>(acc, sm);
     if (threadIdx.x == 0) {
-        for (int k = 0; k < K; ++k)
-            for (int j = 0; j < 3; ++j) atomicAdd(ws + ((long)n * K + k) * 3 + j, (double)acc[k * 3 + j]);
-        atomicAdd(ws + (long)N * K * 3, (double)acc[3 * KMAX]);
+        float* pws = reinterpret_cast<float*>(ws + (long)N * K * 3 + 2) + ((long)n * gridDim.x + blockIdx.x) * (3 * KMAX + 1);
+#pragma unroll
+        for (int i = 0; i < 3 * KMAX + 1; ++i) pws[i] = acc[i];
     }
 }
 
-__global__ void dice_ce_finalize_kernel(const double* ws, int N, int K, long V, int batch_dice, float smooth, float* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one 256-thread block: totals of the per-block partials (fp64), then the loss
+__global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nblk, int N, int K, long V, int batch_dice,
+                                                              float smooth, float* out) {
+    __shared__ double red[NT];
+    constexpr int W = 3 * KMAX + 1;
+    const float* pws = reinterpret_cast<const float*>(ws + (long)N * K * 3 + 2);
+    double ce_sum = 0;
+    for (int n = 0; n < N; ++n)
+        for (int i = 0; i < W; ++i) {
+            if (i < 3 * KMAX && i >= 3 * K) continue;
+            double s = 0;
+            for (int b = threadIdx.x; b < nblk; b += NT) s += (double)pws[((long)n * nblk + b) * W + i];
+            __syncthreads();
+            red[threadIdx.x] = s;
+            __syncthreads();
+            for (int o = NT / 2; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                if (i < 3 * KMAX) ws[((long)n * K + i / 3) * 3 + i % 3] = red[0];
+                else ce_sum += red[0];
+            }
+        }
+    if (threadIdx.x != 0) return;
+    ws[(long)N * K * 3] = ce_sum;
     double dc_sum = 0;
     int cnt = 0;
     if (batch_dice) {
@@ -338,17 +364,18 @@ extern "C" int lnn_seg1x1_bwd(lnn_stream_t s_, const void* z, int ld_z, const fl
     return LNN_OK;
 }
 
-extern "C" size_t lnn_dice_ce_ws_doubles(int N, int K) { return (size_t)N * K * 3 + 2; }
+// totals [N*K*3 + 2] + fp32 per-block partials [N][<=1024 blocks][3*KMAX+1]
+extern "C" size_t lnn_dice_ce_ws_doubles(int N, int K) { return (size_t)N * K * 3 + 2 + ((size_t)N * 1024 * (3 * KMAX + 1) + 1) / 2; }
 
 extern "C" int lnn_dice_ce_fwd(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
                                int batch_dice, float smooth, float* out_loss, double* ws) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(logits && labels && out_loss && ws, "lnn_dice_ce_fwd: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
-    hipMemsetAsync(ws, 0, sizeof(double) * lnn_dice_ce_ws_doubles(N, K), s);
-    hipLaunchKernelGGL(dice_ce_fwd_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, K, V, ws, N);
+    const int nblk = vox_blocks(V);
+    hipLaunchKernelGGL(dice_ce_fwd_kernel, dim3(nblk, N), dim3(NT), 0, s, logits, labels, K, V, ws, N);
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd");
-    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(64), 0, s, ws, N, K, V, batch_dice, smooth, out_loss);
+    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(NT), 0, s, ws, nblk, N, K, V, batch_dice, smooth, out_loss);
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd(finalize)");
     return LNN_OK;
 }
