@@ -335,6 +335,180 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stride-2 gathers (wgrad of the stride-2 3x3x3 conv, EXT = 3, pad 1; wgrad of the 2x2x2 stride-2 transposed conv,
+// EXT = 2, pad 0):  DWP[tap][m][c] += sum_l P[l, m] * Q[2l + d - pad, c].
+// The generic kernel staged a 5x9x17-position Q tile per 64 loop voxels and per 32 P channels and read it with a
+// 128-byte lane stride (2-way bank conflicts); these layers are bound by the Q read (4x the P operand), so:
+//   * the Q tile is stored in LDS as EIGHT PARITY SUB-TILES (z, y, x parity of the position): tap d reads sub-tile
+//     (d & 1 per dimension) at loop coordinate l + (d >> 1) with UNIT stride, i.e. exactly the conflict-free
+//     linear-64-byte-row pattern of the stride-1 kernel above;
+//   * one block owns TWO 32-row P panels (64 P channels) x one 32-column Q panel: the Q tile is read from HBM once
+//     per 64 output rows;
+//   * 512 threads (8 waves, taps wave, wave+8, ...: <= 4 taps x 2 panels = 8 accumulators), one block per CU,
+//     register prefetch of the next tile as in the stride-1 kernel.
+// ------------------------------------------------------------------------------------------------
+template <int EXT>
+__global__ __launch_bounds__(512, 2) void igemm_wgrad_s2_v2_kernel(const WgradParams p) {
+    constexpr int TY = 8, TX = 8, TV = 64;                         // 1 x 8 x 8 loop voxels
+    constexpr int PZ = EXT, PY = 2 * (TY - 1) + EXT, PX = 2 * (TX - 1) + EXT, P = PZ * PY * PX;
+    constexpr int QZ = 1 + (EXT == 3), QY = TY + (EXT == 3), QX = TX + (EXT == 3);
+    constexpr int ST = QZ * QY * QX * 64;                          // bytes per parity sub-tile
+    constexpr int QB = 8 * ST;
+    constexpr int NTAP = EXT * EXT * EXT, TPW = (NTAP + 7) / 8, MP = 2, NT = 512;
+    constexpr int QN = (P * 4 + NT - 1) / NT, PN = (TV * MP * 4 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ql = smem;        // [8 parity sub-tiles][QZ][QY][QX][64 B]
+    char* const pl = smem + QB;   // [MP][TV][64 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cpanels = p.Cpad / 32;
+    const int m0 = (blockIdx.y / cpanels) * 32 * MP, c0 = (blockIdx.y % cpanels) * 32;
+    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
+    const int chb = (cb + 4 * sq) * 2;
+    const int p_addr = (8 * hk + sj) * 64 + chb;
+    const int q_lane = (hk * QX + sj) * 64 + chb;
+
+    floatx16 acc[TPW][MP];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int a = 0; a < MP; ++a)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][a][j] = 0.f;
+
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
+    if (t_begin >= t_end) return;
+
+    int qrel[QN], qlds[QN], prel[PN];
+#pragma unroll
+    for (int i = 0; i < QN; ++i) {
+        const int idx = min(i * NT + tid, P * 4 - 1);
+        const int pos = idx >> 2, c8 = idx & 3;
+        const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+        qrel[i] = ((pz * p.Qh + py) * p.Qw + px) * p.ld_q + c8 * 8;
+        const int par = ((pz & 1) * 2 + (py & 1)) * 2 + (px & 1);
+        qlds[i] = par * ST + (((pz >> 1) * QY + (py >> 1)) * QX + (px >> 1)) * 64 + c8 * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < PN; ++i) {
+        const int idx = i * NT + tid;                 // (mp, voxel, c8)
+        const int c8 = idx & 3, vox = (idx >> 2) % TV, mp = idx / (TV * 4);
+        prel[i] = ((vox / TX) * p.Lw + vox % TX) * p.ld_p + mp * 32 + c8 * 8;
+    }
+
+    half8 qr[QN], pr[PN];
+    unsigned qok = 0, pok = 0;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int lz0 = t % p.Ld; t /= p.Ld;          // TZ = 1: one loop z-plane per tile
+        const int n = t;
+        const int ly0 = ty * TY, lx0 = tx * TX;
+        const int iz0 = 2 * lz0 - p.pad_lo, iy0 = 2 * ly0 - p.pad_lo, ix0 = 2 * lx0 - p.pad_lo;
+        const long qbase = ((((long)n * p.Qd + iz0) * p.Qh + iy0) * p.Qw + ix0) * p.ld_q + c0;
+        const long pbase = ((((long)n * p.Ld + lz0) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
+        const bool interior = iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + PZ <= p.Qd && iy0 + PY <= p.Qh && ix0 + PX <= p.Qw &&
+                              ly0 + TY <= p.Lh && lx0 + TX <= p.Lw && c0 + 32 <= p.C && m0 + 32 * MP <= p.M;
+        if (interior) {
+            const half_t* qp = p.q + qbase;
+            const half_t* pp = p.p + pbase;
+#pragma unroll
+            for (int i = 0; i < QN; ++i) qr[i] = *reinterpret_cast<const half8*>(qp + qrel[i]);
+#pragma unroll
+            for (int i = 0; i < PN; ++i) pr[i] = *reinterpret_cast<const half8*>(pp + prel[i]);
+            qok = 0xFFFFFFFFu; pok = 0xFFFFFFFFu;
+        } else {
+            qok = 0; pok = 0;
+#pragma unroll
+            for (int i = 0; i < QN; ++i) {
+                const int idx = min(i * NT + tid, P * 4 - 1);
+                const int pos = idx >> 2, c8 = idx & 3;
+                const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+                const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                const bool ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
+                                c0 + c8 * 8 < p.C;
+                qr[i] = *reinterpret_cast<const half8*>(p.q + (ok ? qbase + qrel[i] : 0));
+                qok |= (ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < PN; ++i) {
+                const int idx = i * NT + tid;
+                const int c8 = idx & 3, vox = (idx >> 2) % TV, mp = idx / (TV * 4);
+                const bool ok = ly0 + vox / TX < p.Lh && lx0 + vox % TX < p.Lw && m0 + mp * 32 + c8 * 8 < p.M;
+                pr[i] = *reinterpret_cast<const half8*>(p.p + (ok ? pbase + prel[i] : 0));
+                pok |= (ok ? 1u : 0u) << i;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < QN; ++i)
+            if (i * NT + tid < P * 4) *reinterpret_cast<half8*>(ql + qlds[i]) = ((qok >> i) & 1u) ? qr[i] : zero8;
+#pragma unroll
+        for (int i = 0; i < PN; ++i) *reinterpret_cast<half8*>(pl + (i * NT + tid) * 16) = ((pok >> i) & 1u) ? pr[i] : zero8;
+    };
+
+    int tapaddr[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = min(__builtin_amdgcn_readfirstlane(wave) + 8 * ti, NTAP - 1);
+        const int dz = EXT == 3 ? tap / 9 : tap >> 2, dy = EXT == 3 ? (tap / 3) % 3 : (tap >> 1) & 1, dx = EXT == 3 ? tap % 3 : tap & 1;
+        const int par = ((dz & 1) * 2 + (dy & 1)) * 2 + (dx & 1);
+        tapaddr[ti] = q_lane + par * ST + (((dz >> 1) * QY + (dy >> 1)) * QX + (dx >> 1)) * 64;
+    }
+    load_tile(t_begin);
+    store_tile();
+    __syncthreads();
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool more = tile + 1 < t_end;
+        if (more) load_tile(tile + 1);
+#pragma unroll
+        for (int ch = 0; ch < TV / 16; ++ch) {
+            const int pimm = ch * 1024, qimm = 2 * ch * QX * 64;     // chunk rows 2ch, 2ch+1 (+hk in the lane address)
+            half8 a[MP];
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp) {
+                const half4 a0 = lds_tr16(pl + mp * TV * 64 + pimm + p_addr), a1 = lds_tr16(pl + mp * TV * 64 + pimm + 256 + p_addr);
+                a[mp] = half8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            }
+#pragma unroll
+            for (int ti = 0; ti < TPW; ++ti) {
+                if (wave + 8 * ti < NTAP) {
+                    const half4 b0 = lds_tr16(ql + qimm + tapaddr[ti]), b1 = lds_tr16(ql + qimm + 256 + tapaddr[ti]);
+                    const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                    for (int mp = 0; mp < MP; ++mp) acc[ti][mp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mp], b, acc[ti][mp], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+    const int c = c0 + (lane & 31);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = wave + 8 * ti;
+        if (tap < NTAP) {
+            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp) {
+                if (m0 + mp * 32 >= p.Mpad) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + mp * 32 + 8 * (r >> 2) + 4 * hk + (r & 3);
+                    atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][mp][r]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // First layer (C == 1): DWP[0][m][tap] += sum_l dy[l, m] * x[l + tap - 1]     (tap padded to 32)
 // A = dy^T by transpose reads, B[voxel][tap] gathered from a single-channel LDS tile.
 // ------------------------------------------------------------------------------------------------
@@ -453,6 +627,41 @@ int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
     return LNN_OK;
 }
 
+template <int EXT>
+int launch_wgrad_s2_v2(hipStream_t s, WgradParams& p, const char* name) {
+    constexpr int TY = 8, TX = 8;
+    constexpr int QZ = 1 + (EXT == 3), QY = TY + (EXT == 3), QX = TX + (EXT == 3);
+    p.tiles_z = p.Ld; p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
+    p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
+    const int panels = lnn_cdiv(p.Mpad, 64) * (p.Cpad / 32);
+    // one 8-wave block per CU: ~2 rounds of blocks over the chip, >= 1 tile per block
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, 512);
+    if (tpb < 1) tpb = 1;
+    if (tpb > p.tiles_total) tpb = p.tiles_total;
+    p.tiles_per_block = tpb;
+    const size_t lds = (size_t)8 * QZ * QY * QX * 64 + (size_t)2 * 64 * 64;
+    auto kern = igemm_wgrad_s2_v2_kernel<EXT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
+
+// LNN_WGRAD_S2_V1=1 selects the generic kernel for the stride-2 / transposed-conv weight gradients (A/B measurements)
+bool use_wgrad_s2_v2() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LNN_WGRAD_S2_V1");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int check_act_w(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -522,6 +731,7 @@ extern "C" int lnn_conv3d_wgrad(lnn_stream_t s_, const void* x, int ld_x, const 
         if (use_v1) return launch_wgrad<1, 3, 4, 8, 7>(s, p, "lnn_conv3d_wgrad(s1)");
         return launch_wgrad_s1_v2(s, p);
     }
+    if (use_wgrad_s2_v2()) return launch_wgrad_s2_v2<3>(s, p, "lnn_conv3d_wgrad(s2,v2)");
     constexpr int PY = 2 * 3 + 3, PX = 2 * 7 + 3;  // IS=2, TZ=2, TY=4, TX=8
     for (int t = 0; t < 27; ++t) {
         p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
@@ -541,6 +751,7 @@ extern "C" int lnn_convT3d_k2s2_wgrad(lnn_stream_t s_, const void* x, int ld_x, 
     p.p = (const half_t*)x; p.q = (const half_t*)dy; p.dwp = dwp; p.ld_p = ld_x; p.ld_q = ld_dy;
     p.N = N; p.Ld = D; p.Lh = H; p.Lw = W; p.Qd = 2 * D; p.Qh = 2 * H; p.Qw = 2 * W;
     p.M = C; p.C = K; p.Mpad = lnn_round_up(C, 32); p.Cpad = lnn_round_up(K, 32); p.pad_lo = 0;
+    if (use_wgrad_s2_v2()) return launch_wgrad_s2_v2<2>(s, p, "lnn_convT3d_k2s2_wgrad(v2)");
     constexpr int PY = 2 * 3 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=4
     p.taps.ntaps = 8;
     for (int t = 0; t < 8; ++t) {
