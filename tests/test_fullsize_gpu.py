@@ -1,0 +1,164 @@
+"""Full-size (-m gpu) checks at BASELINE configs[1] shapes (160x192x160, B=2), where the fp32 CPU oracle would need
+minutes per tensor: size-independent PROPERTIES of the HIP path through the C-ABI.
+
+  * adjointness:  <conv(x), dy> == <x, dgrad(dy)> == <w, wgrad(x, dy)>   (fwd / dgrad / wgrad of one layer are three
+    views of one trilinear form; any indexing error in a tile border, parity class or tap slot breaks the equality)
+    for the stride-1, stride-2 and transposed convolutions of the heaviest levels, evaluated at dy = conv(x) so that
+    the form is ||y||^2 (no cancellation: the three values agree to ~1e-6, the tolerance is 1e-4);
+  * linearity / exact power-of-two scaling of the conv (fp16 storage, fp32 accumulation: scaling by 2 is exact);
+  * InstanceNorm output statistics (mean 0, variance 1 per (sample, channel));
+  * Dice+CE: shift invariance of the loss in the logits and sum_k dlogits[k] == 0 per voxel;
+  * one complete C2 optimisation step: finite loss / gradient norm, parameters change, loss decreases over 3 steps.
+Inner products are taken in fp64 on the device with torch (plumbing, not the product)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lifelong_nnunet_amd import native as nat                   # noqa: E402
+from tests.gpu_utils import DEV, pack_conv_dgrad, pack_conv_fwd, pack_convT_dgrad, pack_convT_fwd   # noqa: E402
+
+N, D, H, W = 2, 160, 192, 160
+
+
+def _randh(shape, seed, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=DEV) * scale).half()
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def _close(a, b, tol):
+    assert abs(a - b) <= tol * max(abs(a), abs(b)), (a, b)
+
+
+@pytest.mark.parametrize("C,K,s,dims", [(64, 32, 1, (D, H, W)), (32, 32, 1, (D, H, W)), (32, 64, 2, (D, H, W)),
+                                         (128, 64, 1, (80, 96, 80)), (320, 320, 2, (10, 12, 10))])
+def test_conv_trilinear_form_is_consistent(C, K, s, dims):
+    d, h, w_ = dims
+    do, ho, wo = [(x - 1) // s + 1 for x in dims]
+    x = _randh((N, d, h, w_, C), 1, 0.5)
+    w = torch.randn((K, C, 3, 3, 3), generator=torch.Generator(device=DEV).manual_seed(3), device=DEV) * 0.05
+    w = w.half().float()                      # the kernels see fp16 weights
+    zero_b = torch.zeros(K, device=DEV)
+    y = torch.empty((N, do, ho, wo, K), dtype=torch.float16, device=DEV)
+    nat.call("lnn_conv3d_fwd", x, C, pack_conv_fwd(w), zero_b, y, K, N, d, h, w_, C, K, s)
+    dy = y.clone()
+    dx = torch.empty_like(x)
+    nat.call("lnn_conv3d_dgrad", dy, K, pack_conv_dgrad(w), dx, C, N, d, h, w_, C, K, s, 0)
+    panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 27, K, C), device=DEV)
+    nat.call("lnn_conv3d_wgrad", x, C, dy, K, panel, N, d, h, w_, C, K, s)
+    dw = torch.zeros((K, C, 3, 3, 3), device=DEV)
+    nat.call("lnn_unpack_wgrad", panel, dw, 27, K, C, C * 27, 27, 1, 1.0, 0)
+    f = _dot(y, dy)            # = ||y||^2; fp16 rounding of dx / fp32 atomics order: relative error ~ 2^-12 / sqrt(n)
+    assert f > 0
+    _close(f, _dot(x, dx), 1e-4)
+    _close(f, _dot(w, dw), 1e-4)
+    # accumulate flag: dx += dgrad
+    nat.call("lnn_conv3d_dgrad", dy, K, pack_conv_dgrad(w), dx, C, N, d, h, w_, C, K, s, 1)
+    _close(2 * f, _dot(x, dx), 2e-4)
+
+
+@pytest.mark.parametrize("C,K,dims", [(64, 32, (80, 96, 80)), (320, 320, (5, 6, 5))])
+def test_convT_trilinear_form_is_consistent(C, K, dims):
+    d, h, w_ = dims
+    x = _randh((N, d, h, w_, C), 1, 0.5)
+    w = (torch.randn((C, K, 2, 2, 2), generator=torch.Generator(device=DEV).manual_seed(3), device=DEV) * 0.1).half().float()
+    y = torch.empty((N, 2 * d, 2 * h, 2 * w_, K), dtype=torch.float16, device=DEV)
+    nat.call("lnn_convT3d_k2s2_fwd", x, C, pack_convT_fwd(w), y, K, N, d, h, w_, C, K)
+    dy = y.clone()
+    dx = torch.empty_like(x)
+    nat.call("lnn_convT3d_k2s2_dgrad", dy, K, pack_convT_dgrad(w), dx, C, N, d, h, w_, C, K, 0)
+    panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 8, C, K), device=DEV)
+    nat.call("lnn_convT3d_k2s2_wgrad", x, C, dy, K, panel, N, d, h, w_, C, K)
+    dw = torch.zeros((C, K, 2, 2, 2), device=DEV)
+    nat.call("lnn_unpack_wgrad", panel, dw, 8, C, K, K * 8, 8, 1, 1.0, 0)
+    f = _dot(y, dy)
+    assert f > 0
+    _close(f, _dot(x, dx), 1e-4)
+    _close(f, _dot(w, dw), 1e-4)
+
+
+def test_conv_power_of_two_scaling_is_exact():
+    C, K = 32, 32
+    x = _randh((N, D, H, W, C), 5, 0.5)
+    w = torch.randn((K, C, 3, 3, 3), generator=torch.Generator(device=DEV).manual_seed(6), device=DEV) * 0.05
+    wp, b = pack_conv_fwd(w), torch.zeros(K, device=DEV)
+    y1, y2 = torch.empty((N, D, H, W, K), dtype=torch.float16, device=DEV), torch.empty((N, D, H, W, K), dtype=torch.float16, device=DEV)
+    nat.call("lnn_conv3d_fwd", x, C, wp, b, y1, K, N, D, H, W, C, K, 1)
+    nat.call("lnn_conv3d_fwd", x * 2.0, C, wp, b, y2, K, N, D, H, W, C, K, 1)
+    # doubling is exact in fp16 (inputs, no overflow) and in the fp32 accumulation, so the rounded outputs double
+    # exactly -- except where y1 is an fp16 subnormal (< 6.1e-5: fewer mantissa bits than its doubled twin)
+    normal = y1.abs() >= 6.2e-5
+    assert torch.equal((y1 * 2.0)[normal], y2[normal])
+    assert float(((y1.float() * 2 - y2.float()).abs()).max()) <= 1.2e-7       # subnormal spacing 2^-24, doubled
+    # same launch twice: bit-identical (no atomics in the forward path)
+    nat.call("lnn_conv3d_fwd", x, C, wp, b, y2, K, N, D, H, W, C, K, 1)
+    assert torch.equal(y1, y2)
+
+
+def test_instnorm_output_statistics():
+    C, V = 32, D * H * W
+    y = _randh((N, V, C), 7, 3.0) + 1.5
+    z = torch.empty_like(y)
+    mean, rstd = torch.empty(N * C, device=DEV), torch.empty(N * C, device=DEV)
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, C), dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", y, N, V, C, 1e-5, mean, rstd, ws)
+    nat.call("lnn_instnorm_lrelu_fwd", y, z, C, N, V, C, mean, rstd, torch.ones(C, device=DEV), torch.zeros(C, device=DEV), 1.0)
+    zd = z.double()
+    assert float(zd.mean(dim=1).abs().max()) < 2e-3
+    assert float((zd.var(dim=1, unbiased=False) - 1).abs().max()) < 3e-3
+    ref_mean = y.double().mean(dim=1).reshape(-1)
+    assert float((mean.double() - ref_mean).abs().max()) < 1e-5 * float(ref_mean.abs().max()) + 1e-6
+
+
+def test_dice_ce_shift_invariance_and_gradient_sum():
+    K, V = 3, D * H * W
+    g = torch.Generator(device=DEV).manual_seed(9)
+    logits = torch.randn((N, K, V), generator=g, device=DEV) * 2
+    labels = torch.randint(0, K, (N, 1, V), generator=g, device=DEV).float()
+    ws = torch.zeros(nat.query("lnn_dice_ce_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    out1, out2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    nat.call("lnn_dice_ce_fwd", logits, labels, N, K, V, 0, 1e-5, out1, ws)
+    dl = torch.empty_like(logits)
+    nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, 0, 1e-5, ws, 1.0, None, dl)
+    shift = torch.randn((N, 1, V), generator=g, device=DEV)
+    ws2 = torch.zeros_like(ws)
+    nat.call("lnn_dice_ce_fwd", (logits + shift).contiguous(), labels, N, K, V, 0, 1e-5, out2, ws2)
+    assert abs(float(out1) - float(out2)) <= 2e-6 * abs(float(out1)) + 1e-7
+    # softmax-based loss: the gradient is orthogonal to the all-ones direction in every voxel
+    assert float(dl.sum(dim=1).abs().max()) <= 1e-6 * float(dl.abs().max()) + 1e-12
+    # and the loss of one-hot "perfect" logits approaches -1 (Dice) + 0 (CE)
+    perfect = (torch.nn.functional.one_hot(labels[:, 0].long(), K).permute(0, 2, 1).float() * 40).contiguous()
+    nat.call("lnn_dice_ce_fwd", perfect, labels, N, K, V, 0, 1e-5, out2, ws2)
+    assert abs(float(out2) + 1.0) < 1e-4
+
+
+def test_c2_training_steps_are_finite_and_learn():
+    from lifelong_nnunet_amd.losses import DC_and_CE_loss, MultipleOutputLoss2, ds_loss_weights
+    from lifelong_nnunet_amd.network import Generic_UNet
+    from lifelong_nnunet_amd.optim import FusedSGD, GradScaler
+    from lifelong_nnunet_amd.synthetic import make_patch_batch
+    net = Generic_UNet(1, 32, 3, 5, patch_size=(D, H, W), batch_size=N, device=DEV)
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), ds_loss_weights(5))
+    opt, scaler = FusedSGD(net, 1e-2, weight_decay=3e-5), GradScaler()
+    data, tgts = make_patch_batch(N, (D, H, W), 5, seed=12345)
+    data, tgts = data.to(DEV), [t.to(DEV) for t in tgts]
+    theta0 = net.arena.theta.clone()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        l = loss_fn(net(data), tgts)
+        scaler.scale(l).backward()
+        inv = 1.0 / scaler.get_scale()
+        opt.grad_norm_pass(inv)
+        opt.step(inv_scale=inv, max_norm=12.0)
+        norm, found_inf = opt.read_ctrl()
+        scaler.update(found_inf)
+        lv = float(l.detach())
+        assert lv == lv and abs(lv) < 1e6 and norm == norm and norm > 0 and not found_inf
+        losses.append(lv)
+    assert losses[-1] < losses[0]
+    assert float((net.arena.theta - theta0).abs().max()) > 0
