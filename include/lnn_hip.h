@@ -176,6 +176,13 @@ int lnn_ewc_penalty_bwd(lnn_stream_t s, const float* theta, const float* theta_s
 int lnn_fisher_square(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale);
 int lnn_fisher_accumulate(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale, float weight);
 int lnn_fisher_ema(lnn_stream_t s, const float* grad, float* fisher, long n, float unscale, float alpha);
+/* Riemannian Walk running statistics, rw/nnUNetTrainerRW.py:231-265 (_update_f_s_values), fused over a range of the
+ * flat arenas:  g = grad*inv_scale*min(1, max_norm/(sqrt(ctrl[0])+1e-6))  (the unscaled, clipped gradient the
+ * reference reads from param.grad after its optimiser step; ctrl = {sum g^2, #non-finite} from lnn_gradnorm_sumsq,
+ * may be NULL: no clipping);  if have_prev: score += max(0, g*(prev-theta)/(0.5*F*(theta-prev)^2 + eps));
+ * prev = theta;  F = alpha*g^2 + (1-alpha)*F.  Nothing is updated when ctrl[1] > 0 (skipped step). */
+int lnn_rw_update(lnn_stream_t s, const float* theta, float* prev, const float* grad, float* fisher, float* score,
+                  long n, float inv_scale, float max_norm, const double* ctrl, float alpha, float eps, int have_prev);
 /* out2[0] += sum (g*unscale)^2 (double), out2[1] += number of non-finite elements (double);
  * zero_first != 0 clears out2 before (several arena ranges can accumulate into one pair) */
 int lnn_gradnorm_sumsq(lnn_stream_t s, const float* grad, long n, float unscale, double* out2, int zero_first);

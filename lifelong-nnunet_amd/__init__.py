@@ -11,6 +11,7 @@ TRAINER_MAP = {
     "multihead": "lifelong_nnunet_amd.training.network_training.multihead.nnUNetTrainerMultiHead:nnUNetTrainerMultiHead",
     "sequential": "lifelong_nnunet_amd.training.network_training.sequential.nnUNetTrainerSequential:nnUNetTrainerSequential",
     "ewc": "lifelong_nnunet_amd.training.network_training.ewc.nnUNetTrainerEWC:nnUNetTrainerEWC",
+    "rw": "lifelong_nnunet_amd.training.network_training.rw.nnUNetTrainerRW:nnUNetTrainerRW",
     "lwf": "lifelong_nnunet_amd.training.network_training.lwf.nnUNetTrainerLWF:nnUNetTrainerLWF",
     "rehearsal": "lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal:nnUNetTrainerRehearsal",
 }

@@ -201,6 +201,34 @@ __global__ __launch_bounds__(NT) void sgd_clipped_kernel(float* __restrict__ th,
     }
 }
 
+// Riemannian-Walk running statistics (rw/nnUNetTrainerRW.py:231-265) on the flat arena, fused:
+//   g      = grad * inv_scale * clip_coef                      (what param.grad holds after unscale_ + clip_grad_norm_)
+//   score += max(0, g*(prev-theta) / (0.5*F*(theta-prev)^2 + eps))          (only if a previous snapshot exists)
+//   prev   = theta ;  F = alpha*g^2 + (1-alpha)*F
+__global__ __launch_bounds__(NT) void rw_update_kernel(const float* __restrict__ th, float* __restrict__ prev,
+                                                       const float* __restrict__ g, float* __restrict__ fisher,
+                                                       float* __restrict__ score, long n, float inv_scale, float max_norm,
+                                                       const double* __restrict__ ctrl, float alpha, float eps, int have_prev) {
+    float gs = inv_scale;
+    if (ctrl) {
+        if (ctrl[1] > 0.0) return;          // non-finite gradient: the optimiser step was skipped, keep the statistics
+        if (max_norm > 0.f) {
+            const float coef = max_norm / ((float)sqrt(ctrl[0]) + 1e-6f);
+            if (coef < 1.f) gs *= coef;
+        }
+    }
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float t = th[i], gi = g[i] * gs, f = fisher[i];
+        if (have_prev) {
+            const float d = prev[i] - t;
+            const float sc = (gi * d) / (0.5f * f * d * d + eps);
+            if (sc > 0.f) score[i] += sc;
+        }
+        prev[i] = t;
+        fisher[i] = alpha * gi * gi + (1.f - alpha) * f;
+    }
+}
+
 __global__ __launch_bounds__(NT) void cast_kernel(const float* __restrict__ s, half_t* __restrict__ d, long n) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) d[i] = (half_t)s[i];
 }
@@ -327,6 +355,19 @@ extern "C" int lnn_sgd_nesterov_step_clipped(lnn_stream_t s_, float* theta, floa
     hipLaunchKernelGGL(sgd_clipped_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, buf, grad, n, lr, momentum,
                        weight_decay, inv_scale, max_norm, ctrl);
     LNN_CHECK_LAUNCH("lnn_sgd_nesterov_step_clipped");
+    return LNN_OK;
+}
+
+extern "C" int lnn_rw_update(lnn_stream_t s_, const float* theta, float* prev, const float* grad, float* fisher, float* score,
+                             long n, float inv_scale, float max_norm, const double* ctrl, float alpha, float eps,
+                             int have_prev) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(theta && prev && grad && fisher && score, "lnn_rw_update: null pointer");
+    LNN_REQUIRE(alpha > 0.f && alpha <= 1.f, "lnn_rw_update: alpha %g outside (0, 1]", (double)alpha);
+    if (n <= 0) return LNN_OK;
+    hipLaunchKernelGGL(rw_update_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, prev, grad, fisher, score, n, inv_scale,
+                       max_norm, ctrl, alpha, eps, have_prev);
+    LNN_CHECK_LAUNCH("lnn_rw_update");
     return LNN_OK;
 }
 

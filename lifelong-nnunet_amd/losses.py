@@ -147,24 +147,71 @@ class MultipleOutputLossEWC(MultipleOutputLoss2):
             self._flat[key] = (F, S)
         return self._flat[key]
 
+    def _regulariser(self, lam):
+        """sum over ``self.tasks`` of lam/2 * sum F_t (theta - theta*_t)^2, or None when nothing applies."""
+        if len(self.tasks) == 0 or self.network_params is None:
+            return None
+        fishers, stars, arena, anchor = [], [], None, None
+        for task in self.tasks:
+            # deep_supervision.py:65-66: the task loop is outermost and ``network_params`` is whatever the
+            # trainer handed over -- a *generator* for the base EWC trainer (ewc/nnUNetTrainerEWC.py:140,247),
+            # which is exhausted after the first task (and stays exhausted until update_network_params).
+            named = [(n, p) for n, p in self.network_params]
+            if not named:
+                continue
+            arena = named[0][1]._lnn_net.arena
+            anchor = next((p for _, p in named if p.requires_grad), named[0][1])
+            F, S = self._flat_for(task, named, arena)
+            fishers.append(F)
+            stars.append(S)
+        if not fishers:
+            return None
+        return _EWCPenaltyFunction.apply(anchor, arena, fishers, stars, lam)
+
     def forward(self, x, y, reg=True):
         loss = super().forward(x, y)
-        if reg and len(self.tasks) > 0 and self.network_params is not None:
-            fishers, stars, arena, anchor = [], [], None, None
-            for task in self.tasks:
-                # deep_supervision.py:65-66: the task loop is outermost and ``network_params`` is whatever the
-                # trainer handed over -- a *generator* for the base EWC trainer (ewc/nnUNetTrainerEWC.py:140,247),
-                # which is exhausted after the first task (and stays exhausted until update_network_params).
-                named = [(n, p) for n, p in self.network_params]
-                if not named:
+        if reg:
+            pen = self._regulariser(self.ewc_lambda)
+            if pen is not None:
+                loss = loss + pen
+        return loss
+
+
+# ------------------------------------------------------------------------------------------------- RW
+class MultipleOutputLossRW(MultipleOutputLossEWC):
+    """deep_supervision.py:86-135: ``loss + lambda * sum_{task in tasks} sum (F_task + S_task) * (theta - theta*_task)^2``
+    with ``tasks = list(fisher)[:-1]`` (the last entry is the task being trained, :106).  Same flat-arena kernels as
+    EWC: the importance scores are added to the Fisher arena and lambda is doubled (EWC's kernel carries the 1/2).
+    The generator semantics of ``network_params`` are inherited -- and the RW trainer never refreshes it
+    (rw/nnUNetTrainerRW.py:122-125,218-229), so in parity mode the penalty is non-zero for exactly one forward."""
+
+    def __init__(self, loss, weight_factors=None, ewc_lambda=0.4, fisher=dict(), params=dict(), parameter_importance=dict(),
+                 network_params=None, match_sth=False, match=list(), match_true=True):
+        super().__init__(loss, weight_factors, ewc_lambda, fisher, params, network_params, match_sth, match, match_true)
+        self.parameter_importance = parameter_importance
+
+    def update_rw_params(self, fisher, params, parameter_importance):
+        super().update_ewc_params(fisher, params)
+        self.parameter_importance = parameter_importance
+        self.tasks = list(self.fisher.keys())[:-1]
+
+    def _flat_for(self, task, named, arena):
+        key = (task, tuple(n for n, _ in named))
+        if key not in self._flat:
+            F, S = super()._flat_for(task, named, arena)
+            for name, p in named:
+                if not self._selected(name):
                     continue
-                arena = named[0][1]._lnn_net.arena
-                anchor = next((p for _, p in named if p.requires_grad), named[0][1])
-                F, S = self._flat_for(task, named, arena)
-                fishers.append(F)
-                stars.append(S)
-            if fishers:
-                loss = loss + _EWCPenaltyFunction.apply(anchor, arena, fishers, stars, self.ewc_lambda)
+                s = p._lnn_slot
+                F[s.offset:s.offset + s.numel] += self.parameter_importance[task][name].to(F.device, torch.float32).expand(s.shape).reshape(-1)
+            self._flat[key] = (F, S)
+        return self._flat[key]
+
+    def forward(self, x, y):
+        loss = MultipleOutputLoss2.forward(self, x, y)
+        pen = self._regulariser(2.0 * self.ewc_lambda)
+        if pen is not None:
+            loss = loss + pen
         return loss
 
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lnn_fisher_square": (_i, [_p, _p, _p, _l, _f]),
     "lnn_fisher_accumulate": (_i, [_p, _p, _p, _l, _f, _f]),
     "lnn_fisher_ema": (_i, [_p, _p, _p, _l, _f, _f]),
+    "lnn_rw_update": (_i, [_p, _p, _p, _p, _p, _p, _l, _f, _f, _p, _f, _f, _i]),
     "lnn_gradnorm_sumsq": (_i, [_p, _p, _l, _f, _p, _i]),
     "lnn_sgd_nesterov_step_clipped": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p]),
     "lnn_sgd_nesterov_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),

@@ -196,6 +196,7 @@ class nnUNetTrainerMultiHead:
                 self.dp.finish()
                 world_avg = self.dp.averaging_factor
             inv = world_avg / scale
+            self.last_inv_scale = inv
             self.optimizer.grad_norm_pass(inv)                    # unscale_ + the norm of clip_grad_norm_(…, 12)
             self.optimizer.step(inv_scale=inv, max_norm=12.0)      # clip coefficient + inf-skip applied on device
         if run_online_evaluation:

@@ -71,6 +71,24 @@ def ewc_penalty(named_params, fisher, params, ewc_lambda=0.4, first_task_only=Tr
     return pen if pen is not None else torch.zeros(())
 
 
+def rw_penalty(named_params, fisher, params, importance, rw_lambda=0.4, first_task_only=True):
+    """deep_supervision.py:110-135 (MultipleOutputLossRW.forward): for every task but the one being trained
+    (``tasks = list(fisher)[:-1]``, :106) ``lambda * sum((F + S) * (theta - theta*)^2)`` -- no 1/2, unlike EWC.
+    ``first_task_only``: the RW trainer hands the loss ``network.named_parameters()`` (rw/nnUNetTrainerRW.py:122-125,
+    a generator) and never refreshes it, so the nested loop only ever sees parameters for the first task of the FIRST
+    forward with previous tasks; afterwards the penalty is silently zero.  Callers model "afterwards" by passing an
+    empty ``named_params``."""
+    named_params = list(named_params)
+    pen = None
+    for ti, task in enumerate(list(fisher.keys())[:-1]):
+        if first_task_only and ti > 0:
+            break
+        for name, p in named_params:
+            t = rw_lambda * ((fisher[task][name] + importance[task][name]) * (p - params[task][name]).pow(2)).sum()
+            pen = t if pen is None else pen + t
+    return pen if pen is not None else torch.zeros(())
+
+
 def lwf_distillation(pred_logits, teacher_logits, temperature=2.0):
     """deep_supervision.py:194-196: batchmean KL between log-softmaxes at temperature T (no T^2)."""
     return F.kl_div(F.log_softmax(pred_logits.float() / temperature, dim=1),

@@ -83,7 +83,8 @@ def main():
     install_shim()
     torch.manual_seed(0)
     # torch.Tensor.get_device() returns -1 on CPU which the shimmed to_cuda ignores
-    from nnunet_ext.training.loss_functions.deep_supervision import MultipleOutputLossEWC, MultipleOutputLossLWF
+    from nnunet_ext.training.loss_functions.deep_supervision import (MultipleOutputLossEWC, MultipleOutputLossLWF,
+                                                                      MultipleOutputLossRW)
     from nnunet_ext.network_architecture.MultiHead_Module import MultiHead_Module
 
     meta = {}
@@ -127,6 +128,45 @@ def main():
         ewc[f"logits_{i}"] = x.numpy(); ewc[f"target_{i}"] = y.numpy()
     np.savez_compressed(os.path.join(OUT, "ewc_reference.npz"), **ewc)
     meta["ewc"] = {"names": names, "generator": float(v_gen), "list": float(v_list), "base": float(v_base)}
+
+    # ------------------------------------------------------------------ RW loss (reference executed verbatim)
+    # three tasks in the dicts: the last one is the task being trained and is omitted by update_rw_params (DS.py:106)
+    g = torch.Generator().manual_seed(17)
+    tasks3 = ("taskA", "taskB", "taskC")
+    rfisher = OrderedDict((t, OrderedDict((n, torch.rand(s, generator=g)) for n, s in zip(names, shapes))) for t in tasks3)
+    rstar = OrderedDict((t, OrderedDict((n, torch.randn(s, generator=g)) for n, s in zip(names, shapes))) for t in tasks3)
+    rimp = OrderedDict((t, OrderedDict((n, 2 * torch.rand(s, generator=g)) for n, s in zip(names, shapes))) for t in tasks3)
+    rw_gen = MultipleOutputLossRW(base, w, lam, OrderedDict(), OrderedDict(), OrderedDict(), iter(theta.items()))
+    rw_gen.update_rw_params(rfisher, rstar, rimp)
+    for p_ in theta.values():
+        p_.grad = None
+    r_gen = rw_gen(tuple(xs), ys)
+    r_gen.backward()
+    rg_gen = {n: p_.grad.clone() for n, p_ in theta.items()}
+    r_gen2 = rw_gen(tuple(xs), ys)                 # second forward: generator exhausted -> base loss only
+    rw_list = MultipleOutputLossRW(base, w, lam, OrderedDict(), OrderedDict(), OrderedDict(), list(theta.items()))
+    rw_list.update_rw_params(rfisher, rstar, rimp)
+    r_list = rw_list(tuple(xs), ys)
+    o_gen = v_base + losses.rw_penalty(theta.items(), rfisher, rstar, rimp, lam, first_task_only=True)
+    o_list = v_base + losses.rw_penalty(theta.items(), rfisher, rstar, rimp, lam, first_task_only=False)
+    assert abs(float(o_gen.detach()) - float(r_gen.detach())) <= 1e-6 * abs(float(r_gen)), (o_gen, r_gen)
+    assert abs(float(o_list.detach()) - float(r_list.detach())) <= 1e-6 * abs(float(r_list)), (o_list, r_list)
+    assert abs(float(r_gen2.detach()) - float(v_base)) <= 1e-6 * abs(float(v_base))
+    rw = {"lambda": np.float64(lam), "ds_weights": w, "base_loss": np.float64(float(v_base)),
+          "ref_value_generator": np.float64(float(r_gen)), "ref_value_generator_second_call": np.float64(float(r_gen2)),
+          "ref_value_list": np.float64(float(r_list))}
+    for i, n in enumerate(names):
+        rw[f"theta_{i}"] = theta[n].detach().numpy()
+        rw[f"grad_generator_{i}"] = rg_gen[n].numpy()
+        for t in tasks3:
+            rw[f"fisher_{t}_{i}"] = rfisher[t][n].numpy()
+            rw[f"star_{t}_{i}"] = rstar[t][n].numpy()
+            rw[f"importance_{t}_{i}"] = rimp[t][n].numpy()
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        rw[f"logits_{i}"] = x.numpy(); rw[f"target_{i}"] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, "rw_reference.npz"), **rw)
+    meta["rw"] = {"names": names, "tasks": list(tasks3), "generator": float(r_gen), "second_call": float(r_gen2),
+                  "list": float(r_list), "base": float(v_base)}
 
     # ------------------------------------------------------------------ LwF (reference executed verbatim)
     lwf = {}

@@ -59,6 +59,60 @@ def ewc_after_train(net, opt, batches, weights, loss_extra=None, batch_dice=Fals
     return fisher, params
 
 
+RW_EPSILON = 1e-8          # rw/nnUNetTrainerRW.py:17
+
+
+def rw_new_task_state(net):
+    """rw/nnUNetTrainerRW.py:163-169: zero Fisher / score per trainable parameter; prev_param None, count 0 (:179)."""
+    fisher = OrderedDict((n, torch.zeros_like(p)) for n, p in net.named_parameters() if p.requires_grad)
+    scores = OrderedDict((n, torch.zeros_like(p)) for n, p in net.named_parameters() if p.requires_grad)
+    return {"fisher": fisher, "scores": scores, "prev_param": None, "count": 0}
+
+
+def rw_update_f_s(net, st, alpha=0.9, fisher_update_after=10):
+    """rw/nnUNetTrainerRW.py:231-265, called after every run_iteration (``param.grad`` is therefore the clipped
+    gradient the optimiser step just used).  Every ``fisher_update_after`` iterations:
+      score += max(0, g * (prev - theta) / (0.5 * F * (theta - prev)^2 + eps))      (only once a prev exists)
+      prev   = theta
+      F      = alpha * g^2 + (1 - alpha) * F
+    for the parameters that have a gradient."""
+    if st["count"] % fisher_update_after == 0:
+        if st["prev_param"] is not None:
+            for name, p in net.named_parameters():
+                if p.grad is not None:
+                    delta = p.grad.detach() * (st["prev_param"][name] - p.detach())
+                    den = 0.5 * st["fisher"][name] * (p.detach() - st["prev_param"][name]).pow(2) + RW_EPSILON
+                    sc = delta / den
+                    sc[sc < 0] = 0
+                    st["scores"][name] += sc
+        st["prev_param"] = {k: v.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
+        for name, p in net.named_parameters():
+            if p.grad is not None:
+                st["fisher"][name] = alpha * p.grad.data.clone().pow(2) + (1 - alpha) * st["fisher"][name]
+    st["count"] += 1
+
+
+def rw_finish_task(net, st, n_finished, prev_scores=None):
+    """rw/nnUNetTrainerRW.py:174-205, after the epochs of a task (``n_finished`` = len(finished_training_on), which
+    already contains the task).  Quirks kept: the Fisher is normalised with the extrema of the per-tensor maxima of
+    the SCORES (:184-188 reuse ``self.scores``); the scores are rescaled to [0, 2] for the first task (:193-197), left
+    untouched for the second, and for >= 3 tasks averaged with ``scores[finished[-1]]`` which is the task itself
+    (:198-204)."""
+    params = OrderedDict((n, p.data.clone()) for n, p in net.named_parameters())
+    values = [torch.max(v) for v in st["scores"].values()]
+    minim, maxim = min(values), max(values)
+    fisher = OrderedDict((k, (v - minim) / (maxim - minim + RW_EPSILON)) for k, v in st["fisher"].items())
+    scores = OrderedDict((k, v.clone()) for k, v in st["scores"].items())
+    if n_finished == 1:
+        for k, v in st["scores"].items():
+            scores[k] = 2 * ((v - minim) / (maxim - minim + RW_EPSILON))
+    elif n_finished > 2:
+        prev = {k: v.clone() for k, v in st["scores"].items()}
+        for k, v in st["scores"].items():
+            scores[k] = 0.5 * (prev[k] + (v - minim) / (maxim - minim + RW_EPSILON))
+    return fisher, params, scores
+
+
 def lwf_loss_value(base_loss, pred_logits, target_logits, temperature=2.0):
     """deep_supervision.py:201-214 -- KL terms are added to the value; they carry no gradient because
     the predictions are detached (lwf/nnUNetTrainerLWF.py:343)."""

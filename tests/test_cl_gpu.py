@@ -193,3 +193,81 @@ def test_sequential_trainer_heads_and_checkpoint():
     tr2.load_checkpoint_ram(ck)
     sd2 = tr2.mh_network.state_dict()
     assert all(torch.equal(sd2[k].cpu(), v) for k, v in ck["state_dict"].items())
+
+
+def test_rw_loss_class_matches_reference_values(golden_dir):
+    """MultipleOutputLossRW on the flat arenas vs the reference class executed verbatim (rw_reference.npz)."""
+    from lifelong_nnunet_amd.losses import MultipleOutputLossRW
+    d = np.load(golden_dir + "/rw_reference.npz")
+    meta = json.load(open(golden_dir + "/meta.json"))["rw"]
+    names, tasks = meta["names"], meta["tasks"]
+    slots = [ParamSlot(n, tuple(d[f"theta_{i}"].shape)) for i, n in enumerate(names)]
+    arena = ParamArena(slots, DEV)
+    fake_net = types.SimpleNamespace(arena=arena)
+    params = []
+    for i, s in enumerate(slots):
+        p = torch.nn.Parameter(arena.view(s))
+        p._lnn_net, p._lnn_slot = fake_net, s
+        with torch.no_grad():
+            p.copy_(torch.from_numpy(d[f"theta_{i}"]))
+        p.grad = arena.view(s, "grad")
+        params.append((s.name, p))
+    get = lambda key: {t: {n: torch.from_numpy(d[f"{key}_{t}_{i}"]) for i, n in enumerate(names)} for t in tasks}
+    fisher, star, imp = get("fisher"), get("star"), get("importance")
+    xs = tuple(torch.from_numpy(d[f"logits_{i}"]).to(DEV) for i in range(2))
+    ys = [torch.from_numpy(d[f"target_{i}"]).to(DEV) for i in range(2)]
+    lam = float(d["lambda"])
+    loss = MultipleOutputLossRW(_base(), d["ds_weights"], lam, dict(), dict(), dict(), iter(params))
+    loss.update_rw_params(fisher, star, imp)
+    assert loss.tasks == tasks[:-1]                       # the task being trained is omitted (DS.py:106)
+    v = loss(xs, ys)
+    assert abs(float(v) - float(d["ref_value_generator"])) <= 1e-5 * abs(float(d["ref_value_generator"]))
+    arena.grad.zero_()
+    v.backward()
+    for i, (n, p) in enumerate(params):
+        assert torch.allclose(p.grad.cpu(), torch.from_numpy(d[f"grad_generator_{i}"]), rtol=1e-4, atol=1e-5)
+    # generator exhausted and never refreshed by the RW trainer: base loss from now on
+    v2 = loss(xs, ys)
+    assert abs(float(v2) - float(d["ref_value_generator_second_call"])) <= 1e-5 * abs(float(v2))
+    loss.update_network_params(list(params))
+    assert abs(float(loss(xs, ys)) - float(d["ref_value_list"])) <= 1e-5 * abs(float(d["ref_value_list"]))
+
+
+def test_rw_trainer_flow_matches_oracle():
+    """nnUNetTrainerRW (fused lnn_rw_update on the flat arenas) vs oracle.train.rw_update_f_s / rw_finish_task:
+    3 training + 1 validation iteration of task A with fisher_update_after=2, then the end-of-task normalisation."""
+    torch.manual_seed(12345)
+    onet = OracleGenericUNet(1, 8, 3, 2)
+    tr = _make_trainer("rw", "taskA", fisher_update_after=2, rw_alpha=0.9, rw_lambda=0.4)
+    tr.network.load_state_dict(onet.state_dict())
+    tr.mh_network.update_after_iteration()
+    w = olosses.ds_loss_weights(2)
+    oopt = otrain.make_optimizer(onet, lr=tr.optimizer.param_groups[0]['lr'])
+    tr.run_training("taskA")
+    # ---- the same on the oracle
+    st = otrain.rw_new_task_state(onet)
+    gen = default_data_provider("taskA", "train", TOY)
+    ol = []
+    for _ in range(3):
+        b = next(gen)
+        ol.append(otrain.run_iteration(onet, oopt, b['data'], b['target'], w)[0])
+        otrain.rw_update_f_s(onet, st, alpha=0.9, fisher_update_after=2)
+    assert abs(tr.all_tr_losses[0] - np.mean(ol)) <= 1e-4 * abs(np.mean(ol))
+    oopt.zero_grad(set_to_none=False)                  # the validation iteration: zero_grad, no backward (MH.py:612)
+    otrain.rw_update_f_s(onet, st, alpha=0.9, fisher_update_after=2)
+    assert st["count"] == 4 and tr.count == 0          # the trainer resets its counter after the task (:179)
+    ofisher, oparams, oscores = otrain.rw_finish_task(onet, st, n_finished=1)
+    names = list(ofisher.keys())
+    assert list(tr.fisher["taskA"].keys()) == names == list(tr.scores["taskA"].keys())
+    assert "seg_outputs.0.weight" in names             # trainable, but without gradient: stays at its initial zero
+    fg, fo = _flat(tr.fisher["taskA"], names), _flat(ofisher, names)
+    sg, so = _flat(tr.scores["taskA"], names), _flat(oscores, names)
+    pg, po = _flat(tr.params["taskA"], list(oparams.keys())), _flat(oparams, list(oparams.keys()))
+    rel_f, rel_s, rel_p = [float((a - b).norm() / b.norm()) for a, b in ((fg, fo), (sg, so), (pg, po))]
+    print(f"RW fisher rel err {rel_f:.3e}  scores rel err {rel_s:.3e}  theta* rel err {rel_p:.3e}")
+    assert rel_f < 5e-2 and rel_s < 5e-2 and rel_p < 1e-3
+    assert float(sg.max()) <= 2.0 + 1e-5               # first task: scaled so that the largest score is 2 (:193-197)
+    # ---- task B: the penalty is live on the first forward only (generator never refreshed)
+    tr.run_training("taskB")
+    assert tr.loss.tasks == ["taskA"] and list(tr.fisher.keys()) == ["taskA", "taskB"]
+    assert [n for n, _ in tr.loss.network_params] == []

@@ -4,6 +4,7 @@
 MultipleOutputLossEWC / MultipleOutputLossLWF classes (executed verbatim through oracle/make_goldens.py's
 shim in the build container); the rest pins the oracle against independent restatements."""
 import json
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -122,3 +123,61 @@ def test_fisher_is_last_batch_only():
         else:
             assert torch.equal(fi[n], p.grad.pow(2))
         assert torch.equal(pa[n], p.data)
+
+
+def test_rw_penalty_matches_reference_generator_and_list(golden_dir):
+    """oracle.losses.rw_penalty == MultipleOutputLossRW executed verbatim (tests/golden/rw_reference.npz)."""
+    d = np.load(golden_dir + "/rw_reference.npz")
+    meta = json.load(open(golden_dir + "/meta.json"))["rw"]
+    names, tasks = meta["names"], meta["tasks"]
+    theta = [(n, torch.nn.Parameter(torch.from_numpy(d[f"theta_{i}"]))) for i, n in enumerate(names)]
+    get = lambda key: OrderedDict((t, OrderedDict((n, torch.from_numpy(d[f"{key}_{t}_{i}"])) for i, n in enumerate(names))) for t in tasks)
+    fisher, star, imp = get("fisher"), get("star"), get("importance")
+    xs = [torch.from_numpy(d[f"logits_{i}"]) for i in range(2)]
+    ys = [torch.from_numpy(d[f"target_{i}"]) for i in range(2)]
+    base = losses.multiple_output_loss(xs, ys, d["ds_weights"])
+    lam = float(d["lambda"])
+    v_gen = base + losses.rw_penalty(theta, fisher, star, imp, lam, first_task_only=True)
+    v_list = base + losses.rw_penalty(theta, fisher, star, imp, lam, first_task_only=False)
+    assert abs(float(v_gen) - float(d["ref_value_generator"])) <= 1e-6 * abs(float(d["ref_value_generator"]))
+    assert abs(float(v_list) - float(d["ref_value_list"])) <= 1e-6 * abs(float(d["ref_value_list"]))
+    # exhausted generator == no parameters: the reference's second call returns the base loss
+    v_none = base + losses.rw_penalty([], fisher, star, imp, lam)
+    assert abs(float(v_none) - float(d["ref_value_generator_second_call"])) <= 1e-6 * abs(float(v_none))
+    # the task being trained (last key) never contributes
+    v2 = base + losses.rw_penalty(theta, OrderedDict(list(fisher.items())[:2]), star, imp, lam, first_task_only=False)
+    assert abs(float(v2) - float(v_gen)) <= 1e-6 * abs(float(v_gen))
+    g = torch.autograd.grad(v_gen, [p for _, p in theta])
+    for i in range(len(names)):
+        assert torch.allclose(g[i], torch.from_numpy(d[f"grad_generator_{i}"]), rtol=1e-5, atol=1e-7)
+
+
+def test_rw_running_statistics_restatement():
+    """rw_update_f_s / rw_finish_task on a two-parameter toy: hand-computed values of the formulas at
+    rw/nnUNetTrainerRW.py:231-265 and :183-204."""
+    net = torch.nn.Linear(2, 1, bias=False)
+    with torch.no_grad():
+        net.weight.copy_(torch.tensor([[1.0, -2.0]]))
+    st = train.rw_new_task_state(net)
+    net.weight.grad = torch.tensor([[0.5, -1.0]])
+    train.rw_update_f_s(net, st, alpha=0.9, fisher_update_after=2)            # count 0: no prev yet
+    assert torch.allclose(st["fisher"]["weight"], 0.9 * torch.tensor([[0.25, 1.0]]))
+    assert float(st["scores"]["weight"].abs().sum()) == 0 and st["count"] == 1
+    with torch.no_grad():
+        net.weight.copy_(torch.tensor([[0.8, -1.5]]))
+    train.rw_update_f_s(net, st, alpha=0.9, fisher_update_after=2)            # count 1: skipped
+    assert st["count"] == 2 and torch.allclose(st["prev_param"]["weight"], torch.tensor([[1.0, -2.0]]))
+    net.weight.grad = torch.tensor([[1.0, 1.0]])
+    F0 = st["fisher"]["weight"].clone()
+    train.rw_update_f_s(net, st, alpha=0.9, fisher_update_after=2)            # count 2: score + EMA
+    d_ = torch.tensor([[1.0 - 0.8, -2.0 + 1.5]])
+    sc = (torch.tensor([[1.0, 1.0]]) * d_) / (0.5 * F0 * d_.pow(2) + train.RW_EPSILON)
+    sc[sc < 0] = 0
+    assert torch.allclose(st["scores"]["weight"], sc)
+    assert torch.allclose(st["fisher"]["weight"], 0.9 * torch.ones(1, 2) + 0.1 * F0)
+    fisher, params, scores = train.rw_finish_task(net, st, n_finished=1)
+    mx = st["scores"]["weight"].max()
+    assert torch.allclose(scores["weight"], 2 * (st["scores"]["weight"] - mx) / (mx - mx + train.RW_EPSILON))
+    assert torch.allclose(fisher["weight"], (st["fisher"]["weight"] - mx) / train.RW_EPSILON)
+    _, _, scores2 = train.rw_finish_task(net, st, n_finished=2)
+    assert torch.equal(scores2["weight"], st["scores"]["weight"])
