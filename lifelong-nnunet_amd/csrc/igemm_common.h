@@ -39,6 +39,8 @@ __host__ __device__ __forceinline__ long lnn_panel_off(int slot, int m, int kc, 
 int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);
 // v7 (igemm_conv_v7.hip): single-buffered, two 8-wave blocks per CU (hardware interleaves staging and MFMA phases)
 int lnn_launch_conv_s1_v7(hipStream_t s, ConvParams& p, const char* name);
+// v8 (igemm_conv_v8.hip): v5 structure with a 64-output-channel register tile (M >= 64)
+int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name);
 // v6 (igemm_conv_v6.hip): two wave groups per block running half a step out of phase (compute / memory ping-pong).
 int lnn_launch_conv_s1_v6(hipStream_t s, ConvParams& p, const char* name);
 // single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,
