@@ -154,6 +154,19 @@ int lnn_online_dice_counts(lnn_stream_t s, const float* logits, const float* lab
                            float* counts);
 
 /* ------------------------------------------------------------------------------------------------
+ * Sliding-window inference (predict.py:208-219 -> upstream SegmentationNetwork._internal_predict_3D_3Dconv_tiled):
+ * one tile:  agg[k, o + u] += weight * gauss[u] * softmax(logits)[k, flip(u)],   nb[o + u] += gauss[u] (if add_nb)
+ *   logits (K, pd,ph,pw) fp32 of ONE tile as the network produced it from the tile mirrored along flip_mask
+ *   (bit 2 = z, 1 = y, 0 = x); gauss (pd,ph,pw) importance map or NULL (= 1); agg (K, D,H,W), nb (D,H,W) fp32;
+ *   weight = 1 / number of mirror passes.  Tiles of one volume must be accumulated in stream order (plain +=).
+ * finalize: agg /= nb (class probabilities, in place), seg[v] = argmax_k.
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_softmax_accumulate(lnn_stream_t s, const float* logits, const float* gauss, float* agg, float* nb, int K,
+                           int pd, int ph, int pw, int D, int H, int W, int oz, int oy, int ox, int flip_mask,
+                           float weight, int add_nb);
+int lnn_softmax_finalize(lnn_stream_t s, float* agg, const float* nb, int K, long V, int* seg);
+
+/* ------------------------------------------------------------------------------------------------
  * LwF distillation (deep_supervision.py:194-196):
  *   out = (1/N) sum_{n,k,v} softmax(t/T)_k * (logsoftmax(t/T)_k - logsoftmax(y/T)_k)
  * pred / teach: (N,K,V) fp32.  out: one float.  ws: >= 1 double.

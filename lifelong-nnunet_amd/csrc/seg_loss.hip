@@ -325,6 +325,50 @@ __global__ void kl_finalize_kernel(const double* ws, int N, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(ws[0] / (double)N);
 }
 
+// ---------------------------------------------------------------------------------------- sliding-window inference
+// One tile of the tiled predictor (upstream SegmentationNetwork._internal_predict_3D_3Dconv_tiled, reached through
+// predict.py:208-219 / MH.py:1115): agg[k, o + flipback(v)] += weight * gauss[flipback(v)] * softmax(logits[:, v])[k],
+// nb[o + v] += gauss[v] when add_nb.  flip bits: 4 = z, 2 = y, 1 = x (the network saw the tile mirrored on them).
+__global__ __launch_bounds__(NT) void softmax_accumulate_kernel(const float* __restrict__ logits, const float* __restrict__ gauss,
+                                                                float* __restrict__ agg, float* __restrict__ nb, int K, int pd,
+                                                                int ph, int pw, int D, int H, int W, int oz, int oy, int ox,
+                                                                int flip, float weight, int add_nb) {
+    const long Vp = (long)pd * ph * pw, Vi = (long)D * H * W;
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < Vp; v += (long)gridDim.x * NT) {
+        float p[KMAX], x[KMAX], lse;
+        softmax_k(logits, Vp, v, K, 1.f, p, lse, x);
+        int z = (int)(v / ((long)ph * pw)), y = (int)((v / pw) % ph), xx = (int)(v % pw);
+        if (flip & 4) z = pd - 1 - z;
+        if (flip & 2) y = ph - 1 - y;
+        if (flip & 1) xx = pw - 1 - xx;
+        const long vo = ((long)z * ph + y) * pw + xx;
+        const float g = gauss ? gauss[vo] : 1.f;
+        const long vi = ((long)(oz + z) * H + (oy + y)) * W + (ox + xx);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) agg[(long)k * Vi + vi] += weight * g * p[k];
+        if (add_nb) nb[vi] += g;
+    }
+}
+
+// class probabilities = agg / nb (in place), segmentation = argmax_k (first maximum, like numpy / torch)
+__global__ __launch_bounds__(NT) void softmax_finalize_kernel(float* __restrict__ agg, const float* __restrict__ nb, int K, long V,
+                                                              int* __restrict__ seg) {
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        const float inv = 1.f / nb[v];
+        float best = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const float q = agg[(long)k * V + v] * inv;
+                agg[(long)k * V + v] = q;
+                if (q > best) { best = q; arg = k; }
+            }
+        seg[v] = arg;
+    }
+}
+
 int vox_blocks(long V) {
     long b = (V + NT * 8 - 1) / (NT * 8);
     if (b > 1024) b = 1024;
@@ -400,6 +444,29 @@ extern "C" int lnn_online_dice_counts(lnn_stream_t s_, const float* logits, cons
     hipMemsetAsync(counts, 0, sizeof(float) * N * (K - 1) * 3, s);
     hipLaunchKernelGGL(online_dice_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, K, V, counts);
     LNN_CHECK_LAUNCH("lnn_online_dice_counts");
+    return LNN_OK;
+}
+
+extern "C" int lnn_softmax_accumulate(lnn_stream_t s_, const float* logits, const float* gauss, float* agg, float* nb, int K,
+                                      int pd, int ph, int pw, int D, int H, int W, int oz, int oy, int ox, int flip_mask,
+                                      float weight, int add_nb) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(logits && agg && (nb || !add_nb), "lnn_softmax_accumulate: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_softmax_accumulate: K=%d unsupported (2..%d)", K, KMAX);
+    LNN_REQUIRE(pd > 0 && ph > 0 && pw > 0 && oz >= 0 && oy >= 0 && ox >= 0 && oz + pd <= D && oy + ph <= H && ox + pw <= W,
+                "lnn_softmax_accumulate: tile (%d,%d,%d)+(%d,%d,%d) outside the volume (%d,%d,%d)", oz, oy, ox, pd, ph, pw, D, H, W);
+    hipLaunchKernelGGL(softmax_accumulate_kernel, dim3(vox_blocks((long)pd * ph * pw)), dim3(NT), 0, s, logits, gauss, agg, nb, K, pd,
+                       ph, pw, D, H, W, oz, oy, ox, flip_mask, weight, add_nb);
+    LNN_CHECK_LAUNCH("lnn_softmax_accumulate");
+    return LNN_OK;
+}
+
+extern "C" int lnn_softmax_finalize(lnn_stream_t s_, float* agg, const float* nb, int K, long V, int* seg) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(agg && nb && seg, "lnn_softmax_finalize: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_softmax_finalize: K=%d unsupported (2..%d)", K, KMAX);
+    hipLaunchKernelGGL(softmax_finalize_kernel, dim3(vox_blocks(V)), dim3(NT), 0, s, agg, nb, K, V, seg);
+    LNN_CHECK_LAUNCH("lnn_softmax_finalize");
     return LNN_OK;
 }
 

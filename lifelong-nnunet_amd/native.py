@@ -53,6 +53,8 @@ SIGNATURES = {
     "lnn_fisher_accumulate": (_i, [_p, _p, _p, _l, _f, _f]),
     "lnn_fisher_ema": (_i, [_p, _p, _p, _l, _f, _f]),
     "lnn_rw_update": (_i, [_p, _p, _p, _p, _p, _p, _l, _f, _f, _p, _f, _f, _i]),
+    "lnn_softmax_accumulate": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_f, _i]),
+    "lnn_softmax_finalize": (_i, [_p, _p, _p, _i, _l, _p]),
     "lnn_gradnorm_sumsq": (_i, [_p, _p, _l, _f, _p, _i]),
     "lnn_sgd_nesterov_step_clipped": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p]),
     "lnn_sgd_nesterov_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),

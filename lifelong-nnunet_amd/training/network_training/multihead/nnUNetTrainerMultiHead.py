@@ -263,6 +263,20 @@ class nnUNetTrainerMultiHead:
         return results
 
     # ------------------------------------------------------------------------------------------ persistence
+    def predict_preprocessed_data_return_seg_and_softmax(self, data, do_mirroring=True, mirror_axes=None,
+                                                         use_sliding_window=True, step_size=0.5, use_gaussian=True,
+                                                         pad_border_mode='constant', pad_kwargs=None, all_in_gpu=False,
+                                                         verbose=True, mixed_precision=True):
+        """Upstream nnUNetTrainer method the reference calls at predict.py:208-219 and through ``validate``
+        (MH.py:1115): tiled prediction of one preprocessed case with the CURRENT head -> (segmentation, softmax)."""
+        from ....inference import predict_3D
+        assert pad_border_mode == 'constant', "the reference only uses constant (zero) padding here"
+        if mirror_axes is None:
+            mirror_axes = (0, 1, 2)
+        return predict_3D(self.network, data, do_mirroring=do_mirroring, mirror_axes=tuple(mirror_axes),
+                          use_sliding_window=use_sliding_window, step_size=step_size, patch_size=tuple(self.plans["patch_size"]),
+                          use_gaussian=use_gaussian, verbose=verbose)
+
     def save_checkpoint(self, fname=None, save_optimizer=True):
         """MH.py:1164-1197: the whole MultiHead_Module state (model + heads + body) + optimiser + scaler."""
         ckpt = {"state_dict": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.mh_network.state_dict().items()),
