@@ -145,7 +145,13 @@ int lnn_dice_ce_fwd(lnn_stream_t s, const float* logits, const float* labels, in
                     int batch_dice, float smooth, float* out_loss, double* ws);
 int lnn_dice_ce_bwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
                     int batch_dice, float smooth, const double* ws, float gscale, const float* gscale_dev,
-                    float* dlogits);  /* gscale_dev (may be NULL): one device float multiplied into gscale */
+                    float dice_scale, float* dlogits);
+/* gscale_dev (may be NULL): one device float multiplied into gscale.  dice_scale multiplies the Dice part only.
+ * Data-parallel batch Dice: the first N*K*3 doubles of ws (tp/fp/fn) are all-reduced (sum) by the
+ * caller between fwd and bwd, the loss is recomputed with lnn_dice_ce_loss_from_totals, and dice_scale = world size
+ * (the Dice term is global, its gradient w.r.t. the local logits must survive the 1/world of the gradient average). */
+int lnn_dice_ce_loss_from_totals(lnn_stream_t s, const double* ws, int N, int K, long V, int batch_dice, float smooth,
+                                 float* out_loss);
 size_t lnn_dice_ce_ws_doubles(int N, int K);
 
 /* argmax + per-sample hard TP/FP/FN for the foreground classes (nnUNetTrainerMultiHead.py:938-951).

@@ -168,6 +168,31 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
     }
 }
 
+// loss from the totals in ws ([N][K][3] tp/fp/fn, then the CE sum): -mean_{(n,)k>=1} dice + CE mean
+__device__ void dice_ce_loss_from_totals(const double* ws, int N, int K, long V, int batch_dice, float smooth, float* out) {
+    double dc_sum = 0;
+    int cnt = 0;
+    if (batch_dice) {
+        for (int k = 1; k < K; ++k) {
+            double tp = 0, fp = 0, fn = 0;
+            for (int n = 0; n < N; ++n) {
+                tp += ws[((long)n * K + k) * 3]; fp += ws[((long)n * K + k) * 3 + 1]; fn += ws[((long)n * K + k) * 3 + 2];
+            }
+            dc_sum += (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8);
+            ++cnt;
+        }
+    } else {
+        for (int n = 0; n < N; ++n)
+            for (int k = 1; k < K; ++k) {
+                const double tp = ws[((long)n * K + k) * 3], fp = ws[((long)n * K + k) * 3 + 1], fn = ws[((long)n * K + k) * 3 + 2];
+                dc_sum += (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8);
+                ++cnt;
+            }
+    }
+    const double ce = ws[(long)N * K * 3] / ((double)N * (double)V);
+    out[0] = (float)(ce - dc_sum / (cnt > 0 ? cnt : 1));
+}
+
 // one 256-thread block: totals of the per-block partials (fp64), then the loss
 __global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nblk, int N, int K, long V, int batch_dice,
                                                               float smooth, float* out) {
@@ -194,33 +219,18 @@ __global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nb
         }
     if (threadIdx.x != 0) return;
     ws[(long)N * K * 3] = ce_sum;
-    double dc_sum = 0;
-    int cnt = 0;
-    if (batch_dice) {
-        for (int k = 1; k < K; ++k) {
-            double tp = 0, fp = 0, fn = 0;
-            for (int n = 0; n < N; ++n) {
-                tp += ws[((long)n * K + k) * 3]; fp += ws[((long)n * K + k) * 3 + 1]; fn += ws[((long)n * K + k) * 3 + 2];
-            }
-            dc_sum += (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8);
-            ++cnt;
-        }
-    } else {
-        for (int n = 0; n < N; ++n)
-            for (int k = 1; k < K; ++k) {
-                const double tp = ws[((long)n * K + k) * 3], fp = ws[((long)n * K + k) * 3 + 1], fn = ws[((long)n * K + k) * 3 + 2];
-                dc_sum += (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8);
-                ++cnt;
-            }
-    }
-    const double ce = ws[(long)N * K * 3] / ((double)N * (double)V);
-    out[0] = (float)(ce - dc_sum / (cnt > 0 ? cnt : 1));
+    dice_ce_loss_from_totals(ws, N, K, V, batch_dice, smooth, out);
+}
+
+// the loss again after the caller changed the totals (data-parallel batch Dice: tp/fp/fn summed over the ranks)
+__global__ void dice_ce_from_totals_kernel(const double* ws, int N, int K, long V, int batch_dice, float smooth, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) dice_ce_loss_from_totals(ws, N, K, V, batch_dice, smooth, out);
 }
 
 __global__ __launch_bounds__(NT) void dice_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                          int N, int K, long V, int batch_dice, float smooth,
                                                          const double* __restrict__ ws, float gscale,
-                                                         const float* __restrict__ gscale_dev,
+                                                         const float* __restrict__ gscale_dev, float dice_scale,
                                                          float* __restrict__ dlogits) {
     __shared__ float al[KMAX], be[KMAX];
     if (gscale_dev) gscale *= gscale_dev[0];
@@ -239,8 +249,8 @@ __global__ __launch_bounds__(NT) void dice_ce_bwd_kernel(const float* __restrict
             }
             const double cnt = batch_dice ? (double)(K - 1) : (double)N * (K - 1);
             const double num = 2 * tp + smooth, den = 2 * tp + fp + fn + smooth + 1e-8;
-            a = (float)(-2.0 / (cnt * den));
-            b = (float)(num / (cnt * den * den));
+            a = (float)(-2.0 / (cnt * den)) * dice_scale;
+            b = (float)(num / (cnt * den * den)) * dice_scale;
         }
         al[k] = a; be[k] = b;
     }
@@ -424,14 +434,24 @@ extern "C" int lnn_dice_ce_fwd(lnn_stream_t s_, const float* logits, const float
     return LNN_OK;
 }
 
+extern "C" int lnn_dice_ce_loss_from_totals(lnn_stream_t s_, const double* ws, int N, int K, long V, int batch_dice, float smooth,
+                                            float* out_loss) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(ws && out_loss, "lnn_dice_ce_loss_from_totals: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_loss_from_totals: K=%d unsupported (2..%d)", K, KMAX);
+    hipLaunchKernelGGL(dice_ce_from_totals_kernel, dim3(1), dim3(64), 0, s, ws, N, K, V, batch_dice, smooth, out_loss);
+    LNN_CHECK_LAUNCH("lnn_dice_ce_loss_from_totals");
+    return LNN_OK;
+}
+
 extern "C" int lnn_dice_ce_bwd(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
-                               int batch_dice, float smooth, const double* ws, float gscale, const float* gscale_dev,
+                               int batch_dice, float smooth, const double* ws, float gscale, const float* gscale_dev, float dice_scale,
                                float* dlogits) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(logits && labels && dlogits && ws, "lnn_dice_ce_bwd: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_bwd: K=%d unsupported (2..%d)", K, KMAX);
     hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, N, K, V, batch_dice,
-                       smooth, ws, gscale, gscale_dev, dlogits);
+                       smooth, ws, gscale, gscale_dev, dice_scale, dlogits);
     LNN_CHECK_LAUNCH("lnn_dice_ce_bwd");
     return LNN_OK;
 }

@@ -27,6 +27,16 @@ def ds_loss_weights(net_numpool: int) -> np.ndarray:
     return weights / weights.sum()
 
 
+def _world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_reduce_sum(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 class _DiceCEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, batch_dice, smooth):
@@ -37,17 +47,26 @@ class _DiceCEFunction(torch.autograd.Function):
         ws = torch.empty(nat.query("lnn_dice_ce_ws_doubles", N, K), dtype=torch.float64, device=logits.device)
         out = torch.empty(1, device=logits.device)
         nat.call("lnn_dice_ce_fwd", logits, labels, N, K, V, int(batch_dice), float(smooth), out, ws)
+        world = 1
+        if batch_dice:
+            # with batch Dice the tp/fp/fn sums run over the GLOBAL batch: one small all-reduce inside
+            # the loss forward; the same global sums are reused by backward
+            world = _world_size()
+            if world > 1:
+                _all_reduce_sum(ws[:N * K * 3])
+                nat.call("lnn_dice_ce_loss_from_totals", ws, N, K, V, 1, float(smooth), out)
         ctx.save_for_backward(logits, labels, ws)
-        ctx.cfg = (N, K, V, int(batch_dice), float(smooth))
+        ctx.cfg = (N, K, V, int(batch_dice), float(smooth), float(world))
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
         logits, labels, ws = ctx.saved_tensors
-        N, K, V, bd, smooth = ctx.cfg
+        N, K, V, bd, smooth, world = ctx.cfg
         dl = torch.empty_like(logits)
-        # the upstream scalar gradient (deep-supervision weight x loss scale) rides in as gscale
-        nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, bd, smooth, ws, 1.0, g.reshape(1).float().contiguous(), dl)
+        # the upstream scalar gradient (deep-supervision weight x loss scale) rides in as gscale; the global Dice term's
+        # gradient is scaled by the world size because the gradient all-reduce averages over the ranks
+        nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, bd, smooth, ws, 1.0, g.reshape(1).float().contiguous(), world, dl)
         return dl, None, None, None
 
 

@@ -123,7 +123,7 @@ def test_dice_ce_shift_invariance_and_gradient_sum():
     out1, out2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
     nat.call("lnn_dice_ce_fwd", logits, labels, N, K, V, 0, 1e-5, out1, ws)
     dl = torch.empty_like(logits)
-    nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, 0, 1e-5, ws, 1.0, None, dl)
+    nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, 0, 1e-5, ws, 1.0, None, 1.0, dl)
     shift = torch.randn((N, 1, V), generator=g, device=DEV)
     ws2 = torch.zeros_like(ws)
     nat.call("lnn_dice_ce_fwd", (logits + shift).contiguous(), labels, N, K, V, 0, 1e-5, out2, ws2)

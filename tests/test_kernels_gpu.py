@@ -218,7 +218,7 @@ def test_dice_ce_fwd_bwd(N, K, V3, batch_dice):
     nat.call("lnn_dice_ce_fwd", lg, lb, N, K, V, batch_dice, 1e-5, out, ws)
     assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))       # north_star: 1e-4 relative loss
     dl = torch.zeros_like(lg)
-    nat.call("lnn_dice_ce_bwd", lg, lb, N, K, V, batch_dice, 1e-5, ws, 1.5, torch.full((1,), 2.0, device=DEV), dl)
+    nat.call("lnn_dice_ce_bwd", lg, lb, N, K, V, batch_dice, 1e-5, ws, 1.5, torch.full((1,), 2.0, device=DEV), 1.0, dl)
     assert rel_err(dl.cpu(), 3.0 * logits.grad) < 1e-4
 
 
@@ -335,3 +335,38 @@ def test_batched_pack_unpack_match_per_layer():
     nat.call("lnn_unpack_wgrad_batched", torch.cat(panels), grad, torch.tensor(desc, dtype=torch.int64, device=DEV),
              len(layers), first, 2.0, 1)
     assert torch.equal(grad, torch.cat(refs))
+
+
+def test_batch_dice_data_parallel_exchange_equals_full_batch():
+    """batch Dice under data parallelism = all-reduce of tp/fp/fn inside the loss.  Two "ranks" are
+    emulated in one process (the all-reduce is the sum of the two workspaces' totals): mean of the rank losses ==
+    full-batch loss, and rank gradient / world == the full-batch gradient of the same samples."""
+    N, K, V, W = 4, 3, 6 * 8 * 6, 2
+    g = torch.Generator().manual_seed(21)
+    logits = (torch.randn((N, K, V), generator=g) * 2).to(DEV)
+    labels = torch.randint(0, K, (N, 1, V), generator=g).float().to(DEV)
+    nws = nat.query("lnn_dice_ce_ws_doubles", N, K)
+    ws, out = torch.zeros(nws, dtype=torch.float64, device=DEV), torch.zeros(1, device=DEV)
+    nat.call("lnn_dice_ce_fwd", logits, labels, N, K, V, 1, 1e-5, out, ws)
+    full_loss = float(out)
+    dfull = torch.empty_like(logits)
+    nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, 1, 1e-5, ws, 1.0, None, 1.0, dfull)
+    Nr = N // W
+    wss, lgs, lbs = [], [], []
+    for r in range(W):
+        lgs.append(logits[r * Nr:(r + 1) * Nr].contiguous()); lbs.append(labels[r * Nr:(r + 1) * Nr].contiguous())
+        w_r = torch.zeros(nat.query("lnn_dice_ce_ws_doubles", Nr, K), dtype=torch.float64, device=DEV)
+        nat.call("lnn_dice_ce_fwd", lgs[r], lbs[r], Nr, K, V, 1, 1e-5, out, w_r)
+        wss.append(w_r)
+    tot = wss[0][:Nr * K * 3] + wss[1][:Nr * K * 3]                    # dist.all_reduce(ws[:N*K*3], SUM)
+    losses, grads = [], []
+    for r in range(W):
+        wss[r][:Nr * K * 3] = tot
+        nat.call("lnn_dice_ce_loss_from_totals", wss[r], Nr, K, V, 1, 1e-5, out)
+        losses.append(float(out))
+        d = torch.empty_like(lgs[r])
+        nat.call("lnn_dice_ce_bwd", lgs[r], lbs[r], Nr, K, V, 1, 1e-5, wss[r], 1.0, None, float(W), d)
+        grads.append(d / W)                                            # the 1/world of the gradient average
+    assert abs(sum(losses) / W - full_loss) <= 1e-6 * abs(full_loss)
+    got = torch.cat(grads)
+    assert float((got - dfull).abs().max()) <= 1e-6 * float(dfull.abs().max())

@@ -13,6 +13,7 @@ LAYERS = {  # name: (N, C, K, D, H, W, stride)
     "dec4.0": (2, 64, 32, 160, 192, 160, 1), "enc0.1": (2, 32, 32, 160, 192, 160, 1),
     "dec3.0": (2, 128, 64, 80, 96, 80, 1), "enc1.1": (2, 64, 64, 80, 96, 80, 1),
     "dec2.0": (2, 256, 128, 40, 48, 40, 1), "enc3.1": (2, 256, 256, 20, 24, 20, 1),
+    "dec4.0half": (2, 64, 32, 80, 96, 80, 1), "enc0.1half": (2, 32, 32, 80, 96, 80, 1),   # same layers, 1/8 of the voxels (fit the MALL)
     "enc1.0s2": (2, 32, 64, 160, 192, 160, 2), "enc2.0s2": (2, 64, 128, 80, 96, 80, 2),
 }
 UPS = {  # transposed conv k2s2: name: (N, C, K, D, H, W) (low-res extents)
