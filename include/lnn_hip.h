@@ -132,7 +132,10 @@ size_t lnn_instnorm_ws_doubles(int N, int C);
 int lnn_seg1x1_fwd(lnn_stream_t s, const void* z_h, int ld_z, const float* w, float* logits, int N, long V,
                    int C, int K);
 int lnn_seg1x1_bwd(lnn_stream_t s, const void* z_h, int ld_z, const float* w, const float* dlogits, void* dz_h,
-                   int ld_dz, float* dw, int N, long V, int C, int K, int accumulate_dz, float grad_unscale);
+                   int ld_dz, float* dw, int N, long V, int C, int K, int accumulate_dz, float grad_unscale, float* ws);
+/* ws: >= lnn_seg1x1_bwd_ws_floats(N, C) floats of scratch for the per-block dw partials (summed by a small finalize
+ * launch), or NULL: fp32 atomics straight into dw (slower: ~2000 blocks contend for K*C addresses). */
+size_t lnn_seg1x1_bwd_ws_floats(int N, int C);
 
 /* ------------------------------------------------------------------------------------------------
  * DC_and_CE_loss({'batch_dice','smooth':1e-5,'do_bg':False},{}) for ONE deep-supervision level

@@ -41,7 +41,7 @@ template <int KG>
 __global__ __launch_bounds__(NT) void seg_bwd_kernel(const half_t* __restrict__ z, int ld_z, const float* __restrict__ w,
                                                      const float* __restrict__ dl, half_t* __restrict__ dz, int ld_dz,
                                                      float* __restrict__ dw, long V, int C, int K, int k0, int write_dz,
-                                                     int accumulate_dz, float unscale) {
+                                                     int accumulate_dz, float unscale, float* __restrict__ pws) {
     __shared__ float red[NT * (KG * 8 + 1)];
     const int C8 = C >> 3, VPB = NT / C8, c8 = threadIdx.x % C8, vl = threadIdx.x / C8;
     const bool active = vl < VPB;
@@ -106,7 +106,28 @@ __global__ __launch_bounds__(NT) void seg_bwd_kernel(const half_t* __restrict__ 
         if (k0 + k >= K) continue;
         float s = 0.f;
         for (int l = 0; l < VPB; ++l) s += red[(l * C8 + (c >> 3)) * W + k * 8 + (c & 7)];
-        atomicAdd(dw + (long)(k0 + k) * C + c, s * unscale);
+        // per-block partial (summed by seg_bwd_finalize_kernel): ~2000 blocks adding to the same K*C addresses
+        // serialise in L2; the atomic path remains for callers without a workspace
+        if (pws) pws[((long)blockIdx.y * gridDim.x + blockIdx.x) * KMAX * C + (long)(k0 + k) * C + c] = s;
+        else atomicAdd(dw + (long)(k0 + k) * C + c, s * unscale);
+    }
+}
+
+// dw[k][c] += unscale * sum over the nblk * N block partials; one thread block per 16 (k, c) entries
+__global__ void seg_bwd_finalize_kernel(const float* __restrict__ pws, int nparts, int K, int C, float* __restrict__ dw,
+                                        float unscale) {
+    __shared__ double red[256];
+    const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + ii;                // entry k * C + c
+    double s = 0;
+    if (i < K * C)
+        for (int b = sl; b < nparts; b += 16) s += (double)pws[(long)b * KMAX * C + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && i < K * C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + ii];
+        dw[i] += (float)(s * unscale);
     }
 }
 
@@ -400,8 +421,11 @@ extern "C" int lnn_seg1x1_fwd(lnn_stream_t s_, const void* z, int ld_z, const fl
     return LNN_OK;
 }
 
+extern "C" size_t lnn_seg1x1_bwd_ws_floats(int N, int C) { return (size_t)N * 1024 * KMAX * C; }
+
 extern "C" int lnn_seg1x1_bwd(lnn_stream_t s_, const void* z, int ld_z, const float* w, const float* dlogits, void* dz,
-                              int ld_dz, float* dw, int N, long V, int C, int K, int accumulate_dz, float grad_unscale) {
+                              int ld_dz, float* dw, int N, long V, int C, int K, int accumulate_dz, float grad_unscale,
+                              float* ws) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(z && lnn_aligned16(z) && w && dlogits && dz && lnn_aligned16(dz) && dw, "lnn_seg1x1_bwd: null/misaligned pointer");
     LNN_REQUIRE(C % 8 == 0 && C <= 2048 && ld_z >= C && ld_z % 8 == 0 && ld_dz >= C && ld_dz % 8 == 0, "lnn_seg1x1_bwd: bad channel count / ld");
@@ -412,8 +436,12 @@ extern "C" int lnn_seg1x1_bwd(lnn_stream_t s_, const void* z, int ld_z, const fl
     if (b < 1) b = 1;
     for (int k0 = 0; k0 < K; k0 += 4) {
         hipLaunchKernelGGL((seg_bwd_kernel<4>), dim3((int)b, N), dim3(NT), 0, s, (const half_t*)z, ld_z, w, dlogits,
-                           (half_t*)dz, ld_dz, dw, V, C, K, k0, k0 == 0 ? 1 : 0, accumulate_dz, grad_unscale);
+                           (half_t*)dz, ld_dz, dw, V, C, K, k0, k0 == 0 ? 1 : 0, accumulate_dz, grad_unscale, ws);
         LNN_CHECK_LAUNCH("lnn_seg1x1_bwd");
+    }
+    if (ws) {
+        hipLaunchKernelGGL(seg_bwd_finalize_kernel, dim3(lnn_cdiv(K * C, 16)), dim3(256), 0, s, ws, (int)b * N, K, C, dw, grad_unscale);
+        LNN_CHECK_LAUNCH("lnn_seg1x1_bwd(finalize)");
     }
     return LNN_OK;
 }

@@ -312,7 +312,8 @@ class UNetEngine:
         self._unpack_desc = torch.tensor(up, dtype=torch.int64, device=dev)
         self._pack_total, self._unpack_total = pk_total, up_total
         cmax = max(2 * f for f in feats)
-        self.ws = torch.zeros(max(nat.query("lnn_instnorm_ws_doubles", N, cmax), 64), dtype=torch.float64, device=dev)
+        ws_doubles = max(nat.query("lnn_instnorm_ws_doubles", N, cmax), (nat.query("lnn_seg1x1_bwd_ws_floats", N, cmax) + 1) // 2, 64)
+        self.ws = torch.zeros(ws_doubles, dtype=torch.float64, device=dev)
         self.packed_version = -1
         self.unused_heads: List[str] = []
         self._side = None
@@ -494,7 +495,7 @@ class UNetEngine:
                         continue
                     gw = self.pview(item.w, self.grad).view(self.K, item.cin)
                     nat.call("lnn_seg1x1_bwd", at(item.x, n0), item.x.ld, self.pview(item.w), dl[n0:], at(item.gx, n0),
-                             item.gx.ld, gw, nn, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0)
+                             item.gx.ld, gw, nn, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0, ws)
                 elif skip_body:
                     continue
                 elif isinstance(item, ConvBlock):

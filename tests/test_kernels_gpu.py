@@ -195,7 +195,11 @@ def test_seg1x1_fwd_bwd(N, C, K, V3):
     base = _rand((N, C) + V3, 7)
     dzb, _ = to_cl_h(base)
     dw = torch.zeros((K, C), device=DEV)
-    nat.call("lnn_seg1x1_bwd", zb, C, wd, dl.to(DEV), dzb, C, dw, N, V, C, K, 1, 2.0)
+    dw2, dzb2 = dw.clone(), dzb.clone()
+    nat.call("lnn_seg1x1_bwd", zb, C, wd, dl.to(DEV), dzb, C, dw, N, V, C, K, 1, 2.0, None)
+    ws = torch.empty(nat.query("lnn_seg1x1_bwd_ws_floats", N, C), device=DEV)
+    nat.call("lnn_seg1x1_bwd", zb, C, wd, dl.to(DEV), dzb2, C, dw2, N, V, C, K, 1, 2.0, ws)      # workspace path
+    assert torch.allclose(dw2, dw, rtol=1e-5, atol=1e-6) and torch.equal(dzb2, dzb)
     assert rel_err(from_cl_h(dzb, C), z.grad + base) < 3e-3
     assert rel_err(dw.cpu(), 2.0 * w.grad.view(K, C)) < 1e-4
 
