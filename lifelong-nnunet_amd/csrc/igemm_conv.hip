@@ -318,7 +318,12 @@ static unsigned long long* g_dbg = nullptr;
 extern "C" int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64) { g_dbg = (unsigned long long*)dev_ptr_6x_u64; return LNN_OK; }
 
 // LNN_CONV_V1=1 selects the non-pipelined kernel for the stride-1 convs (A/B measurements only)
+// runtime override for the parity tests (lnn_debug_force_conv_kernel): -1 = automatic selection,
+// 1 = generic first version, 5 / 6 / 7 / 8 = that stride-1 kernel for every layer it supports
+int g_force_conv = -1;
+
 bool use_v2() {
+    if (g_force_conv >= 0) return g_force_conv != 1;
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("LNN_CONV_V1");
@@ -330,6 +335,7 @@ bool use_v2() {
 // LNN_CONV_V6=1 selects the ping-pong v6 kernel instead of v5 (A/B measurements only; v6 measured 5-15 % slower:
 // a lone wave per SIMD does not keep the matrix pipe busy through its LDS read latencies)
 bool use_v6() {
+    if (g_force_conv >= 0) return g_force_conv == 6;
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("LNN_CONV_V6");
@@ -362,6 +368,7 @@ bool use_down2() {
 // +4..18 % for layers with >= 128 input channels (weights streamed anyway, many short steps), -3..15 % below.
 // LNN_CONV_V7=1 / 0 forces / forbids v7 (A/B measurements).
 bool use_v7(int C) {
+    if (g_force_conv >= 0) return g_force_conv == 7;
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("LNN_CONV_V7");
@@ -374,6 +381,7 @@ bool use_v7(int C) {
 // the (8x8x8 tile x 64 channel) units fill the chip at least twice; below that the 32-channel units of v7 / v5 spread
 // better.  LNN_CONV_V8=1 / 0 forces / forbids it (A/B measurements).
 bool use_v8(const ConvParams& p) {
+    if (g_force_conv >= 0) return g_force_conv == 8 && p.M >= 64;
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("LNN_CONV_V8");
@@ -394,6 +402,12 @@ int check_act(const void* ptr, int ld, int C, const char* what) {
 }
 
 }  // namespace
+
+extern "C" int lnn_debug_force_conv_kernel(int which) {
+    LNN_REQUIRE(which == -1 || which == 1 || (which >= 5 && which <= 8), "lnn_debug_force_conv_kernel: %d is not one of -1, 1, 5, 6, 7, 8", which);
+    g_force_conv = which;
+    return LNN_OK;
+}
 
 extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const void* wp, const float* bias, void* y,
                               int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride) {

@@ -63,6 +63,7 @@ SIGNATURES = {
     "lnn_cast_f32_to_h": (_i, [_p, _p, _p, _l]),
     "lnn_debug_tr16_probe": (_i, [_p, _p]),
     "lnn_debug_set_phase_buffer": (_i, [_p]),
+    "lnn_debug_force_conv_kernel": (_i, [_i]),
 }
 
 _lib = None

@@ -374,3 +374,19 @@ def test_batch_dice_data_parallel_exchange_equals_full_batch():
     assert abs(sum(losses) / W - full_loss) <= 1e-6 * abs(full_loss)
     got = torch.cat(grads)
     assert float((got - dfull).abs().max()) <= 1e-6 * float(dfull.abs().max())
+
+
+@pytest.mark.parametrize("which", [1, 5, 6, 7, 8])
+def test_every_stride1_conv_kernel_variant(which):
+    """The automatic selection picks v5 / v7 / v8 by layer shape, so the small parity shapes above only exercise v5:
+    pin each shipped stride-1 kernel in turn and run forward + dgrad (with and without accumulation) on all
+    stride-1 cases, including ragged extents and output channels that are not a multiple of 64."""
+    cases = [c for c in CONV_CASES if c[6] == 1] + [(1, 32, 96, 9, 8, 17, 1), (2, 128, 64, 8, 8, 8, 1), (1, 24, 160, 5, 6, 7, 1)]
+    assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
+    try:
+        for (N, C, K, D, H, W, s) in cases:
+            test_conv3d_fwd(N, C, K, D, H, W, s)
+            for acc in (0, 1):
+                test_conv3d_dgrad(N, C, K, D, H, W, s, acc)
+    finally:
+        nat.lib().lnn_debug_force_conv_kernel(-1)
