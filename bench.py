@@ -70,15 +70,23 @@ def kernel_rooflines(trainer):
     N, (D, H, W), C, K = eng.N, blk.in_dims, blk.cin, blk.cout
     flops = 2.0 * N * blk.z.V * C * K * 27
     res = {}
-    t = time_kernel(lambda: nat.call("lnn_conv3d_fwd", blk.x, blk.x.ld, eng._wp(blk.wp_fwd), eng.pview(blk.b), blk.y, K,
-                                     N, D, H, W, C, K, blk.stride))
-    res["igemm_conv_fwd"] = (flops, t)
-    t = time_kernel(lambda: nat.call("lnn_conv3d_dgrad", blk.y, K, eng._wp(blk.wp_dgrad), blk.gx, blk.gx.ld, N, D, H, W,
-                                     C, K, blk.stride, 0))
-    res["igemm_conv_dgrad"] = (flops, t)
-    t = time_kernel(lambda: nat.call("lnn_conv3d_wgrad", blk.x, blk.x.ld, blk.y, K, eng._pn(blk.panel), N, D, H, W, C, K,
-                                     blk.stride))
-    res["igemm_wgrad"] = (flops, t)
+    if blk.x2 is not None:      # the engine keeps the two halves of the top-level concatenation as separate tensors
+        fwd = lambda: nat.call("lnn_conv3d_fwd_cat", blk.x, blk.x2, blk.x.ld, blk.x.C, eng._wp(blk.wp_fwd), eng.pview(blk.b),
+                               blk.y, K, N, D, H, W, C, K)
+        dgrad = lambda: nat.call("lnn_conv3d_dgrad_cat", blk.y, K, eng._wp(blk.wp_dgrad), blk.gx, blk.gx2, blk.gx.ld, blk.gx.C,
+                                 N, D, H, W, C, K, 0)
+        wgrad = lambda: nat.call("lnn_conv3d_wgrad_cat", blk.x, blk.x2, blk.x.ld, blk.x.C, blk.y, K, eng._pn(blk.panel),
+                                 N, D, H, W, C, K)
+    else:
+        fwd = lambda: nat.call("lnn_conv3d_fwd", blk.x, blk.x.ld, eng._wp(blk.wp_fwd), eng.pview(blk.b), blk.y, K,
+                               N, D, H, W, C, K, blk.stride)
+        dgrad = lambda: nat.call("lnn_conv3d_dgrad", blk.y, K, eng._wp(blk.wp_dgrad), blk.gx, blk.gx.ld, N, D, H, W,
+                                 C, K, blk.stride, 0)
+        wgrad = lambda: nat.call("lnn_conv3d_wgrad", blk.x, blk.x.ld, blk.y, K, eng._pn(blk.panel), N, D, H, W, C, K,
+                                 blk.stride)
+    res["igemm_conv_fwd"] = (flops, time_kernel(fwd))
+    res["igemm_conv_dgrad"] = (flops, time_kernel(dgrad))
+    res["igemm_wgrad"] = (flops, time_kernel(wgrad))
     return {"layer": f"{blk.prefix} {C}->{K} @{D}x{H}x{W} N={N}",
             "kernels": {k: {"tflops": f / t / 1e12, "ms": t * 1e3, "gflop": f / 1e9} for k, (f, t) in res.items()}}
 

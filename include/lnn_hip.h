@@ -79,6 +79,19 @@ int lnn_conv3d_dgrad(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp
                      int N, int Di, int Hi, int Wi, int C, int K, int stride, int accumulate);
 int lnn_conv3d_wgrad(lnn_stream_t s, const void* x_h, int ld_x, const void* dy_h, int ld_dy, float* dwp,
                      int N, int Di, int Hi, int Wi, int C, int K, int stride);
+/* The same three ops (stride 1) on the CHANNEL CONCATENATION of two tensors that is never materialised
+ * (torch.cat((up, skip), dim=1) at generic_ViT_UNet.py:263 in front of the first decoder conv of a level):
+ *   x = cat(x_a[..., :c_a], x_b[..., :C - c_a]),  dx_a / dx_b receive the matching channel ranges of dx.
+ * Both parts share one channel stride (ld_x / ld_dx); c_a is a multiple of 32.  Why: with both halves interleaved in
+ * one (N,D,H,W,2c) buffer every 16-channel chunk step touches all 128-byte positions of the tile, 32 CUs x 128 KB of
+ * lines is an XCD's whole L2 and the top decoder conv fetched 5.9 GB for a 1.26 GB input (profiles/r01_pmc_traffic.json);
+ * as two 64-byte-per-voxel tensors the live set halves and the chunk pairs share their lines. */
+int lnn_conv3d_fwd_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int ld_x, int c_a, const void* wp_fwd_h,
+                       const float* bias, void* y_h, int ld_y, int N, int Di, int Hi, int Wi, int C, int K);
+int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp_dgrad_h, void* dx_a_h, void* dx_b_h,
+                         int ld_dx, int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate);
+int lnn_conv3d_wgrad_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int ld_x, int c_a, const void* dy_h, int ld_dy,
+                         float* dwp, int N, int Di, int Hi, int Wi, int C, int K);
 
 /* ------------------------------------------------------------------------------------------------
  * nn.ConvTranspose3d kernel 2, stride 2, no bias (`tu`, convolutional_upsampling=True

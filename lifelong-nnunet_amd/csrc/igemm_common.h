@@ -11,6 +11,9 @@ struct TapTable {
 
 struct ConvParams {
     const half_t* x;
+    const half_t* x2;          // second input tensor of a channel concatenation (channels >= csplit), same ld_x
+    half_t* y2;                // second output tensor (channels >= msplit), same ld_y
+    int csplit = 0x7fffffff, msplit = 0x7fffffff;   // "never": a single tensor
     const half_t* wp;
     const float* bias;
     half_t* y;

@@ -409,8 +409,9 @@ extern "C" int lnn_debug_force_conv_kernel(int which) {
     return LNN_OK;
 }
 
-extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const void* wp, const float* bias, void* y,
-                              int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride) {
+namespace {
+int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int ld_x, const void* wp, const float* bias, void* y,
+                    int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_fwd: stride %d unsupported", stride);
     LNN_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0, "lnn_conv3d_fwd: bad dims");
@@ -419,6 +420,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
     if (int e = check_act(y, ld_y, K, "lnn_conv3d_fwd(y)")) return e;
     ConvParams p{};
     p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.bias = bias; p.y = (half_t*)y;
+    if (x2) { p.x2 = (const half_t*)x2; p.csplit = c_a; }
     p.ld_x = ld_x; p.ld_y = ld_y; p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
     p.Do = (Di - 1) / stride + 1; p.Ho = (Hi - 1) / stride + 1; p.Wo = (Wi - 1) / stride + 1;
     p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32); p.wtaps = C == 1 ? 1 : 27;
@@ -433,7 +435,7 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
         LNN_CHECK_LAUNCH("lnn_conv3d_fwd(C=1)");
         return LNN_OK;
     }
-    if (int e = check_act(x, ld_x, C, "lnn_conv3d_fwd(x)")) return e;
+    if (int e = check_act(x, ld_x, x2 ? c_a : C, "lnn_conv3d_fwd(x)")) return e;
     p.KCpad = lnn_round_up(C, 16);
     p.taps.ntaps = 27;
     if (stride == 1) {
@@ -461,15 +463,38 @@ extern "C" int lnn_conv3d_fwd(lnn_stream_t s_, const void* x, int ld_x, const vo
     }
 }
 
-extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N,
-                                int Di, int Hi, int Wi, int C, int K, int stride, int accumulate) {
+int check_cat(const void* b, int c_a, int C, int stride, const char* what) {
+    LNN_REQUIRE(b != nullptr && lnn_aligned16(b), "%s: second tensor null/misaligned", what);
+    LNN_REQUIRE(stride == 1, "%s: stride 1 only", what);
+    LNN_REQUIRE(c_a > 0 && c_a < C && c_a % 32 == 0 && (C - c_a) % 8 == 0, "%s: split %d of %d channels must be a multiple of 32", what, c_a, C);
+    LNN_REQUIRE(use_v2() && !use_v6(), "%s: not supported by the generic first-version / v6 kernels (forced kernel 1 / 6)", what);
+    return LNN_OK;
+}
+}  // namespace
+
+extern "C" int lnn_conv3d_fwd(lnn_stream_t s, const void* x, int ld_x, const void* wp, const float* bias, void* y,
+                              int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride) {
+    return conv3d_fwd_impl(s, x, nullptr, 0, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, stride);
+}
+
+extern "C" int lnn_conv3d_fwd_cat(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
+                                  const float* bias, void* y, int ld_y, int N, int Di, int Hi, int Wi, int C, int K) {
+    if (int e = check_cat(x_b, c_a, C, 1, "lnn_conv3d_fwd_cat")) return e;
+    LNN_REQUIRE(ld_x >= c_a && ld_x >= C - c_a, "lnn_conv3d_fwd_cat: ld_x %d smaller than a part (%d / %d)", ld_x, c_a, C - c_a);
+    return conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, 1);
+}
+
+namespace {
+int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, void* dx2, int c_a, int ld_dx, int N,
+                      int Di, int Hi, int Wi, int C, int K, int stride, int accumulate) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_dgrad: stride %d unsupported", stride);
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_conv3d_dgrad: weight panel null/misaligned");
     if (int e = check_act(dy, ld_dy, K, "lnn_conv3d_dgrad(dy)")) return e;
-    if (int e = check_act(dx, ld_dx, C, "lnn_conv3d_dgrad(dx)")) return e;
+    if (int e = check_act(dx, ld_dx, dx2 ? c_a : C, "lnn_conv3d_dgrad(dx)")) return e;
     const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     ConvParams p{};
+    if (dx2) { p.y2 = (half_t*)dx2; p.msplit = c_a; }
     // roles: gathered input = dy (K channels), output = dx (C channels); panel wp[slot][C][K]
     p.x = (const half_t*)dy; p.wp = (const half_t*)wp; p.bias = nullptr; p.y = (half_t*)dx;
     p.ld_x = ld_dy; p.ld_y = ld_dx; p.N = N; p.Di = Do; p.Hi = Ho; p.Wi = Wo; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
@@ -517,6 +542,19 @@ extern "C" int lnn_conv3d_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, cons
         rc = dispatch_ck_mt<1, 2, 4, 8>(s, q, "lnn_conv3d_dgrad(s2)");
     }
     return rc;
+}
+}  // namespace
+
+extern "C" int lnn_conv3d_dgrad(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N,
+                                int Di, int Hi, int Wi, int C, int K, int stride, int accumulate) {
+    return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, stride, accumulate);
+}
+
+extern "C" int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx_a, void* dx_b, int ld_dx,
+                                    int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate) {
+    if (int e = check_cat(dx_b, c_a, C, 1, "lnn_conv3d_dgrad_cat")) return e;
+    LNN_REQUIRE(ld_dx >= c_a && ld_dx >= C - c_a, "lnn_conv3d_dgrad_cat: ld_dx %d smaller than a part (%d / %d)", ld_dx, c_a, C - c_a);
+    return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx_a, dx_b, c_a, ld_dx, N, Di, Hi, Wi, C, K, 1, accumulate);
 }
 
 extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s_, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N,

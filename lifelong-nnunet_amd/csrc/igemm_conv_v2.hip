@@ -126,9 +126,12 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v5_kernel(const ConvParam
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     auto load_x = [&](const Step& t) {
-        const long base = ((((long)t.n * p.Di + (t.lz0 - 1)) * p.Hi + (t.ly0 - 1)) * p.Wi + (t.lx0 - 1)) * p.ld_x + t.c0;
+        // channel concatenation of two tensors (lnn_conv3d_*_cat): chunks below csplit come from x, the rest from x2
+        const bool part2 = t.c0 >= p.csplit;
+        const half_t* const xp = part2 ? p.x2 : p.x;
+        const long base = ((((long)t.n * p.Di + (t.lz0 - 1)) * p.Hi + (t.ly0 - 1)) * p.Wi + (t.lx0 - 1)) * p.ld_x + (part2 ? t.c0 - p.csplit : t.c0);
         if (t.interior) {
-            const half_t* bp = p.x + base;
+            const half_t* bp = xp + base;
 #pragma unroll
             for (int i = 0; i < XN; ++i) xr[i] = *reinterpret_cast<const half8*>(bp + xrel[i]);
             xok = 0xFFFFu;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v5_kernel(const ConvParam
                 const int iz = t.lz0 - 1 + pz, iy = t.ly0 - 1 + py, ix = t.lx0 - 1 + px;
                 const bool ok = (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
                                 t.c0 + c2 * 8 < p.C;
-                xr[i] = *reinterpret_cast<const half8*>(p.x + (ok ? base + xrel[i] : 0));
+                xr[i] = *reinterpret_cast<const half8*>(xp + (ok ? base + xrel[i] : 0));
                 m |= (ok ? 1u : 0u) << i;
             }
             xok = m;
@@ -261,7 +264,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v5_kernel(const ConvParam
             for (int vt = 0; vt < VT; ++vt) {
                 const int lz = cur.lz0 + wave, ly = cur.ly0 + vt * 4 + vr, lx = cur.lx0 + vx;
                 if (lz >= p.Ld || ly >= p.Lh || lx >= p.Lw) continue;
-                half_t* yrow = p.y + ((((long)cur.n * p.Do + lz) * p.Ho + ly) * p.Wo + lx) * p.ld_y;
+                const long yoff = ((((long)cur.n * p.Do + lz) * p.Ho + ly) * p.Wo + lx) * p.ld_y;
+                half_t* yrow = p.y + yoff;
+                half_t* yrow2 = p.y2 + yoff - p.msplit;      // output channels >= msplit go to the second tensor
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int m = cur.m0 + qq * 8 + hk * 4;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v5_kernel(const ConvParam
                         const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + m);
                         r0 += bv[0]; r1 += bv[1]; r2 += bv[2]; r3 += bv[3];
                     }
-                    half4* dst = reinterpret_cast<half4*>(yrow + m);
+                    half4* dst = reinterpret_cast<half4*>((m < p.msplit ? yrow : yrow2) + m);
                     if (p.accumulate) {
                         const half4 old = *dst;
                         r0 += (float)old[0]; r1 += (float)old[1]; r2 += (float)old[2]; r3 += (float)old[3];

@@ -25,6 +25,8 @@ struct WTapTable {
 struct WgradParams {
     const half_t* p;
     const half_t* q;
+    const half_t* q2 = nullptr;       // second tensor of a channel concatenation of Q (channels >= csplit), same ld_q
+    int csplit = 0x7fffffff;
     float* dwp;
     int ld_p, ld_q;
     int N, Ld, Lh, Lw, Qd, Qh, Qw;
@@ -194,6 +196,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
+    // Q = channel concatenation of two tensors (lnn_conv3d_wgrad_cat): this block's 32-channel panel lives in one of them
+    const half_t* const qsrc = c0 >= p.csplit ? p.q2 : p.q;
+    const int cq = c0 >= p.csplit ? c0 - p.csplit : c0;
     const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
     const int chb = (cb + 4 * sq) * 2;                 // byte offset of this lane's 4 channels inside a row
     const int p_addr = (8 * hk + sj) * 64 + chb;       // + ch*1024 (+256 for the second read)
@@ -235,12 +240,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
         const int tz = t % p.tiles_z; t /= p.tiles_z;
         const int n = t;
         const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
-        const long qbase = ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + c0;
+        const long qbase = ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + cq;
         const long pbase = ((((long)n * p.Ld + lz0) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
         const bool interior = lz0 >= 1 && ly0 >= 1 && lx0 >= 1 && lz0 + TZ + 1 <= p.Qd && ly0 + TY + 1 <= p.Qh &&
                               lx0 + TX + 1 <= p.Qw && c0 + 32 <= p.C && m0 + 32 <= p.M;
         if (interior) {
-            const half_t* qp = p.q + qbase;
+            const half_t* qp = qsrc + qbase;
             const half_t* pp = p.p + pbase;
 #pragma unroll
             for (int i = 0; i < QN; ++i) qr[i] = *reinterpret_cast<const half8*>(qp + qrel[i]);
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
                 const int iz = lz0 - 1 + pz, iy = ly0 - 1 + py, ix = lx0 - 1 + px;
                 const bool ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
                                 c0 + c8 * 8 < p.C;
-                qr[i] = *reinterpret_cast<const half8*>(p.q + (ok ? qbase + qrel[i] : 0));
+                qr[i] = *reinterpret_cast<const half8*>(qsrc + (ok ? qbase + qrel[i] : 0));
                 qok |= (ok ? 1u : 0u) << i;
             }
 #pragma unroll
@@ -693,14 +698,16 @@ extern "C" size_t lnn_wgrad_panel_elems(int ntaps, int M, int KC) {
     return (size_t)ntaps * lnn_round_up(M, 32) * lnn_round_up(KC, 32);
 }
 
-extern "C" int lnn_conv3d_wgrad(lnn_stream_t s_, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N,
-                                int Di, int Hi, int Wi, int C, int K, int stride) {
+namespace {
+int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int ld_x, const void* dy, int ld_dy, float* dwp, int N,
+                      int Di, int Hi, int Wi, int C, int K, int stride) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_wgrad: stride %d unsupported", stride);
     LNN_REQUIRE(dwp != nullptr, "lnn_conv3d_wgrad: null panel");
     if (int e = check_act_w(dy, ld_dy, K, "lnn_conv3d_wgrad(dy)")) return e;
     WgradParams p{};
     p.p = (const half_t*)dy; p.q = (const half_t*)x; p.dwp = dwp; p.ld_p = ld_dy; p.ld_q = ld_x;
+    if (x2) { p.q2 = (const half_t*)x2; p.csplit = c_a; }
     p.N = N; p.Qd = Di; p.Qh = Hi; p.Qw = Wi;
     p.Ld = (Di - 1) / stride + 1; p.Lh = (Hi - 1) / stride + 1; p.Lw = (Wi - 1) / stride + 1;
     p.M = K; p.C = C; p.Mpad = lnn_round_up(K, 32); p.Cpad = lnn_round_up(C, 32); p.pad_lo = 1;
@@ -718,7 +725,7 @@ extern "C" int lnn_conv3d_wgrad(lnn_stream_t s_, const void* x, int ld_x, const 
         LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(C=1)");
         return LNN_OK;
     }
-    if (int e = check_act_w(x, ld_x, C, "lnn_conv3d_wgrad(x)")) return e;
+    if (int e = check_act_w(x, ld_x, x2 ? c_a : C, "lnn_conv3d_wgrad(x)")) return e;
     p.taps.ntaps = 27;
     if (stride == 1) {
         constexpr int PY = 10, PX = 10;
@@ -728,6 +735,7 @@ extern "C" int lnn_conv3d_wgrad(lnn_stream_t s_, const void* x, int ld_x, const 
         }
         static int use_v1 = -1;
         if (use_v1 < 0) { const char* e = getenv("LNN_CONV_V1"); use_v1 = (e && e[0] == '1') ? 1 : 0; }
+        LNN_REQUIRE(!(use_v1 && x2), "lnn_conv3d_wgrad_cat: not supported by the generic first-version kernel (LNN_CONV_V1)");
         if (use_v1) return launch_wgrad<1, 3, 4, 8, 7>(s, p, "lnn_conv3d_wgrad(s1)");
         return launch_wgrad_s1_v2(s, p);
     }
@@ -738,6 +746,20 @@ extern "C" int lnn_conv3d_wgrad(lnn_stream_t s_, const void* x, int ld_x, const 
         p.taps.slot[t] = (unsigned char)t;
     }
     return launch_wgrad<2, 3, 2, 4, 7>(s, p, "lnn_conv3d_wgrad(s2)");
+}
+}  // namespace
+
+extern "C" int lnn_conv3d_wgrad(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N,
+                                int Di, int Hi, int Wi, int C, int K, int stride) {
+    return conv3d_wgrad_impl(s, x, nullptr, 0, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, stride);
+}
+
+extern "C" int lnn_conv3d_wgrad_cat(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* dy, int ld_dy,
+                                    float* dwp, int N, int Di, int Hi, int Wi, int C, int K) {
+    LNN_REQUIRE(x_b != nullptr && lnn_aligned16(x_b), "lnn_conv3d_wgrad_cat: second tensor null/misaligned");
+    LNN_REQUIRE(c_a > 0 && c_a < C && c_a % 32 == 0 && (C - c_a) % 8 == 0, "lnn_conv3d_wgrad_cat: split %d of %d channels must be a multiple of 32", c_a, C);
+    LNN_REQUIRE(ld_x >= c_a && ld_x >= C - c_a, "lnn_conv3d_wgrad_cat: ld_x %d smaller than a part (%d / %d)", ld_x, c_a, C - c_a);
+    return conv3d_wgrad_impl(s, x_a, x_b, c_a, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, 1);
 }
 
 extern "C" int lnn_convT3d_k2s2_wgrad(lnn_stream_t s_, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp,

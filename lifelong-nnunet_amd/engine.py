@@ -21,6 +21,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import native as nat
@@ -70,6 +72,8 @@ class ConvBlock:
     x: Optional[Act] = None        # input activation (None -> the fp16 image, C == 1 path)
     gx: Optional[Act] = None       # gradient wrt input (None -> not needed)
     gx_accumulate: bool = False
+    x2: Optional[Act] = None       # second half of a never-materialised channel concatenation (x = cat(x, x2))
+    gx2: Optional[Act] = None
     y: Optional[torch.Tensor] = None
     z: Optional[Act] = None
     gz: Optional[Act] = None
@@ -186,12 +190,23 @@ class UNetEngine:
         dims = [tuple(p // 2 ** d for p in patch_size) for d in range(num_pool + 1)]
         self.feats, self.dims = feats, dims
 
-        # ---- concat buffers (one per decoder level u; level u sits at encoder depth d = num_pool-1-u)
-        self.cat, self.gcat = [], []
+        # ---- concat buffers (one per decoder level u; level u sits at encoder depth d = num_pool-1-u).
+        # torch.cat((up, skip), 1) (generic_ViT_UNet.py:263) is never executed: producers write straight into the two
+        # channel ranges of one (N,D,H,W,2c) buffer -- except where a part is 32 channels = 64 bytes per voxel (the top
+        # level): interleaved, every 16-channel chunk step of the consumer touches all 128-byte positions and an XCD's
+        # L2 (32 CUs x 128 KB of lines) thrashes (5.9 GB fetched for a 1.26 GB input, profiles/r01_pmc_traffic.json);
+        # there the two parts stay SEPARATE tensors and the decoder conv takes both (lnn_conv3d_*_cat).
+        self.cat, self.gcat, self.split_cat = [], [], []
         for u in range(num_pool):
             d = num_pool - 1 - u
-            self.cat.append(_cl(N, dims[d], 2 * feats[d], dev))
-            self.gcat.append(_cl(N, dims[d], 2 * feats[d], dev))
+            split = feats[d] % 32 == 0 and feats[d] * 2 <= 64 and os.environ.get("LNN_NO_SPLIT_CAT", "0") != "1"
+            self.split_cat.append(split)
+            if split:
+                self.cat.append((_cl(N, dims[d], feats[d], dev), _cl(N, dims[d], feats[d], dev)))
+                self.gcat.append((_cl(N, dims[d], feats[d], dev), _cl(N, dims[d], feats[d], dev)))
+            else:
+                self.cat.append(_cl(N, dims[d], 2 * feats[d], dev))
+                self.gcat.append(_cl(N, dims[d], 2 * feats[d], dev))
 
         self.image = torch.zeros((N,) + dims[0], dtype=torch.float16, device=dev)
         self.blocks: List[ConvBlock] = []
@@ -224,8 +239,11 @@ class UNetEngine:
         cin = in_channels
         for d in range(num_pool):
             u = num_pool - 1 - d
-            skip = Act(self.cat[u], feats[d], feats[d])
-            gskip = Act(self.gcat[u], feats[d], feats[d])
+            if self.split_cat[u]:
+                skip, gskip = Act(self.cat[u][1], 0, feats[d]), Act(self.gcat[u][1], 0, feats[d])
+            else:
+                skip = Act(self.cat[u], feats[d], feats[d])
+                gskip = Act(self.gcat[u], feats[d], feats[d])
             in_dims = dims[d - 1] if d > 0 else dims[0]
             b0 = new_block(f"conv_blocks_context.{d}.blocks.0", cin, feats[d], 2 if d > 0 else 1,
                            x, gx, d > 0, None, None, in_dims)
@@ -242,13 +260,20 @@ class UNetEngine:
         for u in range(num_pool):
             d = num_pool - 1 - u
             cs = feats[d]
-            up = UpBlock(f"tu.{u}", cdown, cs, x=x, gx=gx, y=Act(self.cat[u], 0, cs), gy=Act(self.gcat[u], 0, cs))
+            if self.split_cat[u]:
+                up_y, up_gy = Act(self.cat[u][0], 0, cs), Act(self.gcat[u][0], 0, cs)
+                cat_act, gcat_act = up_y, up_gy
+            else:
+                up_y, up_gy = Act(self.cat[u], 0, cs), Act(self.gcat[u], 0, cs)
+                cat_act, gcat_act = Act(self.cat[u], 0, 2 * cs), Act(self.gcat[u], 0, 2 * cs)
+            up = UpBlock(f"tu.{u}", cdown, cs, x=x, gx=gx, y=up_y, gy=up_gy)
             up.w = arena.by_name[f"tu.{u}.weight"]
             self.ups.append(up)
             order.append(up)
-            cat_act, gcat_act = Act(self.cat[u], 0, 2 * cs), Act(self.gcat[u], 0, 2 * cs)
             b0 = new_block(f"conv_blocks_localization.{u}.0.blocks.0", 2 * cs, cs, 1, cat_act, gcat_act, False,
                            None, None, dims[d])
+            if self.split_cat[u]:
+                b0.x2, b0.gx2 = Act(self.cat[u][1], 0, cs), Act(self.gcat[u][1], 0, cs)
             b1 = new_block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, 1, b0.z, b0.gz, False, None, None, dims[d])
             seg = SegHead(f"seg_outputs.{u}", cs, x=b1.z, gx=b1.gz, gx_has_prior=(u < num_pool - 1))
             seg.w = arena.by_name[f"seg_outputs.{u}.weight"]
@@ -318,7 +343,6 @@ class UNetEngine:
         self.unused_heads: List[str] = []
         self._side = None
         self._lstreams, self._lws = [], []
-        import os
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
         # little room), kept because it is the natural hook for per-sample pipelining across GPUs / larger batches
@@ -418,8 +442,12 @@ class UNetEngine:
                     xin = at(self.image, n0) if item.x is None else at(item.x, n0)
                     ldx = 1 if item.x is None else item.x.ld
                     C = item.cout
-                    nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
-                             nn, D, H, W, item.cin, C, item.stride)
+                    if item.x2 is not None:
+                        nat.call("lnn_conv3d_fwd_cat", xin, at(item.x2, n0), ldx, item.x.C, self._wp(item.wp_fwd),
+                                 self.pview(item.b), at(item.y, n0), C, nn, D, H, W, item.cin, C)
+                    else:
+                        nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
+                                 nn, D, H, W, item.cin, C, item.stride)
                     V = item.z.V
                     mean, rstd = item.mean[n0 * C:], item.rstd[n0 * C:]
                     nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
@@ -509,12 +537,19 @@ class UNetEngine:
                     ldx = 1 if item.x is None else item.x.ld
 
                     def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
-                        nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
-                                 item.stride)
+                        if item.x2 is not None:
+                            nat.call("lnn_conv3d_wgrad_cat", xin, at(item.x2, n0), ldx, item.x.C, at(item.y, n0), K,
+                                     self._pn(item.panel), nn, D, H, W, C, K)
+                        else:
+                            nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
+                                     item.stride)
                         if per_layer_unpack:
                             unpack(item)
                     on_side(conv_wgrad)
-                    if C != 1 and item.gx is not None:
+                    if C != 1 and item.gx is not None and item.gx2 is not None:
+                        nat.call("lnn_conv3d_dgrad_cat", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0),
+                                 at(item.gx2, n0), item.gx.ld, item.gx.C, nn, D, H, W, C, K, 1 if item.gx_accumulate else 0)
+                    elif C != 1 and item.gx is not None:
                         nat.call("lnn_conv3d_dgrad", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
                                  nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0)
                 else:  # UpBlock

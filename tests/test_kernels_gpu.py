@@ -390,3 +390,41 @@ def test_every_stride1_conv_kernel_variant(which):
                 test_conv3d_dgrad(N, C, K, D, H, W, s, acc)
     finally:
         nat.lib().lnn_debug_force_conv_kernel(-1)
+
+
+@pytest.mark.parametrize("N,Ca,Cb,K,D,H,W", [(2, 32, 32, 32, 8, 16, 8), (1, 32, 32, 64, 9, 8, 17), (1, 64, 32, 96, 5, 9, 11)])
+def test_conv3d_cat_ops_match_concatenated_tensor(N, Ca, Cb, K, D, H, W):
+    """lnn_conv3d_{fwd,dgrad,wgrad}_cat on two separate tensors == the plain ops on their channel concatenation,
+    bit for bit (same kernels, same arithmetic order; only the addressing differs)."""
+    C = Ca + Cb
+    x = _rand((N, C, D, H, W), 1)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1).to(DEV)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3)).to(DEV)
+    dy = _rand((N, K, D, H, W), 4)
+    xb, _ = to_cl_h(x)
+    ld = max(Ca, Cb)
+    xa = torch.zeros((N, D, H, W, ld), dtype=torch.float16, device=DEV); xa[..., :Ca] = xb[..., :Ca]
+    xc = torch.zeros((N, D, H, W, ld), dtype=torch.float16, device=DEV); xc[..., :Cb] = xb[..., Ca:]
+    dyb, _ = to_cl_h(dy)
+    wf, wd = pack_conv_fwd(w), pack_conv_dgrad(w)
+    for which in (-1, 5, 7, 8):
+        assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
+        try:
+            y1 = torch.empty((N, D, H, W, K), dtype=torch.float16, device=DEV); y2 = torch.empty_like(y1)
+            nat.call("lnn_conv3d_fwd", xb, C, wf, b, y1, K, N, D, H, W, C, K, 1)
+            nat.call("lnn_conv3d_fwd_cat", xa, xc, ld, Ca, wf, b, y2, K, N, D, H, W, C, K)
+            assert torch.equal(y1, y2)
+            for acc in (0, 1):
+                base = to_cl_h(_rand((N, C, D, H, W), 5))[0]
+                dx1 = base.clone()
+                da = torch.zeros((N, D, H, W, ld), dtype=torch.float16, device=DEV); da[..., :Ca] = base[..., :Ca]
+                dc = torch.zeros((N, D, H, W, ld), dtype=torch.float16, device=DEV); dc[..., :Cb] = base[..., Ca:]
+                nat.call("lnn_conv3d_dgrad", dyb, K, wd, dx1, C, N, D, H, W, C, K, 1, acc)
+                nat.call("lnn_conv3d_dgrad_cat", dyb, K, wd, da, dc, ld, Ca, N, D, H, W, C, K, acc)
+                assert torch.equal(dx1[..., :Ca], da[..., :Ca]) and torch.equal(dx1[..., Ca:], dc[..., :Cb])
+        finally:
+            nat.lib().lnn_debug_force_conv_kernel(-1)
+    p1 = torch.zeros(nat.query("lnn_wgrad_panel_elems", 27, K, C), device=DEV); p2 = torch.zeros_like(p1)
+    nat.call("lnn_conv3d_wgrad", xb, C, dyb, K, p1, N, D, H, W, C, K, 1)
+    nat.call("lnn_conv3d_wgrad_cat", xa, xc, ld, Ca, dyb, K, p2, N, D, H, W, C, K)
+    assert float((p1 - p2).abs().max()) <= 1e-5 * float(p1.abs().max())      # fp32 atomics: order differs between launches
