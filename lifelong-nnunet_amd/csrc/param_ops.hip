@@ -71,7 +71,11 @@ __global__ __launch_bounds__(NT) void pack_weights_batched_kernel(const float* _
     __shared__ long firsts[DESC_MAX];
     for (int j = threadIdx.x; j < n; j += NT) firsts[j] = desc[j * DESC_W + 8];
     __syncthreads();
-    for (long g = (long)blockIdx.x * NT + threadIdx.x; g < total; g += (long)gridDim.x * NT) {
+    // one thread = 8 consecutive panel elements (same tap and row, channels kc .. kc+7): one 16-byte store, the
+    // descriptor search and the index decomposition once per 8 elements (panel sizes are multiples of 512)
+    const long total8 = total >> 3;
+    for (long g8 = (long)blockIdx.x * NT + threadIdx.x; g8 < total8; g8 += (long)gridDim.x * NT) {
+        const long g = g8 << 3;
         const long* d = desc + find_desc(firsts, n, g) * DESC_W;
         const long i = g - d[8];
         const int ntaps = (int)d[5], M = (int)d[6], KC = (int)d[7];
@@ -81,9 +85,14 @@ __global__ __launch_bounds__(NT) void pack_weights_batched_kernel(const float* _
         const int t = (int)(r % ntaps); r /= ntaps;
         const int ck = (int)(r % nck), mb = (int)(r / nck);
         const int m = mb * 32 + row, kc = ck * 16 + c16;
-        float v = 0.f;
-        if (m < M && kc < KC) v = src[d[0] + m * d[2] + kc * d[3] + t * d[4]];
-        dst[d[1] + i] = (half_t)v;
+        half8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < M) {
+            const float* sp = src + d[0] + m * d[2] + (long)kc * d[3] + t * d[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kc + j < KC) o[j] = (half_t)sp[j * d[3]];
+        }
+        *reinterpret_cast<half8*>(dst + d[1] + i) = o;
     }
 }
 
@@ -266,7 +275,8 @@ extern "C" int lnn_pack_weights_batched(lnn_stream_t s_, const float* src_base, 
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(src_base && dst_base && desc_dev && lnn_aligned16(dst_base), "lnn_pack_weights_batched: null/misaligned pointer");
     LNN_REQUIRE(n > 0 && n <= DESC_MAX && total > 0, "lnn_pack_weights_batched: 1..%d descriptors, total > 0", DESC_MAX);
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(flat_blocks(total, 4)), dim3(NT), 0, s, src_base, (half_t*)dst_base,
+    LNN_REQUIRE(total % 8 == 0, "lnn_pack_weights_batched: total %ld is not a sum of padded panel sizes", total);
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(flat_blocks(total / 8, 2)), dim3(NT), 0, s, src_base, (half_t*)dst_base,
                        desc_dev, n, total);
     LNN_CHECK_LAUNCH("lnn_pack_weights_batched");
     return LNN_OK;
