@@ -1,8 +1,13 @@
-// Implicit-GEMM 3-D convolution family on gfx950 MFMA (v_mfma_f32_32x32x16_f16), channels-last fp16.
+// Implicit-GEMM 3-D convolution family on gfx950 MFMA (v_mfma_f32_32x32x16_f16), channels-last fp16:
+// the C-ABI entry points, the kernel selection, and the GENERIC first-version kernel.
 //
-// One kernel template covers every "gather taps -> contract channels" op of the U-Net:
-//   conv 3x3x3 fwd (stride 1|2), conv dgrad (stride 1; stride 2 as 8 parity classes),
-//   transposed conv k2s2 fwd (8 parity classes, 1 tap each) and its dgrad (8 taps, input stride 2).
+// Production kernels (one file each, selected in the wrappers at the bottom of this file):
+//   stride-1 conv fwd / dgrad   igemm_conv_v2.hip (v5), igemm_conv_v7.hip (>= 128 input channels, small volumes),
+//                               igemm_conv_v8.hip (>= 64 output channels)
+//   stride-2 conv fwd, convT dgrad      igemm_down2.hip          stride-2 dgrad, convT fwd      igemm_up2.hip
+// The generic template below covers every "gather taps -> contract channels" op of the U-Net with one non-pipelined
+// kernel (stride-2 dgrad / transposed conv forward as 8 launches, one per output parity class); it is kept as the
+// A/B baseline behind LNN_CONV_V1 / LNN_UP2_V1 / LNN_DOWN2_V1 and lnn_debug_force_conv_kernel(1):
 //
 //   OUT[n, os*l+par, m] = bias[m] + sum_{tap} sum_{c} IN[n, IS*l + off(tap) - pad_lo, c] * WP[slot(tap)][m][c]
 //
@@ -10,7 +15,7 @@
 // i.e. MFMA rows = output channels, MFMA columns = 32 output voxels, so that each lane ends up with 4
 // consecutive output channels of one voxel per accumulator quad -> 8-byte channels-last stores.
 //
-// Block = 256 threads = 4 waves; block tile = (TZ x TY x 8) loop voxels x (32*MT) output channels.
+// Generic kernel: block = 256 threads = 4 waves; block tile = (TZ x TY x 8) loop voxels x (32*MT) output channels.
 // Input channels are processed in chunks of CK; the (halo) input tile of the chunk is staged once in
 // LDS and reused by all taps; weight panels are staged per tap group.
 // LDS rows are padded by 16 B (row pitch 16*odd) so the 16-byte fragment reads are conflict free.

@@ -25,7 +25,6 @@ constexpr int WBYTES = 27 * MB * ROWB, WCHUNKS = 27 * MB * 2, WN = (WCHUNKS + NT
 __device__ __forceinline__ int xaddr(int pz, int py, int px, int c2) {
     return ((pz * PY + py) * PX + px) * ROWB + ((c2 ^ (py & 1)) << 4);
 }
-__device__ __forceinline__ int waddr(int row, int c2) { return row * ROWB + ((c2 ^ ((row >> 3) & 1)) << 4); }
 
 // lane (0..31) -> (row 0..3, x 0..7) inside a 32-voxel MFMA tile.  ds_read_b128 is serviced in the 16-lane groups
 // {0-3,12-15,20-27} and {4-11,16-19,28-31}: each group gets two full 8-voxel rows (= one 256-byte bank row each,
@@ -288,7 +287,7 @@ int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name) {
         hipDeviceProp_t prop;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    int upb = lnn_cdiv(units, num_cu);     // one resident 8-wave block per CU (116.5 KB of LDS)
+    int upb = lnn_cdiv(units, num_cu);     // one resident 8-wave block per CU (139 KB of LDS)
     if (upb < 1) upb = 1;
     const int grid = lnn_cdiv(units, upb);
     const size_t lds = XBYTES + 2 * WBYTES;
