@@ -176,6 +176,21 @@ int lnn_online_dice_counts(lnn_stream_t s, const float* logits, const float* lab
                            float* counts);
 
 /* ------------------------------------------------------------------------------------------------
+ * MiB (loss part): cross-entropy of softmax(x) against a per-voxel target distribution q,
+ *   out = scale * mean_v sum_k q_k * (logsumexp(x) - x_k),   dx = gscale * scale / count * (softmax(x) - q).
+ *   soft = 0: target = labels (N,1,V) float integers, q = one-hot, voxels with label == ignore_index are skipped and the
+ *             mean runs over the counted voxels  (RobustCrossEntropyLoss(ignore_index=255), deep_supervision.py:393);
+ *   soft = 1: target = teacher logits (N,K,V), q = softmax(alpha * target), scale = 1/K gives
+ *             UnbiasedKnowledgeDistillationLoss for equal class sets (knowledge_distillation.py:11-32 as used at
+ *             deep_supervision.py:409-413).
+ * x: (N,K,V) fp32 logits.  ws: >= 2 doubles (sum, count), filled by fwd and read by bwd.
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_target_ce_fwd(lnn_stream_t s, const float* x, const float* target, int soft, int N, int K, long V, float alpha,
+                      int ignore_index, float scale, float* out, double* ws);
+int lnn_target_ce_bwd(lnn_stream_t s, const float* x, const float* target, int soft, int N, int K, long V, float alpha,
+                      int ignore_index, float scale, const double* ws, float gscale, const float* gscale_dev, float* dx);
+
+/* ------------------------------------------------------------------------------------------------
  * Sliding-window inference (predict.py:208-219 -> upstream SegmentationNetwork._internal_predict_3D_3Dconv_tiled):
  * one tile:  agg[k, o + u] += weight * gauss[u] * softmax(logits)[k, flip(u)],   nb[o + u] += gauss[u] (if add_nb)
  *   logits (K, pd,ph,pw) fp32 of ONE tile as the network produced it from the tile mirrored along flip_mask

@@ -12,6 +12,7 @@ TRAINER_MAP = {
     "sequential": "lifelong_nnunet_amd.training.network_training.sequential.nnUNetTrainerSequential:nnUNetTrainerSequential",
     "ewc": "lifelong_nnunet_amd.training.network_training.ewc.nnUNetTrainerEWC:nnUNetTrainerEWC",
     "rw": "lifelong_nnunet_amd.training.network_training.rw.nnUNetTrainerRW:nnUNetTrainerRW",
+    "mib": "lifelong_nnunet_amd.training.network_training.mib.nnUNetTrainerMiB:nnUNetTrainerMiB",
     "lwf": "lifelong_nnunet_amd.training.network_training.lwf.nnUNetTrainerLWF:nnUNetTrainerLWF",
     "rehearsal": "lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal:nnUNetTrainerRehearsal",
 }

@@ -356,6 +356,79 @@ __global__ void kl_finalize_kernel(const double* ws, int N, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(ws[0] / (double)N);
 }
 
+// ---------------------------------------------------------------------------------------- MiB: CE and unbiased KD
+// Cross-entropy of softmax(x) against a per-voxel target distribution q:
+//   HARD: q = one_hot(label), voxels with label == ignore are skipped, mean over the counted voxels
+//         (RobustCrossEntropyLoss(ignore_index=255), the base loss of MultipleOutputLossMiB, DS.py:393);
+//   SOFT: q = softmax(alpha * t), mean over all voxels, divided by K
+//         (UnbiasedKnowledgeDistillationLoss with equal class sets, knowledge_distillation.py:11-32: new_cl = K,
+//          outputs_bkg = x_0 - lse, outputs_no_bkg = x_{1..} - lse, / targets.shape[1]).
+// ws[0] = sum_v sum_k q_k * (lse - x_k), ws[1] = number of counted voxels.
+template <int SOFT>
+__global__ __launch_bounds__(NT) void target_ce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ tgt, int K, long V,
+                                                           float alpha, int ignore, double* ws) {
+    __shared__ float sm[2 * (NT / 64)];
+    const int n = blockIdx.y;
+    const float* xn = x + (long)n * K * V;
+    float acc[2] = {0.f, 0.f};
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        float p[KMAX], xs[KMAX], lse;
+        softmax_k(xn, V, v, K, 1.f, p, lse, xs);
+        if (SOFT) {
+            float q[KMAX], ts[KMAX], lt;
+            softmax_k(tgt + (long)n * K * V, V, v, K, alpha, q, lt, ts);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) acc[0] += q[k] * (lse - xs[k]);
+            acc[1] += 1.f;
+        } else {
+            const int lab = (int)tgt[(long)n * V + v];
+            if (lab != ignore) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k == lab) acc[0] += lse - xs[k];
+                acc[1] += 1.f;
+            }
+        }
+    }
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) {
+        atomicAdd(ws, (double)acc[0]);
+        atomicAdd(ws + 1, (double)acc[1]);
+    }
+}
+__global__ void target_ce_finalize_kernel(const double* ws, float scale, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = ws[1] > 0 ? (float)(ws[0] / ws[1]) * scale : 0.f;
+}
+// dx_k = gscale * scale / count * (softmax(x)_k - q_k)   (sum_k q_k = 1)
+template <int SOFT>
+__global__ __launch_bounds__(NT) void target_ce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ tgt, int K, long V,
+                                                           float alpha, int ignore, const double* __restrict__ ws, float gscale,
+                                                           const float* __restrict__ gscale_dev, float* __restrict__ dx) {
+    if (gscale_dev) gscale *= gscale_dev[0];
+    const float c = ws[1] > 0 ? gscale / (float)ws[1] : 0.f;
+    const int n = blockIdx.y;
+    const float* xn = x + (long)n * K * V;
+    float* dn = dx + (long)n * K * V;
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
+        float p[KMAX], xs[KMAX], lse, q[KMAX];
+        softmax_k(xn, V, v, K, 1.f, p, lse, xs);
+        float live = 1.f;
+        if (SOFT) {
+            float ts[KMAX], lt;
+            softmax_k(tgt + (long)n * K * V, V, v, K, alpha, q, lt, ts);
+        } else {
+            const int lab = (int)tgt[(long)n * V + v];
+            if (lab == ignore) live = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) q[k] = (k == lab) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) dn[(long)k * V + v] = live * c * (p[k] - q[k]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- sliding-window inference
 // One tile of the tiled predictor (upstream SegmentationNetwork._internal_predict_3D_3Dconv_tiled, reached through
 // predict.py:208-219 / MH.py:1115): agg[k, o + flipback(v)] += weight * gauss[flipback(v)] * softmax(logits[:, v])[k],
@@ -492,6 +565,33 @@ extern "C" int lnn_online_dice_counts(lnn_stream_t s_, const float* logits, cons
     hipMemsetAsync(counts, 0, sizeof(float) * N * (K - 1) * 3, s);
     hipLaunchKernelGGL(online_dice_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, logits, labels, K, V, counts);
     LNN_CHECK_LAUNCH("lnn_online_dice_counts");
+    return LNN_OK;
+}
+
+extern "C" int lnn_target_ce_fwd(lnn_stream_t s_, const float* x, const float* target, int soft, int N, int K, long V, float alpha,
+                                 int ignore_index, float scale, float* out, double* ws) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(x && target && out && ws, "lnn_target_ce_fwd: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_target_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
+    hipMemsetAsync(ws, 0, 2 * sizeof(double), s);
+    if (soft) hipLaunchKernelGGL((target_ce_fwd_kernel<1>), dim3(vox_blocks(V), N), dim3(NT), 0, s, x, target, K, V, alpha, ignore_index, ws);
+    else hipLaunchKernelGGL((target_ce_fwd_kernel<0>), dim3(vox_blocks(V), N), dim3(NT), 0, s, x, target, K, V, alpha, ignore_index, ws);
+    LNN_CHECK_LAUNCH("lnn_target_ce_fwd");
+    hipLaunchKernelGGL(target_ce_finalize_kernel, dim3(1), dim3(64), 0, s, ws, scale, out);
+    LNN_CHECK_LAUNCH("lnn_target_ce_fwd(finalize)");
+    return LNN_OK;
+}
+
+extern "C" int lnn_target_ce_bwd(lnn_stream_t s_, const float* x, const float* target, int soft, int N, int K, long V, float alpha,
+                                 int ignore_index, float scale, const double* ws, float gscale, const float* gscale_dev, float* dx) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(x && target && ws && dx, "lnn_target_ce_bwd: null pointer");
+    LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_target_ce_bwd: K=%d unsupported (2..%d)", K, KMAX);
+    if (soft) hipLaunchKernelGGL((target_ce_bwd_kernel<1>), dim3(vox_blocks(V), N), dim3(NT), 0, s, x, target, K, V, alpha, ignore_index, ws,
+                                 gscale * scale, gscale_dev, dx);
+    else hipLaunchKernelGGL((target_ce_bwd_kernel<0>), dim3(vox_blocks(V), N), dim3(NT), 0, s, x, target, K, V, alpha, ignore_index, ws,
+                            gscale * scale, gscale_dev, dx);
+    LNN_CHECK_LAUNCH("lnn_target_ce_bwd");
     return LNN_OK;
 }
 

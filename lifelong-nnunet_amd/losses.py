@@ -234,6 +234,78 @@ class MultipleOutputLossRW(MultipleOutputLossEWC):
         return loss
 
 
+# ------------------------------------------------------------------------------------------------- MiB
+class _TargetCEFunction(torch.autograd.Function):
+    """scale * mean_v sum_k q_k (lse(x) - x_k): q = one-hot labels (soft=0) or softmax(alpha * teacher) (soft=1)."""
+
+    @staticmethod
+    def forward(ctx, x, target, soft, alpha, ignore_index, scale):
+        x = x.contiguous()
+        N, K = x.shape[:2]
+        V = x[0, 0].numel()
+        tgt = target.detach().to(x.device, torch.float32).contiguous()
+        ws = torch.empty(2, dtype=torch.float64, device=x.device)
+        out = torch.empty(1, device=x.device)
+        nat.call("lnn_target_ce_fwd", x, tgt, int(soft), N, K, V, float(alpha), int(ignore_index), float(scale), out, ws)
+        ctx.save_for_backward(x, tgt, ws)
+        ctx.cfg = (int(soft), N, K, V, float(alpha), int(ignore_index), float(scale))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, tgt, ws = ctx.saved_tensors
+        soft, N, K, V, alpha, ignore, scale = ctx.cfg
+        dx = torch.empty_like(x)
+        nat.call("lnn_target_ce_bwd", x, tgt, soft, N, K, V, alpha, ignore, scale, ws, 1.0, g.reshape(1).float().contiguous(), dx)
+        return dx, None, None, None, None, None
+
+
+class RobustCrossEntropyLoss(nn.Module):
+    """nnunet_ext/training/loss_functions/crossentropy.py:19-25 (upstream CE on ``target[:, 0].long()``) with the
+    ``ignore_index`` the MiB / PLOP losses pass (255); mean over the counted voxels."""
+
+    def __init__(self, ignore_index=-100, **_ignored):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, input, target):
+        return _TargetCEFunction.apply(input, target, 0, 1.0, self.ignore_index, 1.0)
+
+
+class UnbiasedKnowledgeDistillationLoss(nn.Module):
+    """knowledge_distillation.py:3-32 for EQUAL class sets of student and teacher -- the only way the reference uses it
+    (every task keeps the label set, deep_supervision.py:393): new_cl = K, so the "background" term is the plain
+    background log-probability and the loss is  -1/K * mean sum_k softmax(alpha*t)_k * log_softmax(x)_k."""
+
+    def __init__(self, reduction='mean', alpha=1.):
+        super().__init__()
+        assert reduction == 'mean', "the reference constructs it with the default reduction (deep_supervision.py:399)"
+        self.reduction, self.alpha = reduction, alpha
+
+    def forward(self, inputs, targets, mask=None):
+        assert mask is None and inputs.shape[1] == targets.shape[1], "equal class sets, no mask (deep_supervision.py:409-413)"
+        return _TargetCEFunction.apply(inputs, targets, 1, self.alpha, -1, 1.0 / inputs.shape[1])
+
+
+class MultipleOutputLossMiB(MultipleOutputLoss2):
+    """deep_supervision.py:383-416: deep-supervised CE (no Dice, ignore_index 255) + for EVERY level i (zero-weight
+    ones included, multiplied by 0) ``weights[i] * lkd * UnbiasedKD(x[i], x_o[i])``; ``x_o`` = the previous model's
+    outputs, detached by the caller."""
+
+    def __init__(self, alpha=1., lkd=10, weight_factors=None):
+        super().__init__(RobustCrossEntropyLoss(ignore_index=255), weight_factors)
+        self.lkd, self.alpha = lkd, alpha
+        self.lkd_loss = UnbiasedKnowledgeDistillationLoss(alpha=self.alpha)
+
+    def forward(self, x, x_o, y):
+        assert isinstance(x_o, (tuple, list)), "x_o must be either tuple or list"
+        loss = super().forward(x, y)
+        weights = self.weight_factors if self.weight_factors is not None else [1] * len(x)
+        for i in range(len(x)):
+            loss = loss + weights[i] * self.lkd * self.lkd_loss(x[i], x_o[i])
+        return loss
+
+
 # ------------------------------------------------------------------------------------------------- LwF
 def kl_logits(pred, teach, temperature):
     """F.kl_div(log_softmax(pred/T,1), log_softmax(teach/T,1), 'batchmean', log_target=True)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "lnn_fisher_accumulate": (_i, [_p, _p, _p, _l, _f, _f]),
     "lnn_fisher_ema": (_i, [_p, _p, _p, _l, _f, _f]),
     "lnn_rw_update": (_i, [_p, _p, _p, _p, _p, _p, _l, _f, _f, _p, _f, _f, _i]),
+    "lnn_target_ce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _l, _f, _i, _f, _p, _p]),
+    "lnn_target_ce_bwd": (_i, [_p, _p, _p, _i, _i, _i, _l, _f, _i, _f, _p, _f, _p, _p]),
     "lnn_softmax_accumulate": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_f, _i]),
     "lnn_softmax_finalize": (_i, [_p, _p, _p, _i, _l, _p]),
     "lnn_gradnorm_sumsq": (_i, [_p, _p, _l, _f, _p, _i]),

@@ -89,6 +89,34 @@ def rw_penalty(named_params, fisher, params, importance, rw_lambda=0.4, first_ta
     return pen if pen is not None else torch.zeros(())
 
 
+def unbiased_kd(inputs, targets, alpha=1.0):
+    """knowledge_distillation.py:11-32 (UnbiasedKnowledgeDistillationLoss, reduction 'mean', no mask), restated for any
+    class counts: ``new_cl`` = K_new - K_old, or K when they are equal (the reference's own quirk at :12)."""
+    k_in, k_t = inputs.shape[1], targets.shape[1]
+    new_cl = k_in - k_t if k_in != k_t else k_in
+    t = targets * alpha
+    den = torch.logsumexp(inputs, dim=1)
+    no_bkg = (inputs[:, 1:-new_cl] if (k_in - new_cl) > 1 else inputs[:, 1:]) - den.unsqueeze(1)
+    idx = torch.tensor([0] + list(range(k_t, k_in)))
+    bkg = torch.logsumexp(inputs.index_select(1, idx), dim=1) - den
+    lab = torch.softmax(t, dim=1)
+    loss = (lab[:, 0] * bkg + (lab[:, 1:] * no_bkg).sum(dim=1)) / k_t
+    return -loss.mean()
+
+
+def mib_loss(outputs, old_outputs, targets, weights, alpha=1.0, lkd=10.0, ignore_index=255):
+    """deep_supervision.py:401-416: sum_i w_i CE(x_i, y_i) (zero weights skipped) + sum_i w_i * lkd * UKD(x_i, x_o_i)."""
+    l = None
+    for i, (x, y) in enumerate(zip(outputs, targets)):
+        if i > 0 and weights[i] == 0:
+            continue
+        t = weights[i] * torch.nn.functional.cross_entropy(x, y[:, 0].long(), ignore_index=ignore_index)
+        l = t if l is None else l + t
+    for i, (x, xo) in enumerate(zip(outputs, old_outputs)):
+        l = l + weights[i] * lkd * unbiased_kd(x, xo, alpha)
+    return l
+
+
 def lwf_distillation(pred_logits, teacher_logits, temperature=2.0):
     """deep_supervision.py:194-196: batchmean KL between log-softmaxes at temperature T (no T^2)."""
     return F.kl_div(F.log_softmax(pred_logits.float() / temperature, dim=1),

@@ -84,7 +84,8 @@ def main():
     torch.manual_seed(0)
     # torch.Tensor.get_device() returns -1 on CPU which the shimmed to_cuda ignores
     from nnunet_ext.training.loss_functions.deep_supervision import (MultipleOutputLossEWC, MultipleOutputLossLWF,
-                                                                      MultipleOutputLossRW)
+                                                                      MultipleOutputLossMiB, MultipleOutputLossRW)
+    from nnunet_ext.training.loss_functions.knowledge_distillation import UnbiasedKnowledgeDistillationLoss
     from nnunet_ext.network_architecture.MultiHead_Module import MultiHead_Module
 
     meta = {}
@@ -128,6 +129,30 @@ def main():
         ewc[f"logits_{i}"] = x.numpy(); ewc[f"target_{i}"] = y.numpy()
     np.savez_compressed(os.path.join(OUT, "ewc_reference.npz"), **ewc)
     meta["ewc"] = {"names": names, "generator": float(v_gen), "list": float(v_list), "base": float(v_base)}
+
+    # ------------------------------------------------------------------ MiB loss (reference executed verbatim)
+    mxs, mys = toy_logits(31)
+    mxo, _ = toy_logits(32)
+    mxs = [x.clone().requires_grad_(True) for x in mxs]
+    ref_mib = MultipleOutputLossMiB(alpha=1.0, lkd=10, weight_factors=w)
+    v_mib = ref_mib(tuple(mxs), tuple(mxo), mys)
+    g_mib = torch.autograd.grad(v_mib, mxs, allow_unused=True)
+    o_mib = losses.mib_loss([x.detach() for x in mxs], mxo, mys, w, 1.0, 10.0)
+    assert abs(float(o_mib) - float(v_mib.detach())) <= 1e-6 * abs(float(v_mib)), (o_mib, v_mib)
+    ukd = {a: float(UnbiasedKnowledgeDistillationLoss(alpha=a)(mxs[0].detach(), mxo[0])) for a in (1.0, 0.5)}
+    for a, val in ukd.items():
+        assert abs(float(losses.unbiased_kd(mxs[0].detach(), mxo[0], a)) - val) <= 1e-6 * abs(val)
+    # more student classes than teacher classes (the class-incremental form the loss was written for)
+    xin = torch.randn((2, 5, 6, 8, 6), generator=torch.Generator().manual_seed(33))
+    ukd_inc = float(UnbiasedKnowledgeDistillationLoss(alpha=1.0)(xin, mxo[0]))
+    assert abs(float(losses.unbiased_kd(xin, mxo[0], 1.0)) - ukd_inc) <= 1e-6 * abs(ukd_inc)
+    mib = {"ds_weights": w, "ref_value": np.float64(float(v_mib)), "ukd_alpha1": np.float64(ukd[1.0]),
+           "ukd_alpha05": np.float64(ukd[0.5]), "ukd_incremental": np.float64(ukd_inc), "x_incremental": xin.numpy()}
+    for i in range(len(mxs)):
+        mib[f"logits_{i}"] = mxs[i].detach().numpy(); mib[f"old_logits_{i}"] = mxo[i].numpy(); mib[f"target_{i}"] = mys[i].numpy()
+        mib[f"grad_{i}"] = (g_mib[i] if g_mib[i] is not None else torch.zeros_like(mxs[i])).numpy()
+    np.savez_compressed(os.path.join(OUT, "mib_reference.npz"), **mib)
+    meta["mib"] = {"value": float(v_mib), "alpha": 1.0, "lkd": 10}
 
     # ------------------------------------------------------------------ RW loss (reference executed verbatim)
     # three tasks in the dicts: the last one is the task being trained and is omitted by update_rw_params (DS.py:106)

@@ -271,3 +271,55 @@ def test_rw_trainer_flow_matches_oracle():
     tr.run_training("taskB")
     assert tr.loss.tasks == ["taskA"] and list(tr.fisher.keys()) == ["taskA", "taskB"]
     assert [n for n, _ in tr.loss.network_params] == []
+
+
+def test_mib_loss_class_matches_reference_values(golden_dir):
+    """MultipleOutputLossMiB (fused lnn_target_ce kernels) vs the reference class executed verbatim: value, gradients
+    w.r.t. every deep-supervision level, and the distillation term alone at two alphas."""
+    from lifelong_nnunet_amd.losses import MultipleOutputLossMiB, RobustCrossEntropyLoss, UnbiasedKnowledgeDistillationLoss
+    d = np.load(golden_dir + "/mib_reference.npz")
+    xs = tuple(torch.from_numpy(d[f"logits_{i}"]).to(DEV).requires_grad_(True) for i in range(2))
+    xo = tuple(torch.from_numpy(d[f"old_logits_{i}"]).to(DEV) for i in range(2))
+    ys = [torch.from_numpy(d[f"target_{i}"]).to(DEV) for i in range(2)]
+    loss = MultipleOutputLossMiB(alpha=1.0, lkd=10, weight_factors=d["ds_weights"])
+    v = loss(xs, xo, ys)
+    assert abs(float(v.detach()) - float(d["ref_value"])) <= 1e-5 * abs(float(d["ref_value"]))
+    g = torch.autograd.grad(v, xs, allow_unused=True)
+    for i in range(2):
+        ref = torch.from_numpy(d[f"grad_{i}"])
+        gi = torch.zeros_like(ref) if g[i] is None else g[i].cpu()
+        assert float((gi - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9
+    for a, key in ((1.0, "ukd_alpha1"), (0.5, "ukd_alpha05")):
+        got = float(UnbiasedKnowledgeDistillationLoss(alpha=a)(xs[0].detach(), xo[0]))
+        assert abs(got - float(d[key])) <= 1e-5 * abs(float(d[key]))
+    # ignore_index: voxels labelled 255 drop out of the mean
+    lab = ys[0].clone(); lab[:, :, :2] = 255
+    ce = float(RobustCrossEntropyLoss(ignore_index=255)(xs[0].detach(), lab))
+    ref = float(torch.nn.functional.cross_entropy(xs[0].detach().cpu(), lab[:, 0].long().cpu(), ignore_index=255))
+    assert abs(ce - ref) <= 1e-5 * abs(ref)
+
+
+def test_mib_trainer_flow_matches_oracle():
+    """Task A with the plain loss, task B with CE + unbiased KD against the frozen task-A model: first task-B iteration
+    vs the oracle on the same weights / batch."""
+    tr = _make_trainer("mib", "taskA", transfer_heads=True)
+    tr.run_training("taskA")
+    assert tr.network_old is None
+    tr.num_batches_per_epoch = 1
+    onet_old = OracleGenericUNet(1, 8, 3, 2)
+    onet_old.load_state_dict({k: v.cpu() for k, v in tr.network.state_dict().items()})
+    b = next(default_data_provider("taskB", "train", TOY))
+    # first task-B iteration: the new head is a copy of the old one (transfer_heads) -> new model == old model
+    tr.max_num_epochs, tr.epoch = 1, 0
+    tr.run_training("taskB")
+    assert tr.network_old is not None and not any(p.requires_grad for p in tr.network_old.parameters())
+    with torch.no_grad():
+        out_old = onet_old(b['data'])
+    onet_new = OracleGenericUNet(1, 8, 3, 2)
+    onet_new.load_state_dict(onet_old.state_dict())
+    # the oracle's new model starts from the same body and (transfer_heads) the same head
+    out_new = onet_new(b['data'])
+    w = olosses.ds_loss_weights(2)
+    o_val = float(olosses.mib_loss(out_new, [o.detach() for o in out_old], b['target'], w, 1.0, 10.0))
+    print(f"MiB task B iter 0: oracle {o_val:.6f} hip {tr.all_tr_losses[-1]:.6f}")
+    assert abs(tr.all_tr_losses[-1] - o_val) <= 2e-4 * abs(o_val)

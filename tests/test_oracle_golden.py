@@ -181,3 +181,21 @@ def test_rw_running_statistics_restatement():
     assert torch.allclose(fisher["weight"], (st["fisher"]["weight"] - mx) / train.RW_EPSILON)
     _, _, scores2 = train.rw_finish_task(net, st, n_finished=2)
     assert torch.equal(scores2["weight"], st["scores"]["weight"])
+
+
+def test_mib_loss_matches_reference(golden_dir):
+    """oracle.losses.mib_loss / unbiased_kd == MultipleOutputLossMiB / UnbiasedKnowledgeDistillationLoss executed
+    verbatim (tests/golden/mib_reference.npz), incl. the class-incremental form (more student than teacher classes)."""
+    d = np.load(golden_dir + "/mib_reference.npz")
+    xs = [torch.from_numpy(d[f"logits_{i}"]).requires_grad_(True) for i in range(2)]
+    xo = [torch.from_numpy(d[f"old_logits_{i}"]) for i in range(2)]
+    ys = [torch.from_numpy(d[f"target_{i}"]) for i in range(2)]
+    v = losses.mib_loss(xs, xo, ys, d["ds_weights"], 1.0, 10.0)
+    assert abs(float(v) - float(d["ref_value"])) <= 1e-6 * abs(float(d["ref_value"]))
+    g = torch.autograd.grad(v, xs, allow_unused=True)
+    for i in range(2):
+        gi = g[i] if g[i] is not None else torch.zeros_like(xs[i])
+        assert torch.allclose(gi, torch.from_numpy(d[f"grad_{i}"]), rtol=1e-5, atol=1e-8)
+    assert abs(float(losses.unbiased_kd(xs[0].detach(), xo[0], 0.5)) - float(d["ukd_alpha05"])) <= 1e-6 * abs(float(d["ukd_alpha05"]))
+    xin = torch.from_numpy(d["x_incremental"])
+    assert abs(float(losses.unbiased_kd(xin, xo[0], 1.0)) - float(d["ukd_incremental"])) <= 1e-6 * abs(float(d["ukd_incremental"]))
