@@ -47,7 +47,8 @@ def main():
             print(f"{name:9s} {C:4d}->{K:<4d} convT @{D}x{H}x{W} : fwd {t*1e3:7.3f} ms  {gb/t:6.0f} GB/s algorithmic", flush=True)
             del x, y
             continue
-        N, C, K, D, H, W, s = LAYERS[name]
+        cat = name.endswith("cat")            # e.g. dec4.0cat: the input as two separate 32-channel tensors
+        N, C, K, D, H, W, s = LAYERS[name[:-3] if cat else name]
         Do, Ho, Wo = [(x - 1) // s + 1 for x in (D, H, W)]
         x = (torch.randn((N, D, H, W, C), device=dev) * 0.5).half()
         dy = (torch.randn((N, Do, Ho, Wo, K), device=dev) * 0.5).half()
@@ -61,7 +62,10 @@ def main():
         nat.call("lnn_pack_weights", w, wd, 27, C, K, 27, C * 27, 1)
         panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 27, K, C), device=dev)
         flops = 2.0 * N * Do * Ho * Wo * C * K * 27
-        fns = {"fwd": lambda: nat.call("lnn_conv3d_fwd", x, C, wf, b, y, K, N, D, H, W, C, K, s),
+        if cat:
+            xa = x[..., :C // 2].contiguous(); xb = x[..., C // 2:].contiguous()
+        fns = {"fwd": (lambda: nat.call("lnn_conv3d_fwd_cat", xa, xb, C // 2, C // 2, wf, b, y, K, N, D, H, W, C, K)) if cat else
+                      (lambda: nat.call("lnn_conv3d_fwd", x, C, wf, b, y, K, N, D, H, W, C, K, s)),
                "dgrad": lambda: nat.call("lnn_conv3d_dgrad", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0),
                "wgrad": lambda: nat.call("lnn_conv3d_wgrad", x, C, dy, K, panel, N, D, H, W, C, K, s)}
         out = []
