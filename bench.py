@@ -150,6 +150,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("LNN_FORCE_DP", "0") == "1"
+    # stdout must carry exactly ONE line (the JSON): libraries that print to the C-level stdout (RCCL writes a version
+    # banner there at communicator creation) are sent to stderr; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -230,7 +235,8 @@ def main():
     if rank == 0:
         info = nat.device_info()
         out["device"] = info
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
