@@ -66,10 +66,20 @@ class GradScaler:
                 self._growth_tracker = 0
 
     def state_dict(self):
-        return {"scale": self._scale, "_growth_tracker": self._growth_tracker}
+        """Same keys as ``torch.cuda.amp.GradScaler.state_dict()`` (checkpoint interop, MH.py:1164-1197 -> upstream
+        ``NetworkTrainer.save_checkpoint``)."""
+        if not self.enabled:
+            return {}
+        return {"scale": self._scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self._growth_tracker}
 
     def load_state_dict(self, d):
-        self._scale, self._growth_tracker = d["scale"], d["_growth_tracker"]
+        if not d:
+            return
+        self._scale, self._growth_tracker = float(d["scale"]), int(d["_growth_tracker"])
+        self.growth_factor = d.get("growth_factor", self.growth_factor)
+        self.backoff_factor = d.get("backoff_factor", self.backoff_factor)
+        self.growth_interval = d.get("growth_interval", self.growth_interval)
 
 
 class FusedSGD:
@@ -116,12 +126,47 @@ class FusedSGD:
         c = self.ctrl.cpu()
         return float(c[0]) ** 0.5, bool(c[1] > 0)
 
+    def _trainable(self):
+        """Parameters in ``torch.optim.SGD(self.network.parameters(), ...)`` order (MH.py:294-301: those that require grad)."""
+        return [(n, p) for n, p in self.net._named if p.requires_grad]
+
     def state_dict(self):
-        return {"momentum": self.net.arena.momentum.clone(), "lr": self.param_groups[0]["lr"]}
+        """``torch.optim.SGD.state_dict()`` layout, so checkpoints interoperate with the reference's trainers
+        (upstream ``NetworkTrainer.save_checkpoint`` / ``load_checkpoint_ram``): ``state[i]['momentum_buffer']`` per
+        parameter index, one param group.  A parameter the optimiser never stepped (momentum still all zero AND listed in
+        ``params_without_grad``) has no state entry, as in torch."""
+        g = self.param_groups[0]
+        named = self._trainable()
+        skip = getattr(self.net, "params_without_grad", ())
+        state = {}
+        for i, (n, p) in enumerate(named):
+            if n in skip:
+                continue
+            s = p._lnn_slot
+            state[i] = {"momentum_buffer": self.net.arena.momentum[s.offset:s.offset + s.numel].view(s.shape).clone()}
+        group = {"lr": g["lr"], "momentum": g["momentum"], "dampening": 0, "weight_decay": g["weight_decay"],
+                 "nesterov": True, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(len(named)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, d):
-        self.net.arena.momentum.copy_(d["momentum"])
-        self.param_groups[0]["lr"] = d["lr"]
+        if "param_groups" not in d:                      # round-1 private format {"momentum": arena, "lr": float}
+            self.net.arena.momentum.copy_(d["momentum"])
+            self.param_groups[0]["lr"] = d["lr"]
+            return
+        named = self._trainable()
+        grp = d["param_groups"][0]
+        assert len(grp["params"]) == len(named), "optimizer state was saved for a different set of trainable parameters"
+        for k in ("lr", "momentum", "weight_decay"):
+            self.param_groups[0][k] = grp[k]
+        self.net.arena.momentum.zero_()
+        for pos, idx in enumerate(grp["params"]):
+            st = d["state"].get(idx)
+            if st is None or st.get("momentum_buffer") is None:
+                continue
+            s = named[pos][1]._lnn_slot
+            self.net.arena.momentum[s.offset:s.offset + s.numel].copy_(
+                st["momentum_buffer"].to(self.net.arena.momentum.device, torch.float32).reshape(-1))
 
 
 def clip_grad_norm_(net, max_norm, optimizer: FusedSGD, inv_scale=1.0):

@@ -53,6 +53,11 @@ class nnUNetTrainerMultiHead:
                  plans: Optional[dict] = None, data_provider: Optional[Callable] = None, device="cuda",
                  process_group=None):
         assert not use_vit, "Generic_ViT_UNet variants are out of scope (SURVEY.md section 2 row 8)"
+        # the positional constructor arguments the reference stores next to every checkpoint (MH.py:181-185)
+        self.init_args = (split, task, plans_file, fold, output_folder, dataset_directory, batch_dice, stage, unpack_data,
+                          deterministic, fp16, save_interval, already_trained_on, use_progress, identifier, extension,
+                          tasks_list_with_char, mixed_precision, save_csv, del_log, use_vit, vit_type, version, split_gpu,
+                          transfer_heads, ViT_task_specific_ln, do_LSA, do_SPT)
         self.split, self.task, self.fold = split, task, fold
         self.plans = dict(DEFAULT_PLANS if plans is None else plans)
         self.batch_dice = batch_dice          # False for single-stage 3d_fullres (run/default_configuration.py:93-100)
@@ -278,25 +283,53 @@ class nnUNetTrainerMultiHead:
                           use_gaussian=use_gaussian, verbose=verbose)
 
     def save_checkpoint(self, fname=None, save_optimizer=True):
-        """MH.py:1164-1197: the whole MultiHead_Module state (model + heads + body) + optimiser + scaler."""
-        ckpt = {"state_dict": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.mh_network.state_dict().items()),
-                "heads": list(self.mh_network.heads.keys()), "active_task": self.mh_network.active_task,
-                "epoch": self.epoch, "amp_grad_scaler": self.amp_grad_scaler.state_dict() if self.amp_grad_scaler else None,
-                "optimizer_state_dict": self.optimizer.state_dict() if (save_optimizer and self.optimizer) else None}
+        """MH.py:1164-1197 -> upstream ``NetworkTrainer.save_checkpoint`` / ``nnUNetTrainer.save_checkpoint``: the WHOLE
+        MultiHead_Module state (``model.* / body.* / heads.<task>.*``, CPU tensors), ``epoch + 1``, the optimiser and
+        GradScaler state in torch's own layouts, the loss curves, and next to ``fname`` a ``.pkl`` with the constructor
+        arguments and plans -- the dictionary a reference trainer's ``load_checkpoint_ram`` consumes.  The head list and
+        the active task (kept by the reference in ``<ext>_trained_on.pkl``, MH.py:1174-1180) are stored in the
+        checkpoint as well so that it is self-contained."""
+        self.already_trained_on.setdefault(str(self.fold), {})
+        self.already_trained_on[str(self.fold)]['checkpoint_should_exist'] = True
+        self.already_trained_on[str(self.fold)]['tasks_at_time_of_checkpoint'] = list(self.mh_network.heads.keys())
+        self.already_trained_on[str(self.fold)]['active_task_at_time_of_checkpoint'] = self.mh_network.active_task
+        ckpt = {"epoch": self.epoch + 1,
+                "state_dict": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.mh_network.state_dict().items()),
+                "optimizer_state_dict": self.optimizer.state_dict() if (save_optimizer and self.optimizer) else None,
+                "lr_scheduler_state_dict": None,
+                "plot_stuff": (self.all_tr_losses, self.all_val_losses, [], []),
+                "best_stuff": (None, None, None),
+                "heads": list(self.mh_network.heads.keys()), "active_task": self.mh_network.active_task}
+        if ckpt["optimizer_state_dict"] is not None:
+            for st in ckpt["optimizer_state_dict"]["state"].values():
+                st["momentum_buffer"] = st["momentum_buffer"].cpu()
+        if self.amp_grad_scaler is not None:
+            ckpt["amp_grad_scaler"] = self.amp_grad_scaler.state_dict()
         if fname is not None:
+            import pickle
             torch.save(ckpt, fname)
+            info = OrderedDict(init=self.init_args, name=self.__class__.__name__, plans=self.plans)
+            info["class"] = str(self.__class__)
+            with open(fname + ".pkl", "wb") as f:
+                pickle.dump(info, f)
         return ckpt
 
     def load_checkpoint_ram(self, checkpoint, train=True):
-        """MH.py:1278-1313: heads must exist before the state dict is loaded."""
-        self.mh_network.add_n_tasks_and_activate(checkpoint["heads"], checkpoint["active_task"])
-        self.mh_network.load_state_dict(checkpoint["state_dict"])
+        """MH.py:1278-1313: the heads must exist before the state dict is loaded; ``module.`` prefixes are stripped as
+        upstream does; optimiser / GradScaler states are read in torch's layouts (or this package's round-1 one)."""
+        heads = checkpoint.get("heads") or self.already_trained_on[str(self.fold)]['tasks_at_time_of_checkpoint']
+        active = checkpoint.get("active_task") or self.already_trained_on[str(self.fold)]['active_task_at_time_of_checkpoint']
+        self.mh_network.add_n_tasks_and_activate(heads, active)
+        curr = set(self.mh_network.state_dict().keys())
+        sd = OrderedDict((k[7:] if (k not in curr and k.startswith("module.")) else k, v) for k, v in checkpoint["state_dict"].items())
+        self.mh_network.load_state_dict(sd)
         self.network = self.mh_network.model
         self.network.mark_params_changed()
         self.epoch = checkpoint.get("epoch", 0)
         if train and checkpoint.get("optimizer_state_dict") is not None:
-            self.optimizer.load_state_dict({k: (v.to(self.device) if torch.is_tensor(v) else v)
-                                            for k, v in checkpoint["optimizer_state_dict"].items()})
+            self.optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+        if "plot_stuff" in checkpoint:
+            self.all_tr_losses, self.all_val_losses = list(checkpoint["plot_stuff"][0]), list(checkpoint["plot_stuff"][1])
         if checkpoint.get("amp_grad_scaler") and self.amp_grad_scaler:
             self.amp_grad_scaler.load_state_dict(checkpoint["amp_grad_scaler"])
 

@@ -162,3 +162,66 @@ def test_sliding_window_steps_and_gaussian_map():
     seg = np.array([[0, 1, 1, 2]]); lab = np.array([[0, 1, 2, 2]])
     d = dice_per_class(seg, lab, 4)
     assert d[1]["Dice"] == 2 / 3 and d[2]["Dice"] == 2 / 3 and d[1]["IoU"] == 0.5 and np.isnan(d[3]["Dice"])
+
+
+def test_checkpoint_interoperates_with_torch_optimizer_and_upstream_layout(tmp_path, golden_dir):
+    """SURVEY.md 8f rank 4 (checkpoint interop): ``save_checkpoint`` writes the dictionary upstream
+    ``NetworkTrainer.load_checkpoint_ram`` consumes -- MultiHead_Module state-dict keys as the REFERENCE class produces
+    them (golden), ``torch.optim.SGD`` / ``GradScaler`` state layouts, ``epoch + 1``, the ``.pkl`` sidecar -- and reads
+    the same back, including a state dict written by a real ``torch.optim.SGD``."""
+    import pickle
+    from lifelong_nnunet_amd import get_trainer_class
+    from oracle.unet import OracleGenericUNet
+    plans = {"patch_size": (16, 16, 16), "batch_size": 2, "num_pool": 2, "base_num_features": 8, "num_classes": 3,
+             "num_input_channels": 1, "synthetic_period": 4}
+    tr = get_trainer_class("multihead")("seg_outputs", "taskA", plans=plans, device="cpu")
+    tr.initialize(True, num_epochs=3)
+    tr.mh_network.add_new_task("taskB", use_init=False)
+    tr.epoch = 2
+    tr.all_tr_losses, tr.all_val_losses = [0.5, 0.4], [0.6]
+    g = torch.Generator().manual_seed(1)
+    tr.network.arena.momentum.copy_(torch.randn(tr.network.arena.size, generator=g))
+    fname = str(tmp_path / "model_final_checkpoint.model")
+    ckpt = tr.save_checkpoint(fname)
+    # ---- layout
+    m = json.load(open(f"{golden_dir}/meta.json"))["multihead"]
+    assert list(ckpt["state_dict"].keys()) == m["state_dict_keys"]          # produced by the reference MultiHead_Module
+    assert ckpt["epoch"] == 3 and ckpt["lr_scheduler_state_dict"] is None and len(ckpt["plot_stuff"]) == 4
+    assert set(ckpt["amp_grad_scaler"]) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    info = pickle.load(open(fname + ".pkl", "rb"))
+    assert info["name"] == "nnUNetTrainerMultiHead" and info["plans"]["num_pool"] == 2 and info["init"][0] == "seg_outputs"
+    disk = torch.load(fname, weights_only=False)
+    assert list(disk["state_dict"].keys()) == list(ckpt["state_dict"].keys())
+    # ---- a real torch.optim.SGD over a network with the same parameters accepts the optimiser state ...
+    onet = OracleGenericUNet(1, 8, 3, 2)
+    names = [n for n, p in onet.named_parameters() if p.requires_grad]
+    assert names == [n for n, _ in tr.optimizer._trainable()]
+    topt = torch.optim.SGD([p for p in onet.parameters() if p.requires_grad], 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    topt.load_state_dict(ckpt["optimizer_state_dict"])
+    by_name = dict(tr.network.named_parameters())
+    for p_, n in zip(topt.param_groups[0]["params"], names):
+        s = by_name[n]._lnn_slot
+        assert torch.equal(topt.state[p_]["momentum_buffer"].reshape(-1), tr.network.arena.momentum[s.offset:s.offset + s.numel])
+    # ... and its own state dict loads back into the fused optimiser (a checkpoint written by a reference trainer)
+    orig0 = ckpt["optimizer_state_dict"]["state"][0]["momentum_buffer"].clone()      # torch may alias the loaded tensors
+    orig3 = ckpt["optimizer_state_dict"]["state"][3]["momentum_buffer"].clone()
+    for st in topt.state.values():
+        st["momentum_buffer"].mul_(2.0)
+    topt.param_groups[0]["lr"] = 3e-3
+    tr.optimizer.load_state_dict(topt.state_dict())
+    assert tr.optimizer.param_groups[0]["lr"] == 3e-3
+    s0 = by_name[names[0]]._lnn_slot
+    assert torch.equal(tr.network.arena.momentum[s0.offset:s0.offset + s0.numel],
+                       2.0 * orig0.reshape(-1))
+    # ---- round trip through a fresh trainer (upstream strips DataParallel's "module." prefix: do the same)
+    tr2 = get_trainer_class("multihead")("seg_outputs", "taskA", plans=plans, device="cpu")
+    tr2.initialize(True, num_epochs=3)
+    ck2 = dict(disk)
+    ck2["state_dict"] = {"module." + k: v for k, v in disk["state_dict"].items()}
+    tr2.load_checkpoint_ram(ck2, train=True)
+    assert tr2.epoch == 3 and list(tr2.mh_network.heads.keys()) == ["taskA", "taskB"] and tr2.all_tr_losses == [0.5, 0.4]
+    for (k1, v1), (k2, v2) in zip(tr.mh_network.state_dict().items(), tr2.mh_network.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    s = by_name[names[3]]._lnn_slot
+    assert torch.equal(tr2.network.arena.momentum[s.offset:s.offset + s.numel], orig3.reshape(-1))
+    assert tr2.amp_grad_scaler.get_scale() == tr.amp_grad_scaler.get_scale()
