@@ -238,6 +238,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
+        if world > 1:
+            dist.barrier()          # rank 0 may still be timing the roofline kernels: leave together
         dist.destroy_process_group()
 
 
