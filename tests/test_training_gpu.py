@@ -120,3 +120,41 @@ def test_sliding_window_inference_matches_oracle():
     seg_o, prob_o = oinf.predict_3d_tiled(onet, small, (16, 16, 16), 0.5, False, (), True)
     seg_g, prob_g = predict_3D(net, small, do_mirroring=False, mirror_axes=(), step_size=0.5, patch_size=(16, 16, 16))
     assert prob_g.shape == (3, 16, 10, 16) and float(np.abs(prob_g - prob_o).max()) < 2e-2
+
+
+def test_sliding_window_kernels_exact_properties():
+    """lnn_softmax_accumulate / lnn_softmax_finalize through predict_3D with stand-in networks whose tiled prediction is
+    known in closed form: constant logits -> the same probabilities everywhere; a pointwise (flip-equivariant) network
+    -> tiling, Gaussian blending and 8-fold mirroring change nothing (fp32 logits, so the tolerance is round-off)."""
+    from lifelong_nnunet_amd.inference import predict_3D
+
+    class Fake(torch.nn.Module):
+        def __init__(self, pointwise):
+            super().__init__()
+            self.device_, self.num_classes, self.do_ds = torch.device(DEV), 3, True
+            self.c = torch.nn.Conv3d(1, 3, 1).to(DEV) if pointwise else None
+        def forward(self, x):
+            if self.c is not None:
+                return self.c(x.to(DEV)).contiguous()
+            out = torch.zeros((x.shape[0], 3) + tuple(x.shape[2:]), device=DEV)
+            out[:, 1] = 1.0; out[:, 2] = -0.5
+            return out
+
+    g = torch.Generator().manual_seed(0)
+    vol = torch.randn((1, 21, 30, 17), generator=g).numpy()
+    p_const = torch.softmax(torch.tensor([0.0, 1.0, -0.5]), 0).numpy()
+    for mirror in (False, True):
+        seg, prob = predict_3D(Fake(False), vol, do_mirroring=mirror, mirror_axes=(0, 1, 2), step_size=0.5, patch_size=(8, 16, 8))
+        assert prob.shape == (3, 21, 30, 17) and np.allclose(prob, p_const[:, None, None, None], atol=1e-6) and (seg == 1).all()
+    torch.manual_seed(3)
+    net = Fake(True)
+    with torch.no_grad():
+        ref = torch.softmax(net(torch.from_numpy(vol)[None]), 1)[0].cpu().numpy()
+    for kw in (dict(do_mirroring=False, mirror_axes=()), dict(do_mirroring=True, mirror_axes=(0, 1, 2)),
+               dict(do_mirroring=True, mirror_axes=(2,), use_gaussian=False, step_size=0.25)):
+        args = dict(step_size=0.5, patch_size=(8, 16, 8)); args.update(kw)
+        seg, prob = predict_3D(net, vol, **args)
+        assert np.allclose(prob, ref, atol=2e-6) and np.allclose(prob.sum(0), 1.0, atol=1e-5)
+        assert (seg == ref.argmax(0)).mean() > 0.9999
+    seg, prob = predict_3D(net, vol[:, :5], do_mirroring=False, mirror_axes=(), step_size=0.5, patch_size=(8, 16, 8))
+    assert prob.shape == (3, 5, 30, 17) and np.allclose(prob, ref[:, :5], atol=2e-6)
