@@ -225,3 +225,80 @@ def test_checkpoint_interoperates_with_torch_optimizer_and_upstream_layout(tmp_p
     s = by_name[names[3]]._lnn_slot
     assert torch.equal(tr2.network.arena.momentum[s.offset:s.offset + s.numel], orig3.reshape(-1))
     assert tr2.amp_grad_scaler.get_scale() == tr.amp_grad_scaler.get_scale()
+
+
+def _write_case(folder, name, shape, seed, channels=1):
+    import pickle
+    rng = np.random.RandomState(seed)
+    img = rng.randn(channels, *shape).astype(np.float32)
+    seg = np.zeros(shape, dtype=np.float32)
+    c = [s // 2 for s in shape]
+    seg[c[0] - 2:c[0] + 2, c[1] - 3:c[1] + 3, c[2] - 2:c[2] + 2] = 1
+    seg[c[0] - 1:c[0] + 1, c[1] - 1:c[1] + 1, c[2] - 1:c[2] + 1] = 2
+    np.savez(os.path.join(folder, name + ".npz"), data=np.concatenate([img, seg[None]], 0))
+    locs = {k: np.argwhere(seg == k) for k in (1, 2)}
+    pickle.dump({"class_locations": locs, "size_after_resampling": shape}, open(os.path.join(folder, name + ".pkl"), "wb"))
+    return img, seg
+
+
+def test_preprocessed_data_loader(tmp_path):
+    """lifelong-nnunet_amd/dataloading.py (restated upstream loader -- parity unpinned): crops are
+    exact sub-volumes of their case, foreground oversampling, padding values, split, deep-supervision targets."""
+    from lifelong_nnunet_amd.dataloading import (DataLoader3D, PreprocessedDataProvider, do_split, downsample_seg_for_ds,
+                                                 load_dataset, unpack_dataset)
+    folder = str(tmp_path / "Task900_Toy" / "nnUNetData_plans_v2.1_stage0")
+    os.makedirs(folder)
+    cases = {f"toy_{i:03d}": _write_case(folder, f"toy_{i:03d}", (20 + 2 * i, 24, 18 + i), i) for i in range(10)}
+    ds = load_dataset(folder)
+    assert list(ds.keys()) == sorted(cases) and "class_locations" in ds["toy_000"]["properties"]
+    unpack_dataset(folder)
+    assert os.path.isfile(os.path.join(folder, "toy_003.npy"))
+    tr, val = do_split(ds, 0)
+    from sklearn.model_selection import KFold
+    keys = np.array(sorted(cases))
+    ref_tr, ref_val = next(iter(KFold(n_splits=5, shuffle=True, random_state=12345).split(keys)))
+    assert list(tr) == sorted(keys[ref_tr]) and list(val) == sorted(keys[ref_val]) and not set(tr) & set(val)
+    # ---- every crop is an exact sub-volume; the last round(B * 0.33) samples contain foreground
+    np.random.seed(0)
+    B, ps = 6, (16, 16, 16)
+    dl = DataLoader3D(ds, ps, ps, B, False, oversample_foreground_percent=0.33, pad_mode="constant", memmap_mode="r")
+    assert [dl.get_do_oversample(j) for j in range(B)] == [False] * 4 + [True] * 2
+    for _ in range(5):
+        b = next(dl)
+        assert b["data"].shape == (B, 1) + ps and b["seg"].shape == (B, 1) + ps
+        for j, k in enumerate(b["keys"]):
+            img, seg = cases[k]
+            inside = b["seg"][j, 0] >= 0
+            assert inside.all()                         # all toy cases are larger than the patch: nothing padded
+            # locate the crop: its voxel values must reappear at one offset of the case
+            found = False
+            pos = np.argwhere(np.isclose(img[0], b["data"][j, 0, 0, 0, 0]))
+            for (z, y, x) in pos:
+                if z + ps[0] <= img.shape[1] and y + ps[1] <= img.shape[2] and x + ps[2] <= img.shape[3] and \
+                        np.array_equal(img[0, z:z + ps[0], y:y + ps[1], x:x + ps[2]], b["data"][j, 0]):
+                    assert np.array_equal(seg[z:z + ps[0], y:y + ps[1], x:x + ps[2]], b["seg"][j, 0])
+                    found = True
+                    break
+            assert found
+            if j >= 4:
+                assert (b["seg"][j, 0] > 0).any()
+    # ---- a case smaller than the patch is padded: image with zeros, segmentation with -1
+    small_folder = str(tmp_path / "small")
+    os.makedirs(small_folder)
+    img, seg = _write_case(small_folder, "tiny", (10, 24, 12), 99)
+    dl = DataLoader3D(load_dataset(small_folder), ps, ps, 2, False, oversample_foreground_percent=0.0, pad_mode="constant")
+    b = next(dl)
+    assert (b["seg"] == -1).sum() > 0 and np.all(b["data"][b["seg"] == -1] == 0)
+    assert np.isclose((b["seg"][0, 0] >= 0).sum(), 10 * 16 * 12)
+    # ---- deep-supervision targets: order-0 resize at pixel centres (voxel 2^i * o + 2^(i-1))
+    s = np.arange(2 * 1 * 8 * 8 * 8, dtype=np.float32).reshape(2, 1, 8, 8, 8)
+    t = downsample_seg_for_ds(s, 3)
+    assert [x.shape for x in t] == [(2, 1, 8, 8, 8), (2, 1, 4, 4, 4), (2, 1, 2, 2, 2)]
+    assert np.array_equal(t[1], s[:, :, 1::2, 1::2, 1::2]) and np.array_equal(t[2], s[:, :, 2::4, 2::4, 2::4])
+    # ---- provider contract of the trainers
+    plans = {"patch_size": ps, "batch_size": 2, "num_pool": 3, "base_num_features": 8, "num_classes": 3, "num_input_channels": 1}
+    prov = PreprocessedDataProvider({"Task900_Toy": folder}, fold=0)
+    d = next(prov("Task900_Toy", "train", plans))
+    assert tuple(d["data"].shape) == (2, 1) + ps and [tuple(x.shape) for x in d["target"]] == [(2, 1, 16, 16, 16), (2, 1, 8, 8, 8), (2, 1, 4, 4, 4)]
+    assert set(d["keys"]) <= set(tr) and float(d["target"][0].min()) >= 0
+    assert set(next(prov("Task900_Toy", "val", plans))["keys"]) <= set(val)
