@@ -305,7 +305,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
 #pragma unroll
         for (int ch = 0; ch < TV / 16; ++ch) {
             // chunk rows 2ch, 2ch+1: immediates, the per-lane part lives in p_addr / tapaddr
-            constexpr int dummy = 0; (void)dummy;
             const int pimm = ch * 1024;
             const int qimm = (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64;
             const half4 a0 = lds_tr16(pl + pimm + p_addr), a1 = lds_tr16(pl + pimm + 256 + p_addr);
