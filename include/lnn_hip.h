@@ -255,8 +255,11 @@ int lnn_sgd_nesterov_step_clipped(lnn_stream_t s, float* theta, float* momentum_
  * per phase {issue loads, MFMA, barrier, LDS stores, barrier} and the step count; pass NULL to disable. */
 int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64);
 /* Parity tests only: pin the stride-1 conv forward / dgrad kernel (-1 automatic, 1 generic first version, 5 = v5,
- * 6 = v6, 7 = v7, 8 = v8 where the layer has >= 64 output channels, v5 otherwise).  Process-wide, not thread-safe. */
+ * 7 = v7, 8 = v8 where the layer has >= 64 output channels, 9 = v9 where the layer has 32 / 64 input channels and no
+ * accumulation, v5 otherwise).  Process-wide, not thread-safe: a debug hook, not part of the production surface. */
 int lnn_debug_force_conv_kernel(int which);
+/* Parity tests only: number of z segments the v9 kernel cuts a column into (0 = automatic).  Process-wide. */
+int lnn_debug_set_v9_zseg(int segments);
 
 /* fp32 <-> fp16 helpers for the image input (N,1,D,H,W f32 -> fp16, same memory order when C == 1) */
 int lnn_cast_f32_to_h(lnn_stream_t s, const float* src, void* dst_h, long n);

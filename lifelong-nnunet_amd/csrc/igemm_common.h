@@ -44,8 +44,9 @@ int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);
 int lnn_launch_conv_s1_v7(hipStream_t s, ConvParams& p, const char* name);
 // v8 (igemm_conv_v8.hip): v5 structure with a 64-output-channel register tile (M >= 64)
 int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name);
-// v6 (igemm_conv_v6.hip): two wave groups per block running half a step out of phase (compute / memory ping-pong).
-int lnn_launch_conv_s1_v6(hipStream_t s, ConvParams& p, const char* name);
+// v9 (igemm_conv_v9.hip): z-streaming, register-resident weights, direct-to-LDS input ring (C = 32 / 64, M % 32 == 0)
+bool lnn_conv_s1_v9_supported(const ConvParams& p);
+int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name);
 // single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,
 // all eight output parity classes per block
 int lnn_launch_up2_dgrad(hipStream_t s, ConvParams& p, const char* name);

@@ -324,7 +324,7 @@ extern "C" int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64) { g_dbg = (unsig
 
 // LNN_CONV_V1=1 selects the non-pipelined kernel for the stride-1 convs (A/B measurements only)
 // runtime override for the parity tests (lnn_debug_force_conv_kernel): -1 = automatic selection,
-// 1 = generic first version, 5 / 6 / 7 / 8 = that stride-1 kernel for every layer it supports
+// 1 = generic first version, 5 / 7 / 8 / 9 = that stride-1 kernel for every layer it supports
 int g_force_conv = -1;
 
 bool use_v2() {
@@ -337,16 +337,20 @@ bool use_v2() {
     return v == 1;
 }
 
-// LNN_CONV_V6=1 selects the ping-pong v6 kernel instead of v5 (A/B measurements only; v6 measured 5-15 % slower:
-// a lone wave per SIMD does not keep the matrix pipe busy through its LDS read latencies)
-bool use_v6() {
-    if (g_force_conv >= 0) return g_force_conv == 6;
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LNN_CONV_V6");
-        v = (e && e[0] == '1') ? 1 : 0;
+// v9 (z-streaming, register-resident weights): the kernel for the 32- / 64-input-channel layers of the two highest
+// resolutions.  LNN_CONV_V9=0 forbids it (A/B measurements); lnn_debug_force_conv_kernel(9) forces it wherever supported.
+bool use_v9(const ConvParams& p) {
+    if (!lnn_conv_s1_v9_supported(p)) return false;
+    if (g_force_conv >= 0) return g_force_conv == 9;
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("LNN_CONV_V9");
+        v = e ? (e[0] == '1' ? 1 : 0) : -1;
     }
-    return v == 1;
+    if (v == 0) return false;
+    if (v == 1) return true;
+    // automatic: long z columns only (the column walk has ~4 plane steps of fixed cost per item)
+    return p.Ld >= 32;
 }
 
 // LNN_UP2_V1=1 selects the one-launch-per-parity-class path for stride-2 dgrad / convT forward (A/B measurements only)
@@ -409,7 +413,7 @@ int check_act(const void* ptr, int ld, int C, const char* what) {
 }  // namespace
 
 extern "C" int lnn_debug_force_conv_kernel(int which) {
-    LNN_REQUIRE(which == -1 || which == 1 || (which >= 5 && which <= 8), "lnn_debug_force_conv_kernel: %d is not one of -1, 1, 5, 6, 7, 8", which);
+    LNN_REQUIRE(which == -1 || which == 1 || which == 5 || (which >= 7 && which <= 9), "lnn_debug_force_conv_kernel: %d is not one of -1, 1, 5, 7, 8, 9", which);
     g_force_conv = which;
     return LNN_OK;
 }
@@ -450,9 +454,10 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
             p.taps.slot[t] = (unsigned char)t;
         }
         p.dbg = g_dbg;
+        if (use_v2() && use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9)");
         if (use_v2() && use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_fwd(s1,v8)");
         if (use_v2() && use_v7(p.C)) return lnn_launch_conv_s1_v7(s, p, "lnn_conv3d_fwd(s1,v7)");
-        if (use_v2()) return use_v6() ? lnn_launch_conv_s1_v6(s, p, "lnn_conv3d_fwd(s1,v6)") : lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
+        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
     if (use_down2()) return lnn_launch_down2_conv(s, p, "lnn_conv3d_fwd(s2,down2)");
@@ -472,7 +477,7 @@ int check_cat(const void* b, int c_a, int C, int stride, const char* what) {
     LNN_REQUIRE(b != nullptr && lnn_aligned16(b), "%s: second tensor null/misaligned", what);
     LNN_REQUIRE(stride == 1, "%s: stride 1 only", what);
     LNN_REQUIRE(c_a > 0 && c_a < C && c_a % 32 == 0 && (C - c_a) % 8 == 0, "%s: split %d of %d channels must be a multiple of 32", what, c_a, C);
-    LNN_REQUIRE(use_v2() && !use_v6(), "%s: not supported by the generic first-version / v6 kernels (forced kernel 1 / 6)", what);
+    LNN_REQUIRE(use_v2(), "%s: not supported by the generic first-version kernel (forced kernel 1)", what);
     return LNN_OK;
 }
 }  // namespace
@@ -516,9 +521,10 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
         p.dbg = g_dbg;
+        if (use_v2() && use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad(s1,v9)");
         if (use_v2() && use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_dgrad(s1,v8)");
         if (use_v2() && use_v7(p.C)) return lnn_launch_conv_s1_v7(s, p, "lnn_conv3d_dgrad(s1,v7)");
-        if (use_v2()) return use_v6() ? lnn_launch_conv_s1_v6(s, p, "lnn_conv3d_dgrad(s1,v6)") : lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
+        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
     }
     // stride 2: dx[2l+par] = sum over taps d with (par - d + 1) even: dy[l + (par - d + 1)/2]

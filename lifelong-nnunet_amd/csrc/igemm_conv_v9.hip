@@ -1,0 +1,417 @@
+// Stride-1 3x3x3 implicit-GEMM convolution, z-streaming with register-resident weights (v9).
+//
+// Replaces nn.Conv3d forward / data gradient (test/network_architecture/test_MultiHead_Module.py:346-415) for the
+// layers of the two highest resolutions, where the input has 32 or 64 channels.  Same GEMM mapping as the other
+// kernels (v_mfma_f32_32x32x16_f16: rows = 32 output channels, columns = 32 voxels, contraction = 16 input channels
+// of one tap); what changed is WHERE the operands live.  v5 / v8 read both MFMA operands from LDS for every MFMA
+// (1.0 - 1.5 KB of ds_read_b128 per MFMA: LDS-feed-limited at ~30 % of the matrix peak).  Here:
+//   * a wave owns ONE 16-channel chunk of the input channels and ONE 32-row block of output channels and keeps the 27
+//     weight fragments of that (block, chunk) in 108 VGPRs for the whole launch: no A-operand traffic at all;
+//   * a wave owns a 4 (y) x 8 (x) footprint and walks it along z.  The B fragment of input plane zi at in-plane shift
+//     (dy, dx) is read ONCE from LDS and feeds three MFMAs: output planes zi+1, zi, zi-1 with taps dz = 0, 1, 2
+//     (three rolling accumulators): 9 ds_read_b128 per 27 MFMAs = 0.33 KB of LDS reads per MFMA;
+//   * the channel chunks of one footprint are spread over NCK waves; their partial sums meet in LDS once per output
+//     plane (each wave finalises 32 / NCK of the channels: balanced, and the NCK = 2 case ends in 16-byte stores
+//     after a v_permlane32_swap);
+//   * input planes (footprint + 1 halo, all channel groups) are brought into an LDS ring by direct-to-LDS buffer
+//     loads (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass; out-of-volume positions use the
+//     buffer descriptor's range check (offset 0x80000000 / num_records = 0 -> zeros land in LDS), and the epilogue
+//     stores drop out-of-volume lanes the same way, so the steady-state loop has no branches;
+//   * the z halo is free (a column is walked continuously); the in-plane halo is shared between neighbouring blocks
+//     through the XCD's L2: blocks are placed so that the 32 CUs of an XCD work on adjacent columns.
+// LDS layout of a plane slab: [32-channel group][py][px (row stride PXS)][4 x 16 bytes]; the 16-byte piece index is
+// XOR-keyed with ((px >> 2) & 1) | ((py & 1) << 1): with the lane -> voxel map below every ds_read_b128 16-lane
+// group reads 16 distinct 16-byte bank slots for all 9 in-plane shifts (conflict free).  The DMA writes LDS linearly
+// (wave-uniform base + lane * 16), so the key is applied to the SOURCE piece each lane fetches.
+#include "igemm_common.h"
+
+namespace {
+
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int V>
+struct IC { static constexpr int value = V; };
+
+// s_waitcnt vmcnt(N) [lgkmcnt(0)] with a literal count (an "n" operand that depends on a template parameter makes the
+// host pass drop the kernel's instantiation without a diagnostic).  The "memory" clobber is what keeps the compiler from
+// moving LDS accesses across the wait / the raw s_barrier that follows it.
+template <int N, bool LGKM>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 6, "extend the table");
+    if constexpr (LGKM) {
+        if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    } else {
+        if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+}
+
+// 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16), range-checked by the buffer descriptor.
+// A plain (non-template) device function: inside the kernel template the host pass drops the instantiation silently.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
+__device__ __forceinline__ void lane_voxel9(int v, int& r, int& x) {   // see igemm_conv_v2.hip
+    if (v < 4) { r = 0; x = v; }
+    else if (v < 12) { r = 2; x = v - 4; }
+    else if (v < 16) { r = 0; x = v - 8; }
+    else if (v < 20) { r = 3; x = v - 16; }
+    else if (v < 28) { r = 1; x = v - 20; }
+    else { r = 3; x = v - 24; }
+}
+
+// NCK input-channel chunks (C = 16 NCK) x NMB output-channel blocks (32 NMB per item) x NF footprints = 8 waves
+template <int NCK_, int NMB_, int NF_>
+struct V9 {
+    static constexpr int NCK = NCK_, NMB = NMB_, NF = NF_;
+    static_assert(NCK * NMB * NF == 8 && (NCK == 2 || NCK == 4), "8 waves per block");
+    static constexpr int NG = NCK / 2;                       // 32-channel groups of the input
+    static constexpr int NFX = NF >= 4 ? 2 : 1, NFY = NF / NFX;
+    static constexpr int FY = 4 * NFY, FX = 8 * NFX;         // block footprint
+    static constexpr int PY = FY + 2, PX = FX + 2, PXS = (PX + 3) / 4 * 4;
+    static constexpr int GRAW = PY * PXS * 64;               // bytes of one group slab
+    static constexpr int DPW = (NG * ((GRAW + 1023) / 1024) + 7) / 8;   // DMA instructions per wave per plane
+    static constexpr int GSLAB = DPW * 8 / NG * 1024;
+    static_assert(GSLAB >= GRAW && (DPW * 8) % NG == 0, "slab padding");
+    static constexpr int PLANE = NG * GSLAB;
+    static constexpr int D = 4, R = 5;                       // planes in flight / ring slots (R >= D + 1)
+    static constexpr int QN = 4 / NCK;                       // accumulator quads a wave finalises
+    static constexpr int EXB = NF * NMB * NCK * (NCK - 1) * QN * 1024;   // one partial-sum exchange buffer
+    static constexpr int LDS = R * PLANE + 2 * EXB;
+};
+
+struct V9Launch {
+    int items, S, L, tiles_y, tiles_x, nslots, ipx;
+};
+
+template <int NCK_, int NMB_, int NF_>
+__global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvParams p, const V9Launch q) {
+    using K = V9<NCK_, NMB_, NF_>;
+    constexpr int NCK = K::NCK, NMB = K::NMB, NFX = K::NFX, PXS = K::PXS, PY = K::PY, PX = K::PX;
+    constexpr int GSLAB = K::GSLAB, PLANE = K::PLANE, DPW = K::DPW, D = K::D, R = K::R, QN = K::QN, EXB = K::EXB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const exch = smem + R * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ck = wave % NCK, mb = (wave / NCK) % NMB, f = wave / (NCK * NMB);
+    const int fxi = f % NFX, fyi = f / NFX, gi = f * NMB + mb;
+    const int hk = lane >> 5, v = lane & 31;
+    int vr, vx;
+    lane_voxel9(v, vr, vx);
+
+    // ---- B-fragment read addresses: lbase[dx][parity of dy] + dy * PXS * 64 + ring slot ----------------------------
+    int lbase[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int py0 = 4 * fyi + vr, px = 8 * fxi + vx + dx;
+            const int key = ((px >> 2) & 1) | (((py0 + par) & 1) << 1);
+            lbase[dx][par] = (ck >> 1) * GSLAB + (py0 * PXS + px) * 64 + (((((ck & 1) << 1) | hk) ^ key) << 4);
+        }
+
+    // ---- DMA lane constants (item independent) ----------------------------------------------------------------------
+    int drel[DPW], dpk[DPW];
+    const half_t* gten[DPW];
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {
+        const int j = wave * DPW + k;
+        const int gg = (j * 1024) / GSLAB;                   // wave-uniform: a DMA instruction never straddles groups
+        const int cc = j * 64 + lane - gg * (GSLAB / 16);
+        const int pos = cc >> 2, pc = cc & 3, py = pos / PXS, pxs = pos % PXS;
+        const int key = ((pxs >> 2) & 1) | ((py & 1) << 1);
+        const int cabs = 32 * gg;
+        const bool part2 = cabs >= p.csplit;
+        gten[k] = part2 ? p.x2 : p.x;
+        drel[k] = (((py - 1) * p.Wi + (pxs - 1)) * p.ld_x + (part2 ? cabs - p.csplit : cabs) + (pc ^ key) * 8) * 2;
+        dpk[k] = (py < PY && pxs < PX) ? (py | (pxs << 8)) : -1;
+    }
+    const unsigned in_plane_bytes = (unsigned)p.Hi * p.Wi * p.ld_x * 2u;
+    const unsigned out_plane_bytes = (unsigned)p.Ho * p.Wo * p.ld_y * 2u;
+
+    // ---- partial-sum exchange addresses ------------------------------------------------------------------------------
+    const int rbase = (gi * NCK + ck) * (NCK - 1) * QN * 1024 + lane * 16;
+    int wbase[NCK - 1];
+#pragma unroll
+    for (int jj = 1; jj < NCK; ++jj)
+        wbase[jj - 1] = ((gi * NCK + (ck + jj) % NCK) * (NCK - 1) + (NCK - jj - 1)) * QN * 1024 + lane * 16;
+
+    half8 A[27];
+    float biasv[4 * QN];
+    int cur_mg = -1;
+    floatx16 acc[3];
+    half8 b[3];
+    float own[4 * QN];
+#pragma unroll
+    for (int i = 0; i < 4 * QN; ++i) own[i] = 0.f;
+    const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int xcd = blockIdx.x & 7, cu_slot = blockIdx.x >> 3;
+
+#pragma unroll 1
+    for (int round = 0;; ++round) {
+        const int local = round * q.nslots + cu_slot;
+        if (local >= q.ipx) break;
+        int it = xcd * q.ipx + local;
+        if (it >= q.items) break;
+        const int fxb = it % q.tiles_x; it /= q.tiles_x;
+        const int fyb = it % q.tiles_y; it /= q.tiles_y;
+        const int zs = it % q.S; it /= q.S;
+        const int n = it % p.N;
+        const int mg = it / p.N;
+        const int y0 = fyb * K::FY, x0 = fxb * K::FX;
+        const int zs0 = zs * q.L, zs1 = min(zs0 + q.L, p.Ld);
+        const int T = zs1 - zs0 + 2;
+
+        // ---- weights of this wave's (output block, chunk): 27 fragments, resident until the block changes ----
+        const int m0 = 32 * (mg * NMB + mb);
+        if (mg != cur_mg) {
+            cur_mg = mg;
+            // MFMA row rho of a wave with chunk role ck holds output channel m0 + ((rho + 8 QN ck) & 31): the rows a wave
+            // finalises are always its accumulator quads [0, QN)
+            const int row = ((lane & 31) + 8 * QN * ck) & 31;
+#pragma unroll
+            for (int tl = 0; tl < 27; ++tl) {
+                const half_t* wp = p.wp + lnn_panel_off(p.taps.slot[tl], m0, 16 * ck, 27, p.KCpad);
+                A[tl] = *reinterpret_cast<const half8*>(wp + row * 16 + hk * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 4 * QN; ++i) biasv[i] = 0.f;
+            if (p.bias) {
+                // the channels of this lane's own accumulator quads: quad qq, register i -> m0 + 8 QN ck + 8 qq + 4 hk + i
+#pragma unroll
+                for (int i = 0; i < 4 * QN; ++i) biasv[i] = p.bias[m0 + 8 * QN * ck + 8 * (i >> 2) + 4 * hk + (i & 3)];
+            }
+        }
+
+        // ---- per-item lane offsets ----
+        int dvoff[DPW];
+#pragma unroll
+        for (int k = 0; k < DPW; ++k) {
+            const int py = dpk[k] & 255, pxs = (dpk[k] >> 8) & 255;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + pxs;
+            const bool ok = dpk[k] >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            dvoff[k] = ok ? drel[k] + (y0 * p.Wi + x0) * p.ld_x * 2 : (int)0x80000000;
+        }
+        int svoff;
+        half_t* yten;
+        {
+            const int oy = y0 + 4 * fyi + vr, ox = x0 + 8 * fxi + vx;
+            const bool ok = oy < p.Lh && ox < p.Lw;
+            const bool part2 = m0 >= p.msplit;
+            yten = part2 ? p.y2 : p.y;
+            const int ch = (part2 ? m0 - p.msplit : m0) + (NCK == 2 ? 16 * ck + 8 * hk : 8 * ck + 4 * hk);
+            svoff = ok ? ((oy * p.Wo + ox) * p.ld_y + ch) * 2 : (int)0x80000000;
+        }
+
+        // running plane pointers / ring offsets (scalar): no multiplications in the plane loop
+        const long in_plane = (long)p.Hi * p.Wi * p.ld_x, out_plane = (long)p.Ho * p.Wo * p.ld_y;
+        const half_t* din[DPW];
+#pragma unroll
+        for (int k = 0; k < DPW; ++k) din[k] = gten[k] + ((long)n * p.Di + (zs0 - 1)) * in_plane;
+        const int tp_lo = zs0 >= 1 ? 0 : 1;                            // planes tp in [tp_lo, tp_hi) lie inside the volume
+        const int tp_hi = min(T, p.Di - (zs0 - 1));
+        int dtp = 0, dslot_off = 0;
+        auto dma = [&]() {                  // next plane of this item (input z = zs0 - 1 + dtp) -> next ring slot
+            const bool zok = dtp >= tp_lo && dtp < tp_hi;
+            const int nrec = zok ? (int)in_plane_bytes : 0;
+#pragma unroll
+            for (int k = 0; k < DPW; ++k) {
+                const int j = wave * DPW + k;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)din[k], 0, nrec, 0x00020000);
+                dma16(rs, smem + dslot_off + j * 1024, dvoff[k]);
+                din[k] += in_plane;
+            }
+            ++dtp;
+            dslot_off = dslot_off + PLANE == R * PLANE ? 0 : dslot_off + PLANE;
+        };
+
+        // output plane completed at step tprev (z = zs0 + tprev - 2): own quads + the other chunks' partial sums -> y.
+        // Split in two so that the LDS reads are in flight while the first MFMAs of the step issue.
+        half_t* optr = yten + ((long)n * p.Do + (zs0 - 3)) * out_plane;      // plane of tprev = -1
+        floatx4 pv[(NCK - 1) * QN];
+        auto fin_load = [&](int tprev) {
+            const char* eb = exch + (tprev & 1) * EXB + rbase;
+#pragma unroll
+            for (int s = 0; s < (NCK - 1) * QN; ++s) pv[s] = *reinterpret_cast<const floatx4*>(eb + s * 1024);
+        };
+        auto fin_store = [&](int tprev) {
+            const bool ov = tprev >= 2 && tprev < T;
+            float fin[4 * QN];
+#pragma unroll
+            for (int i = 0; i < 4 * QN; ++i) fin[i] = own[i];
+#pragma unroll
+            for (int s = 0; s < (NCK - 1) * QN; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fin[(s % QN) * 4 + i] += pv[s][i];
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)optr, 0, ov ? (int)out_plane_bytes : 0, 0x00020000);
+            optr += out_plane;
+            if constexpr (NCK == 2) {
+                // lane l holds channels {4hk..4hk+3} of both quads, lane l+32 the other four of each: pack to fp16 and
+                // exchange halves (vdst = quad 0, src = quad 1) so that every lane ends with 8 consecutive channels
+                // (lanes < 32: [own quad 0 | upper's quad 0], lanes >= 32: [lower's quad 1 | own quad 1]) -> ONE 16-byte store
+                const half2v a0 = {(half_t)(fin[0] + biasv[0]), (half_t)(fin[1] + biasv[1])};
+                const half2v a1 = {(half_t)(fin[2] + biasv[2]), (half_t)(fin[3] + biasv[3])};
+                const half2v b0 = {(half_t)(fin[4] + biasv[4]), (half_t)(fin[5] + biasv[5])};
+                const half2v b1 = {(half_t)(fin[6] + biasv[6]), (half_t)(fin[7] + biasv[7])};
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+                const uint4v o = {s0[0], s1[0], s0[1], s1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs, svoff, 0, 0);
+            } else {
+                half4 o4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[i] = (half_t)(fin[i] + biasv[i]);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2v, o4), rs, svoff, 0, 0);
+            }
+        };
+
+        auto ldb = [&](int slot_off, int i) -> half8 {      // i = dy * 3 + dx (compile time after unrolling)
+            const int dy = i / 3, dx = i % 3;
+            return *reinterpret_cast<const half8*>(smem + slot_off + lbase[dx][dy & 1] + dy * PXS * 64);
+        };
+
+        // ---- prologue: first D planes in flight, planes 0 and 1 landed ----
+#pragma unroll
+        for (int tp = 0; tp < D; ++tp) dma();
+        wait_vm<(D - 2) * DPW, false>();
+        __builtin_amdgcn_s_barrier();
+        b[0] = ldb(0, 0);
+        b[1] = ldb(0, 1);
+        int ro = 0;
+
+        auto step = [&](auto U_, int t) {
+            constexpr int U = decltype(U_)::value;
+            fin_load(t - 1);
+            dma();
+            const int rn = ro + PLANE == R * PLANE ? 0 : ro + PLANE;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (i == 3) fin_store(t - 1);
+                const int ii = i + 2;
+                b[ii % 3] = ii < 9 ? ldb(ro, ii) : ldb(rn, ii - 9);
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int a = (U + 1 - dz + 3) % 3;
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[dz * 9 + i], b[i % 3], (i == 0 && dz == 0) ? zero16 : acc[a], 0, 0, 0);
+                }
+            }
+            ro = rn;
+            // publish the completed accumulator: own quads stay in registers, the rest goes to the waves that finalise them
+            constexpr int c = (U + 2) % 3;
+#pragma unroll
+            for (int i = 0; i < 4 * QN; ++i) own[i] = acc[c][i];
+            char* eb = exch + (t & 1) * EXB;
+#pragma unroll
+            for (int jj = 1; jj < NCK; ++jj)
+#pragma unroll
+                for (int qi = 0; qi < QN; ++qi) {
+                    const int r0 = (jj * QN + qi) * 4;
+                    const floatx4 w = {acc[c][r0], acc[c][r0 + 1], acc[c][r0 + 2], acc[c][r0 + 3]};
+                    *reinterpret_cast<floatx4*>(eb + wbase[jj - 1] + qi * 1024) = w;
+                }
+            wait_vm<(D - 2) * DPW, true>();
+            __builtin_amdgcn_s_barrier();
+        };
+
+        // T plane steps + one more that stores the last output plane, rounded up to the 3-step accumulator rotation
+        // (the extra steps run on zero planes and store nothing)
+        const int T3 = (T + 1 + 2) / 3 * 3;
+#pragma unroll 1
+        for (int t = 0; t < T3; t += 3) {
+            step(IC<0>{}, t);
+            step(IC<1>{}, t + 1);
+            step(IC<2>{}, t + 2);
+        }
+        wait_vm<0, true>();
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+int g_v9_zseg = 0;     // lnn_debug_set_v9_zseg (parity tests): 0 = automatic
+
+template <class K>
+int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
+    const int tiles_y = lnn_cdiv(p.Lh, K::FY), tiles_x = lnn_cdiv(p.Lw, K::FX);
+    const int mgroups = p.M / (32 * K::NMB);
+    const long cols = (long)mgroups * p.N * tiles_y * tiles_x;
+    int G = num_cu / 8 * 8;
+    if (G < 8) G = 8;
+    // z segments: a column is walked continuously (2 extra plane steps per segment), so prefer few segments; split only
+    // when the columns alone cannot balance the chip
+    int bestS = 1;
+    double best = 1e30;
+    const int forceS = g_v9_zseg;
+    for (int S = 1; S <= 16 && S <= p.Ld; ++S) {
+        const int L = lnn_cdiv(p.Ld, S);
+        if ((long)(S - 1) * L >= p.Ld) continue;                    // empty last segment
+        const long items = cols * S;
+        const double cost = (double)lnn_cdiv(lnn_cdiv(items, 8), G / 8) * (L + 2 + 3);
+        if (cost < best * 0.97) { best = cost; bestS = S; }
+    }
+    if (forceS > 0 && forceS <= p.Ld && (long)(forceS - 1) * lnn_cdiv(p.Ld, forceS) < p.Ld) bestS = forceS;
+    V9Launch q;
+    q.S = bestS; q.L = lnn_cdiv(p.Ld, bestS); q.tiles_y = tiles_y; q.tiles_x = tiles_x;
+    q.items = (int)(cols * bestS);
+    q.ipx = lnn_cdiv(q.items, 8);
+    q.nslots = G / 8;
+    if (q.nslots > q.ipx) q.nslots = q.ipx;
+    const int grid = q.nslots * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF>), dim3(grid), dim3(512), K::LDS, s, p, q);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
+
+}  // namespace
+
+extern "C" int lnn_debug_set_v9_zseg(int segments) {
+    LNN_REQUIRE(segments >= 0 && segments <= 64, "lnn_debug_set_v9_zseg: %d out of range", segments);
+    g_v9_zseg = segments;
+    return LNN_OK;
+}
+
+bool lnn_conv_s1_v9_supported(const ConvParams& p) {
+    if (p.accumulate || p.os != 1) return false;
+    if (p.C != 32 && p.C != 64) return false;
+    if (p.M % 32 != 0) return false;
+    if (p.ld_x % 8 != 0 || p.ld_y % 8 != 0) return false;
+    if (p.csplit != 0x7fffffff && p.csplit % 32 != 0) return false;
+    if (p.msplit != 0x7fffffff && p.msplit % 32 != 0) return false;
+    if ((double)p.Hi * p.Wi * p.ld_x * 2.0 >= 2147483648.0 || (double)p.Ho * p.Wo * p.ld_y * 2.0 >= 2147483648.0) return false;
+    return true;
+}
+
+int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name) {
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    if (p.C == 32) {
+        if (p.M % 64 == 0) return launch_v9<V9<2, 2, 2>>(s, p, num_cu, name);
+        return launch_v9<V9<2, 1, 4>>(s, p, num_cu, name);
+    }
+    if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>>(s, p, num_cu, name);
+    return launch_v9<V9<4, 1, 2>>(s, p, num_cu, name);
+}

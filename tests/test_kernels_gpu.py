@@ -376,12 +376,15 @@ def test_batch_dice_data_parallel_exchange_equals_full_batch():
     assert float((got - dfull).abs().max()) <= 1e-6 * float(dfull.abs().max())
 
 
-@pytest.mark.parametrize("which", [1, 5, 6, 7, 8])
+@pytest.mark.parametrize("which", [1, 5, 7, 8, 9])
 def test_every_stride1_conv_kernel_variant(which):
-    """The automatic selection picks v5 / v7 / v8 by layer shape, so the small parity shapes above only exercise v5:
+    """The automatic selection picks v5 / v7 / v8 / v9 by layer shape, so the small parity shapes above only exercise v5:
     pin each shipped stride-1 kernel in turn and run forward + dgrad (with and without accumulation) on all
-    stride-1 cases, including ragged extents and output channels that are not a multiple of 64."""
-    cases = [c for c in CONV_CASES if c[6] == 1] + [(1, 32, 96, 9, 8, 17, 1), (2, 128, 64, 8, 8, 8, 1), (1, 24, 160, 5, 6, 7, 1)]
+    stride-1 cases, including ragged extents and output channels that are not a multiple of 64.  The 32- / 64-channel
+    cases cover the four wave-role configurations of v9 (chunks x output blocks x footprints), forward and dgrad."""
+    cases = [c for c in CONV_CASES if c[6] == 1] + [(1, 32, 96, 9, 8, 17, 1), (2, 128, 64, 8, 8, 8, 1), (1, 24, 160, 5, 6, 7, 1),
+                                                    (1, 32, 64, 7, 9, 18, 1), (1, 64, 64, 6, 10, 9, 1), (2, 64, 128, 5, 12, 9, 1),
+                                                    (1, 32, 32, 37, 5, 21, 1)]
     assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
     try:
         for (N, C, K, D, H, W, s) in cases:
@@ -390,6 +393,32 @@ def test_every_stride1_conv_kernel_variant(which):
                 test_conv3d_dgrad(N, C, K, D, H, W, s, acc)
     finally:
         nat.lib().lnn_debug_force_conv_kernel(-1)
+
+
+@pytest.mark.parametrize("zseg", [2, 3, 5])
+def test_v9_z_segments(zseg):
+    """v9 walks a column of output planes; long columns can be cut into z segments (item = column x segment): every cut
+    must reproduce the unsegmented result bit for bit (each segment re-reads one halo plane on either side)."""
+    N, C, K, D, H, W = 1, 32, 32, 23, 9, 17
+    x = _rand((N, C, D, H, W), 1)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3))
+    ref = F.conv3d(x, w, b, padding=1)
+    xb, _ = to_cl_h(x)
+    wp = pack_conv_fwd(w.to(DEV))
+    outs = []
+    try:
+        assert nat.lib().lnn_debug_force_conv_kernel(9) == 0
+        for z in (1, zseg):
+            assert nat.lib().lnn_debug_set_v9_zseg(z) == 0
+            yb = torch.zeros((N, D, H, W, K), dtype=torch.float16, device=DEV)
+            nat.call("lnn_conv3d_fwd", xb, C, wp, b.to(DEV), yb, K, N, D, H, W, C, K, 1)
+            outs.append(yb)
+    finally:
+        nat.lib().lnn_debug_set_v9_zseg(0)
+        nat.lib().lnn_debug_force_conv_kernel(-1)
+    assert rel_err(from_cl_h(outs[0], K), ref) < 2e-3
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("N,Ca,Cb,K,D,H,W", [(2, 32, 32, 32, 8, 16, 8), (1, 32, 32, 64, 9, 8, 17), (1, 64, 32, 96, 5, 9, 11)])
@@ -407,7 +436,7 @@ def test_conv3d_cat_ops_match_concatenated_tensor(N, Ca, Cb, K, D, H, W):
     xc = torch.zeros((N, D, H, W, ld), dtype=torch.float16, device=DEV); xc[..., :Cb] = xb[..., Ca:]
     dyb, _ = to_cl_h(dy)
     wf, wd = pack_conv_fwd(w), pack_conv_dgrad(w)
-    for which in (-1, 5, 7, 8):
+    for which in (-1, 5, 7, 8, 9):
         assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
         try:
             y1 = torch.empty((N, D, H, W, K), dtype=torch.float16, device=DEV); y2 = torch.empty_like(y1)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--phases", action="store_true", help="print the v3 conv kernel's per-phase cycle split")
+    ap.add_argument("--check", default="", help="comma list of forced kernels (e.g. 5,9): run fwd/dgrad with each and compare outputs")
     a = ap.parse_args()
     dev = "cuda:0"
     for name in a.layers.split(","):
@@ -80,6 +81,20 @@ def main():
             t = e0.elapsed_time(e1) / a.iters * 1e-3
             out.append(f"{k} {t*1e3:7.3f} ms {flops/t/1e12:6.0f} TF/s")
         print(f"{name:9s} {C:4d}->{K:<4d} @{D}x{H}x{W} s{s} : " + " | ".join(out), flush=True)
+        if a.check and s == 1:
+            res = {}
+            for which in [int(t) for t in a.check.split(",")]:
+                nat.lib().lnn_debug_force_conv_kernel(which)
+                y.zero_(); dx.zero_()
+                fns["fwd"](); fns["dgrad"](); torch.cuda.synchronize()
+                res[which] = (y.float().clone(), dx.float().clone())
+            nat.lib().lnn_debug_force_conv_kernel(-1)
+            ks = list(res)
+            for k in ks[1:]:
+                dfy = float((res[k][0] - res[ks[0]][0]).abs().max()); dfx = float((res[k][1] - res[ks[0]][1]).abs().max())
+                print(f"   check kernel {k} vs {ks[0]}: fwd max|diff| {dfy:.3e} (max|y| {float(res[ks[0]][0].abs().max()):.2f})  "
+                      f"dgrad max|diff| {dfx:.3e} (max|dx| {float(res[ks[0]][1].abs().max()):.2f})", flush=True)
+            del res
         if a.phases and s == 1:
             dbg = torch.zeros(6, dtype=torch.int64, device=dev)
             nat.lib().lnn_debug_set_phase_buffer(dbg.data_ptr())
