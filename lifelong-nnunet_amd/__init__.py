@@ -15,6 +15,7 @@ TRAINER_MAP = {
     "mib": "lifelong_nnunet_amd.training.network_training.mib.nnUNetTrainerMiB:nnUNetTrainerMiB",
     "lwf": "lifelong_nnunet_amd.training.network_training.lwf.nnUNetTrainerLWF:nnUNetTrainerLWF",
     "rehearsal": "lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal:nnUNetTrainerRehearsal",
+    "rehearsal_ewc": "lifelong_nnunet_amd.training.network_training.rehearsal_ewc.nnUNetTrainerRehearsalEWC:nnUNetTrainerRehearsalEWC",
 }
 
 

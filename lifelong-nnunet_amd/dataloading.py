@@ -188,17 +188,27 @@ class PreprocessedDataProvider:
         self.unpack = unpack
         self.extra_train = extra_train or {}         # task -> dataset entries mixed in (rehearsal, REH.py:130-136)
 
-    def __call__(self, task, split, plans):
+    # ---- the three hooks nnUNetTrainerRehearsal uses to build its fused training set from real folders (REH.py:105-164)
+    def dataset_for(self, task):
         folder = self.folders[str(task)]
         if self.unpack:
             unpack_dataset(folder)
-        tr, val = do_split(load_dataset(folder), self.fold, os.path.join(os.path.dirname(folder), "splits_final.pkl"))
+        return load_dataset(folder)
+
+    def splits_file_for(self, task):
+        return os.path.join(os.path.dirname(self.folders[str(task)]), "splits_final.pkl")
+
+    def generator_for(self, dataset, plans, split="train"):
+        loader = DataLoader3D(dataset, plans["patch_size"], plans["patch_size"], plans["batch_size"], False,
+                              oversample_foreground_percent=self.oversample, pad_mode="constant", memmap_mode='r')
+        return _DictAdapter(loader, plans["num_pool"])
+
+    def __call__(self, task, split, plans):
+        tr, val = do_split(self.dataset_for(task), self.fold, self.splits_file_for(task))
         ds = OrderedDict(tr) if split == "train" else val
         if split == "train":
             ds.update(self.extra_train.get(str(task), {}))
-        loader = DataLoader3D(ds, plans["patch_size"], plans["patch_size"], plans["batch_size"], False,
-                              oversample_foreground_percent=self.oversample, pad_mode="constant", memmap_mode='r')
-        return _DictAdapter(loader, plans["num_pool"])
+        return self.generator_for(ds, plans, split)
 
 
 class _DictAdapter:

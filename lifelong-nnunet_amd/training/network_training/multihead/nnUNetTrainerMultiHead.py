@@ -12,6 +12,7 @@ the reference's data dicts ``{'data','target','keys'}`` (MH.py:606-608).
 """
 from __future__ import annotations
 
+import warnings
 from collections import OrderedDict
 from typing import Callable, Dict, Optional
 
@@ -80,6 +81,8 @@ class nnUNetTrainerMultiHead:
         self.trainer_model = network
         self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
         self.subject_names_raw = []
+        self._last_eval_keys = None
+        self.eval_names_from_same_batch = False       # False = the reference's tee() pairing in _perform_validation
         self.all_tr_losses, self.all_val_losses = [], []
         self.validation_results = dict()
         self.amp_grad_scaler = None
@@ -164,7 +167,11 @@ class nnUNetTrainerMultiHead:
             self.all_tr_losses.append(float(np.mean(tr)))
             with torch.no_grad():
                 self.network.eval()
-                va = [self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)]
+                va = []
+                for _ in range(self.num_val_batches_per_epoch):
+                    va.append(self.run_iteration(self.val_gen, False, True))
+                    if self._last_eval_keys is not None:       # epoch-end evaluation pairs every batch with its own names
+                        self.subject_names_raw.append(np.asarray(self._last_eval_keys))
                 if va:
                     self.all_val_losses.append(float(np.mean(va)))
             self.on_epoch_end()
@@ -173,8 +180,7 @@ class nnUNetTrainerMultiHead:
 
     def on_epoch_end(self):
         if self.online_eval_tp:
-            self.validation_results.setdefault(str(self.epoch), {})[str(self.task)] = \
-                self.finish_online_evaluation_extended(self.task)
+            self.last_online_eval = self.finish_online_evaluation_extended(self.task)
         self.maybe_update_lr()
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, detach=True, no_loss=False):
@@ -206,6 +212,7 @@ class nnUNetTrainerMultiHead:
             self.optimizer.step(inv_scale=inv, max_norm=12.0)      # clip coefficient + inf-skip applied on device
         if run_online_evaluation:
             self.run_online_evaluation(output, target)
+            self._last_eval_keys = data_dict.get('keys')
         if do_backprop:
             self.mh_network.update_after_iteration()
         if no_loss:
@@ -236,21 +243,45 @@ class nnUNetTrainerMultiHead:
         self.online_eval_tp.append(c[:, :, 0]); self.online_eval_fp.append(c[:, :, 1]); self.online_eval_fn.append(c[:, :, 2])
 
     def finish_online_evaluation_extended(self, task, unique_subject_names=None):
-        """MH.py:963-1049 reduced to its arithmetic: Dice = 2TP/(2TP+FP+FN), IoU = TP/(TP+FP+FN) per class,
-        NaN (0/0) entries dropped from the mean (MH.py:1015-1022)."""
-        tp = np.concatenate(self.online_eval_tp, 0); fp = np.concatenate(self.online_eval_fp, 0)
-        fn = np.concatenate(self.online_eval_fn, 0)
-        with np.errstate(invalid='ignore', divide='ignore'):
-            dice = 2 * tp / (2 * tp + fp + fn)
-            iou = tp / (tp + fp + fn)
-        res = {"mean_dice_per_class": np.nanmean(dice, 0).tolist(), "mean_iou_per_class": np.nanmean(iou, 0).tolist(),
-               "mean_dice": float(np.nanmean(dice)), "mean_iou": float(np.nanmean(iou))}
-        self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], []
-        return res
+        """MH.py:963-1049.  TP / FP / FN of all samples that carry the same subject name (``self.subject_names_raw``, one
+        array of names per evaluated batch, MH.py:802,819) are SUMMED first; Dice = 2TP/(2TP+FP+FN) and
+        IoU = TP/(TP+FP+FN) are then taken per subject and foreground class and stored under
+        ``self.validation_results['epoch_<e>'][task][subject]['mask_<c>']`` exactly as the reference does (0/0 stays NaN
+        in the stored value).  Without recorded names every sample is its own subject.  Returns a summary (means over
+        subjects, NaN entries ignored) for callers that want one number; the reference returns nothing."""
+        tp = np.array(self.online_eval_tp); fp = np.array(self.online_eval_fp); fn = np.array(self.online_eval_fn)
+        tp = tp.reshape(-1, tp.shape[-1]); fp = fp.reshape(-1, fp.shape[-1]); fn = fn.reshape(-1, fn.shape[-1])
+        raw = np.array(self.subject_names_raw).flatten()
+        if raw.size == 0:
+            raw = np.array([f"sample_{i:06d}" for i in range(tp.shape[0])])
+        assert raw.shape[0] == tp.shape[0], f"{raw.shape[0]} subject names for {tp.shape[0]} evaluated samples"
+        subject_names = list(np.unique(raw)) if unique_subject_names is None else list(unique_subject_names)
+        store, dice_rows, iou_rows = dict(), [], []
+        for subject in subject_names:
+            idx = np.where(raw == subject)
+            i, j, k = tp[idx].sum(axis=0), fp[idx].sum(axis=0), fn[idx].sum(axis=0)
+            if np.isnan(i).any():                      # MH.py:1015-1022: subjects with NaN counts are dropped
+                continue
+            with np.errstate(invalid='ignore', divide='ignore'):
+                iou, dc = i / (i + j + k), 2 * i / (2 * i + j + k)
+            store[str(subject)] = {'mask_' + str(c + 1): {'IoU': np.float64(iou[c]), 'Dice': np.float64(dc[c])}
+                                   for c in range(len(iou))}
+            dice_rows.append(dc); iou_rows.append(iou)
+        self.validation_results.setdefault('epoch_' + str(self.epoch), {})[task] = store
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
+        self.subject_names_raw = []
+        dice, iou = np.array(dice_rows), np.array(iou_rows)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            return {"mean_dice_per_class": np.nanmean(dice, 0).tolist(), "mean_iou_per_class": np.nanmean(iou, 0).tolist(),
+                    "mean_dice": float(np.nanmean(dice)), "mean_iou": float(np.nanmean(iou)), "per_subject": store}
 
     def _perform_validation(self, use_tasks=None, num_batches=None, call_for_eval=False):
         """MH.py:678-901 hot part: for every head, assemble it, run no-grad iterations on that task's validation
-        generator with online evaluation, collect Dice/IoU."""
+        generator with online evaluation, collect per-subject Dice/IoU.  Subject names: the reference draws them from a
+        ``tee(self.val_gen, 1)[0]`` copy (MH.py:812-819), which for a generator ADVANCES the generator itself -- the
+        names of batch 2k are paired with the predictions of batch 2k+1.  Parity mode reproduces that;
+        ``self.eval_names_from_same_batch = True`` pairs every prediction with its own batch's names."""
         use_tasks = use_tasks or list(self.mh_network.heads.keys())
         num_batches = num_batches or self.num_val_batches_per_epoch
         active = self.mh_network.active_task
@@ -261,7 +292,13 @@ class nnUNetTrainerMultiHead:
                 self.network.eval()
                 gen = self.data_provider(t, "val", self.plans)
                 for _ in range(num_batches):
-                    self.run_iteration(gen, False, True)
+                    if getattr(self, "eval_names_from_same_batch", False):
+                        batch = next(gen)
+                        self.subject_names_raw.append(np.asarray(batch['keys']))
+                        self.run_iteration(iter([batch]), False, True, no_loss=call_for_eval)
+                    else:
+                        self.subject_names_raw.append(np.asarray(next(gen)['keys']))
+                        self.run_iteration(gen, False, True, no_loss=call_for_eval)
                 results[str(t)] = self.finish_online_evaluation_extended(t)
         self.network = self.mh_network.assemble_model(active)
         self.network.train()

@@ -1,17 +1,30 @@
 """``nnUNetTrainerRehearsal`` -- training set = current task + a seeded 25 % sample of every previous task.
 
-Mirror of the sampling semantics of nnunet_ext/training/network_training/rehearsal/nnUNetTrainerRehearsal.py
-:65-173 (``random.seed(self.seed)`` :73, per previous task in head order
-``random.sample(dataset_tr.items(), round(len * samples))`` :132, validation = current task only :142,
-``random.seed()`` reset :169).  The file-system part (loading each task's preprocessed folder) is out of scope;
-a task's "dataset" here is its list of case identifiers and each batch draws cases uniformly from the fused
-list, which yields the mixed-task batches of BASELINE config 5.
+Mirror of nnunet_ext/training/network_training/rehearsal/nnUNetTrainerRehearsal.py:65-173
+(``get_basic_generators``), pinned by ``tests/golden/trainer_reference.json:rehearsal`` which the REFERENCE's own
+method produced (oracle/make_goldens_trainers.py):
+  * ``random.seed(self.seed)`` (REH.py:73); the current task's dataset is loaded and split (REH.py:76-77);
+  * for every task already in ``mh_network.heads`` -- in head order, the current task is NOT excluded by the reference
+    loop, it simply is not a head yet when the generators are built -- that task's dataset is loaded, split with the SAME
+    fold, and ``random.sample(dataset_tr.items(), round(len(dataset_tr) * samples))`` (REH.py:127-132) is merged into the
+    fused training dictionary (current task's training cases first, then the samples in draw order);
+  * validation uses the current task only (REH.py:142); ``random.seed()`` afterwards (REH.py:169).
+The fused dictionary feeds ONE loader that draws cases uniformly (upstream ``DataLoader3D``), which yields the mixed-task
+batches of BASELINE config 5.
+
+Where the cases come from is the ``data_provider``'s business: a provider that offers ``dataset_for(task)`` /
+``splits_file_for(task)`` / ``generator_for(dataset, plans, split)`` (``dataloading.PreprocessedDataProvider``: real
+nnU-Net-preprocessed folders) is used for BOTH splits; the default synthetic provider falls back to deterministic
+synthetic patches per case identifier.  ``RehearsalMixin`` carries the behaviour so that it can be combined with another
+trainer (``rehearsal_ewc/nnUNetTrainerRehearsalEWC.py`` = BASELINE config 5).
 """
 import random
+from collections import OrderedDict
 
 import numpy as np
 import torch
 
+from ....dataloading import do_split
 from ....synthetic import make_patch_batch
 from ..multihead.nnUNetTrainerMultiHead import nnUNetTrainerMultiHead
 
@@ -19,7 +32,7 @@ HYPERPARAMS = {'samples_in_perc': float, 'seed': int}
 
 
 def task_cases(task, n_cases=40):
-    """Synthetic stand-in for ``dataset_tr`` keys (sorted, as MH.py:273-277 produces them)."""
+    """Synthetic stand-in for a task's case identifiers (sorted, as ``load_dataset`` returns them)."""
     return [f"{task}_{i:03d}" for i in range(1, n_cases + 1)]
 
 
@@ -51,35 +64,58 @@ class RehearsalPatchGenerator:
         return {'data': data, 'target': target, 'keys': keys}
 
 
-class nnUNetTrainerRehearsal(nnUNetTrainerMultiHead):
-    def __init__(self, split, task, *args, samples_in_perc=0.25, seed=3299, cases_per_task=40, **kwargs):
-        kwargs.setdefault("extension", "rehearsal")
-        super().__init__(split, task, *args, **kwargs)
+class RehearsalMixin:
+    """``get_basic_generators`` / ``reinitialize`` / ``initialize`` of the rehearsal trainer, for any multi-head trainer."""
+
+    def _init_rehearsal(self, samples_in_perc, seed, cases_per_task):
         assert 0 < samples_in_perc <= 1, "Your provided samples are not in the correct range (0, 1]"
         self.samples, self.seed, self.cases_per_task = samples_in_perc, seed, cases_per_task
-        self.dataset_tr = None
+        self.dataset = self.dataset_tr = self.dataset_val = None
+        self.sampled = {}
+
+    # ---- where a task's cases come from
+    def _task_dataset(self, task):
+        dp = self.data_provider
+        if hasattr(dp, "dataset_for"):
+            return dp.dataset_for(task)
+        return OrderedDict((k, {"case": k}) for k in task_cases(task, self.cases_per_task))
+
+    def _split(self, dataset, task):
+        dp = self.data_provider
+        return do_split(dataset, self.fold, dp.splits_file_for(task) if hasattr(dp, "splits_file_for") else None)
+
+    def _generator(self, dataset, split):
+        dp = self.data_provider
+        if hasattr(dp, "generator_for"):
+            return dp.generator_for(dataset, self.plans, split)
+        if split == "val":
+            return dp(self.task, "val", self.plans)
+        return RehearsalPatchGenerator(list(dataset.keys()), self.plans, seed=12345 + self.fold)
 
     def get_basic_generators(self, use_all_data=False):
         random.seed(self.seed)                                               # REH.py:73
-        dataset_tr_fused = list(task_cases(self.task, self.cases_per_task))
+        self.dataset = self._task_dataset(self.task)                         # REH.py:76-77
+        self.dataset_tr, self.dataset_val = self._split(self.dataset, self.task)
+        dataset_fused, dataset_tr_fused = OrderedDict(self.dataset), OrderedDict(self.dataset_tr)
         try:
-            tasks_in_head = [t for t in self.mh_network.heads.keys() if t != str(self.task)]
+            tasks_in_head = list(self.mh_network.heads.keys())               # REH.py:88-91
         except AttributeError:
             tasks_in_head = []
         self.sampled = {}
         for task in tasks_in_head:                                            # head order (REH.py:107)
-            items = task_cases(task, self.cases_per_task)
-            sample_tr = random.sample(items, round(len(items) * self.samples))   # REH.py:132
-            self.sampled[task] = sample_tr
-            dataset_tr_fused += sample_tr
-        self.dataset_tr = dataset_tr_fused
+            ds = self._task_dataset(task)                                     # REH.py:127-128
+            ds_tr, _ = self._split(ds, task)
+            items = list(ds_tr.items())
+            sample_tr = random.sample(items, round(len(ds_tr) * self.samples))    # REH.py:132
+            self.sampled[task] = [k for k, _ in sample_tr]
+            dataset_fused.update(ds)                                          # REH.py:135-136
+            dataset_tr_fused.update(sample_tr)
+        self.dataset, self.dataset_tr = dataset_fused, dataset_tr_fused      # REH.py:140-142: validation stays the current task's
         random.seed()                                                         # REH.py:169
-        dl_tr = RehearsalPatchGenerator(dataset_tr_fused, self.plans, seed=12345 + self.fold)
-        dl_val = self.data_provider(self.task, "val", self.plans)             # validation: current task only (REH.py:142)
-        return dl_tr, dl_val
+        return self._generator(self.dataset_tr, "train"), self._generator(self.dataset_val, "val")
 
     def reinitialize(self, task, print_loss_info=True):
-        self.task = task
+        super().reinitialize(task, print_loss_info)
         self.tr_gen, self.val_gen = self.get_basic_generators()
 
     def initialize(self, training=True, force_load_plans=False, num_epochs=500, prev_trainer_path=None,
@@ -87,3 +123,10 @@ class nnUNetTrainerRehearsal(nnUNetTrainerMultiHead):
         super().initialize(training, force_load_plans, num_epochs, prev_trainer_path, call_for_eval)
         if training:
             self.tr_gen, self.val_gen = self.get_basic_generators()
+
+
+class nnUNetTrainerRehearsal(RehearsalMixin, nnUNetTrainerMultiHead):
+    def __init__(self, split, task, *args, samples_in_perc=0.25, seed=3299, cases_per_task=40, **kwargs):
+        kwargs.setdefault("extension", "rehearsal")
+        super().__init__(split, task, *args, **kwargs)
+        self._init_rehearsal(samples_in_perc, seed, cases_per_task)

@@ -1,0 +1,340 @@
+"""Generate tests/golden/trainer_reference.{npz,json} by EXECUTING THE REFERENCE'S TRAINER METHODS verbatim -- run in the
+build container only (needs /root/reference):
+
+    python -m oracle.make_goldens_trainers
+
+The reference trainer classes are imported from /root/reference through ``oracle.ref_shim`` (stand-ins for the
+un-vendored ``nnunet`` / ``batchgenerators`` packages) and instantiated WITHOUT their constructors
+(``object.__new__``); the attributes the executed methods read are set by hand; the network is the oracle's
+``OracleGenericUNet`` (the upstream Generic_UNet source is not in the reference tree), the data the build's synthetic
+patches.  Executed verbatim, with file:line of the reference:
+
+  nnUNetTrainerMultiHead.initialize_optimizer_and_scheduler   MH.py:294-301
+  nnUNetTrainerMultiHead.run_iteration (fp32 branch)          MH.py:598-656
+  nnUNetTrainerMultiHead.run_online_evaluation                MH.py:924-961
+  nnUNetTrainerMultiHead.finish_online_evaluation_extended    MH.py:963-1049
+  nnUNetTrainerMultiHead._update_loss_after_plans_change      MH.py:1363-1387
+  nnUNetTrainerMultiHead.reorder_UNet_components              MH.py:1391-1408
+  nnUNetTrainerMultiHead.do_split                             MH.py:186-277
+  nnUNetTrainerEWC.run_iteration / run_training / after_train EWC.py:179-310
+  nnUNetTrainerRW.run_iteration / run_training / _update_f_s_values  RW.py:128-265
+  nnUNetTrainerRehearsal.get_basic_generators                 REH.py:65-173
+  test/network_architecture/test_MultiHead_Module.py:281-433  (module-tree dump, parsed into names + channel counts)
+
+``run_training`` of the multi-head base class (epoch loop, file system, plans) is replaced by a 3-line loop over
+``self.run_iteration`` so that the EWC / RW bookkeeping AROUND it runs unchanged.  Only DATA is written (arrays, names,
+numbers); no reference source or bytecode is copied.  TEST INFRASTRUCTURE ONLY.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import re
+import tempfile
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import losses, ref_shim, train
+from .unet import OracleGenericUNet
+
+REF = ref_shim.REF
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+TOY_CTOR = (1, 8, 3, 2)
+PATCH = (16, 16, 16)
+
+
+def batches(task_seed, n, patch=PATCH, B=2, num_pool=2):
+    """Deterministic synthetic batches in the reference's data-dict form (regenerated identically by the tests)."""
+    from importlib import import_module
+    synth = import_module("lifelong_nnunet_amd.synthetic")
+    out = []
+    for i in range(n):
+        data, tgts = synth.make_patch_batch(B, patch, num_pool, seed=task_seed + i)
+        out.append({"data": data.numpy(), "target": [t.numpy() for t in tgts],
+                    "keys": np.array([f"case_{task_seed + i}_{b}" for b in range(B)])})
+    return out
+
+
+def new_trainer(cls, net, task, **attrs):
+    tr = object.__new__(cls)
+    tr.network = net
+    tr.fp16 = False
+    tr.task = task
+    tr.fold = 0
+    tr.batch_dice = False
+    tr.initial_lr, tr.weight_decay = 1e-2, 3e-5
+    tr.eval_batch = False
+    tr.online_eval_tp, tr.online_eval_fp, tr.online_eval_fn, tr.online_eval_foreground_dc = [], [], [], []
+    tr.subject_names_raw = []
+    tr.validation_results = dict()
+    tr.epoch = 0
+
+    class _MH:      # only the call the iteration makes (MH.py:650)
+        heads = OrderedDict()
+
+        def update_after_iteration(self):
+            pass
+    tr.mh_network = _MH()
+    for k, v in attrs.items():
+        setattr(tr, k, v)
+    return tr
+
+
+def flat(d, names):
+    return np.concatenate([np.asarray(d[n].detach().cpu().float()).reshape(-1) for n in names])
+
+
+SUB = 7     # the big per-parameter arrays are committed as every 7th element + per-tensor sum / L2 / max tables
+
+
+def put(arrs, key, d, names):
+    """Fixture form of a per-parameter dict: strided sample of the flattened values and a (len(names), 3) float64 table
+    of per-tensor [sum, L2 norm, max |.|] (both are checked by the tests)."""
+    f = flat(d, names)
+    arrs[key + "::sub"] = f[::SUB].copy()
+    arrs[key + "::stats"] = np.array([[float(d[n].double().sum()), float(d[n].double().norm()), float(d[n].double().abs().max())]
+                                      for n in names], dtype=np.float64)
+
+
+def parse_module_tree():
+    """test_MultiHead_Module.py:281-433: the printed Generic_UNet(3, 5, 2, 3) -> [(dotted path, type, cin, cout)] of the
+    leaves that hold parameters."""
+    src = open(os.path.join(REF, "test", "network_architecture", "test_MultiHead_Module.py")).read()
+    start = src.index("Generic_UNet(\n", src.index('""" GenericUNet using input_channels=3'))
+    lines = src[start:].split("\n")
+    stack, leaves = [], []
+    for ln in lines[1:]:
+        if ln.strip() == '"""' or ln.startswith('"""'):
+            break
+        m = re.match(r"^(\s*)\((\w+)\): (\w+)\((.*)$", ln)
+        if not m:
+            if ln.strip() == ")":
+                if stack:
+                    stack.pop()
+            continue
+        name, typ, rest = m.group(2), m.group(3), m.group(4)
+        if rest.endswith(")") and rest.count("(") < rest.count(")") + 0 and not rest.strip() == "":
+            # single-line leaf, e.g. Conv2d(40, 20, kernel_size=...)
+            path = ".".join(stack + [name])
+            nums = re.match(r"^(\d+)(?:, (\d+))?", rest)
+            if typ.startswith("Conv") or typ.startswith("BatchNorm") or typ.startswith("InstanceNorm"):
+                cin = int(nums.group(1))
+                cout = int(nums.group(2)) if nums.group(2) else None
+                leaves.append([path, typ, cin, cout])
+        elif rest.strip() == "" or not rest.endswith(")"):
+            stack.append(name)
+        else:
+            stack.append(name)
+    return leaves
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_shim.install()
+    warnings.filterwarnings("ignore")
+    _, RefMH = ref_shim.import_trainer("multihead", "nnUNetTrainerMultiHead")
+    ewc_mod, RefEWC = ref_shim.import_trainer("ewc", "nnUNetTrainerEWC")
+    rw_mod, RefRW = ref_shim.import_trainer("rw", "nnUNetTrainerRW")
+    reh_mod, RefREH = ref_shim.import_trainer("rehearsal", "nnUNetTrainerRehearsal")
+    from nnunet_ext.training.loss_functions.deep_supervision import MultipleOutputLossEWC, MultipleOutputLossRW
+    arrs, meta = {}, {}
+
+    # ------------------------------------------------------------------ module tree (reference test file, parsed)
+    meta["module_tree"] = {"ctor": [3, 5, 2, 3], "leaves": parse_module_tree()}
+
+    # ------------------------------------------------------------------ deep-supervision weights + loss wrapper
+    dsw = {}
+    for npool in (2, 3, 5):
+        tr = new_trainer(RefMH, None, "t")
+        tr._update_loss_after_plans_change([[2, 2, 2]] * npool, PATCH)
+        dsw[str(npool)] = [float(x) for x in tr.ds_loss_weights]
+        assert np.allclose(tr.ds_loss_weights, losses.ds_loss_weights(npool))
+    meta["ds_weights"] = dsw
+
+    # ------------------------------------------------------------------ reorder_UNet_components
+    torch.manual_seed(1)
+    net = OracleGenericUNet(*TOY_CTOR)
+    before = [n for n, _ in net.named_parameters()]
+    tr = new_trainer(RefMH, net, "t")
+    tr.reorder_UNet_components()
+    meta["reorder"] = {"ctor": list(TOY_CTOR), "before": before, "after": [n for n, _ in net.named_parameters()]}
+
+    # ------------------------------------------------------------------ do_split (5-fold KFold + the beyond-range fold)
+    keys = [f"hippocampus_{i:03d}" for i in range(1, 41)]
+    splits = {}
+    with tempfile.TemporaryDirectory() as td:
+        for fold in (0, 1, 4, 7):
+            tr = new_trainer(RefMH, None, "t", fold=fold, dataset_directory=td, param_split=False,
+                             dataset=OrderedDict((k, {"data_file": k}) for k in keys))
+            tr.do_split()
+            splits[str(fold)] = {"train": list(tr.dataset_tr.keys()), "val": list(tr.dataset_val.keys())}
+    meta["do_split"] = {"keys": keys, "folds": splits}
+
+    # ------------------------------------------------------------------ rehearsal: get_basic_generators
+    datasets = {"/data/TaskA": [f"hippocampus_{i:03d}" for i in range(1, 41)], "/data/TaskB": [f"la_{i:03d}" for i in range(1, 17)],
+                "/data/TaskC": [f"prostate_{i:02d}" for i in range(1, 25)]}
+    recorded = {}
+
+    class RecLoader:
+        def __init__(self, data, *a, **k):
+            recorded.setdefault("loaders", []).append(list(data.keys()))
+
+    with tempfile.TemporaryDirectory() as td:
+        def fake_default_configuration(network_name, task, running_task, prev_trainer, tasks_joined, identifier, extension_type=None):
+            d = os.path.join(td, task)
+            os.makedirs(d, exist_ok=True)
+            return os.path.join(d, "plans.pkl"), None, d, None, 0, None
+        reh_mod.get_default_configuration = fake_default_configuration
+        reh_mod.load_pickle = lambda f: {"data_identifier": "nnUNetData_plans_v2.1"}
+        reh_mod.load_dataset = lambda folder: OrderedDict(
+            (k, {"data_file": k}) for k in datasets["/data/" + os.path.basename(os.path.dirname(folder))])
+        reh_mod.DataLoader3D = RecLoader
+        cur = os.path.join(td, "TaskC")
+        os.makedirs(cur, exist_ok=True)
+        tr = new_trainer(RefREH, None, "TaskC", seed=3299, samples=0.25, dataset_directory=cur, param_split=False, threeD=True,
+                         already_trained_on={"0": {"prev_trainer": ["nnUNetTrainerRehearsal"] * 2}}, network_name="3d_fullres",
+                         tasks_joined_name="TaskA_TaskB_TaskC", identifier="x", extension="rehearsal",
+                         basic_generator_patch_size=PATCH, patch_size=PATCH, batch_size=2, oversample_foreground_percent=0.33,
+                         pad_all_sides=None)
+        tr.mh_network.heads = OrderedDict([("TaskA", None), ("TaskB", None)])
+        tr.load_dataset = lambda: setattr(tr, "dataset", OrderedDict((k, {"data_file": k}) for k in datasets["/data/TaskC"]))
+        tr.get_basic_generators()
+    meta["rehearsal"] = {"seed": 3299, "samples": 0.25, "datasets": datasets, "heads": ["TaskA", "TaskB"], "current": "TaskC",
+                         "train_keys_fused": recorded["loaders"][0], "val_keys": recorded["loaders"][1]}
+
+    # ------------------------------------------------------------------ online evaluation
+    g = torch.Generator().manual_seed(41)
+    tr = new_trainer(RefMH, None, "taskA")
+    names_per_batch, ev = [], {}
+    for bi in range(3):
+        lg = torch.randn(2, 3, 6, 8, 6, generator=g) * 2
+        tg = torch.randint(0, 3, (2, 1, 6, 8, 6), generator=g).float()
+        if bi == 2:
+            tg[1][tg[1] == 2] = 0             # a sample without class 2: tp = fn = 0 -> Dice is NaN unless fp > 0
+        tr.run_online_evaluation((lg,), [tg])
+        ev[f"logits_{bi}"] = lg.numpy(); ev[f"target_{bi}"] = tg.numpy()
+        names_per_batch.append(["subj_a", "subj_b"] if bi != 1 else ["subj_a", "subj_c"])     # subj_a appears three times
+    for bi in range(3):
+        ev[f"tp_{bi}"], ev[f"fp_{bi}"], ev[f"fn_{bi}"] = tr.online_eval_tp[bi], tr.online_eval_fp[bi], tr.online_eval_fn[bi]
+        tp, fp, fn = losses.online_dice_counts(torch.from_numpy(ev[f"logits_{bi}"]), torch.from_numpy(ev[f"target_{bi}"]))
+        assert np.array_equal(tp.numpy(), ev[f"tp_{bi}"]) and np.array_equal(fp.numpy(), ev[f"fp_{bi}"]) and np.array_equal(fn.numpy(), ev[f"fn_{bi}"])
+    tr.subject_names_raw = [np.array(n) for n in names_per_batch]
+    tr.epoch = 4
+    tr.finish_online_evaluation_extended("taskA")
+    for k, v in ev.items():
+        arrs["eval::" + k] = v
+    meta["online_eval"] = {"names_per_batch": names_per_batch, "epoch": 4, "task": "taskA",
+                           "validation_results": json.loads(json.dumps(tr.validation_results, default=float))}
+
+    # ------------------------------------------------------------------ EWC flow: task A (3 iterations) -> after_train -> task B
+    def light_run_training(self, task, output_folder=None, build_folder=True):
+        """Stand-in for nnUNetTrainerMultiHead.run_training (MH.py:520-596: epoch loop + files): N training iterations."""
+        if self.task != task:             # MH.py:541-545
+            self.reinitialize(task)
+            self.task = task
+        if task not in self.mh_network.heads:       # MH.py:551-552
+            self.mh_network.heads[task] = None
+        self.network.train()
+        out = [float(self.run_iteration(self.tr_gen, True)) for _ in range(self.num_batches_per_epoch)]
+        self.already_trained_on[str(self.fold)]['finished_training_on'].append(task)
+        self.loop_losses = out
+        return out
+
+    def light_reinitialize(self, task, print_loss_info=True):
+        """Stand-in for nnUNetTrainerMultiHead.reinitialize (MH.py:458-518: new data loaders from files)."""
+        self.tr_gen = self.gens[task]
+
+    orig_run_training, orig_reinitialize = RefMH.run_training, RefMH.reinitialize
+    RefMH.run_training, RefMH.reinitialize = light_run_training, light_reinitialize
+    try:
+        with tempfile.TemporaryDirectory() as td, ref_shim.cuda_as_cpu():
+            torch.manual_seed(12345)
+            net = OracleGenericUNet(*TOY_CTOR)
+            init_sd = {k: v.clone() for k, v in net.state_dict().items()}
+            names = [n for n, _ in net.named_parameters()]
+            tr = new_trainer(RefEWC, net, "taskA", ewc_lambda=0.4, fisher=dict(), params=dict(), num_batches_per_epoch=3,
+                             already_trained_on={"0": {"finished_training_on": [], "fisher_at": None, "params_at": None}},
+                             ewc_data_path=os.path.join(td, "ewc_data"), trained_on_path=td, extension="ewc", output_folder=td)
+            tr.update_init_args = lambda: None
+            tr.save_init_args = lambda *a, **k: None
+            tr.initialize_optimizer_and_scheduler()
+            tr._update_loss_after_plans_change([[2, 2, 2]] * 2, PATCH)
+            base = ewc_mod.DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {})
+            tr.loss = MultipleOutputLossEWC(base, tr.ds_loss_weights, tr.ewc_lambda, tr.fisher, tr.params, tr.network.named_parameters())
+            tr.gens = {"taskA": iter(batches(1000, 6)), "taskB": iter(batches(2000, 6))}   # 3 training batches + the 3 of after_train
+            tr.tr_gen = tr.gens["taskA"]
+            tr.mh_network.heads = OrderedDict()
+            tr.run_training("taskA", td)
+            ewc = {"lossesA": tr.loop_losses}
+            fA, pA = tr.fisher["taskA"], tr.params["taskA"]
+            # the oracle's restatement of the same flow must agree exactly
+            torch.manual_seed(12345)
+            onet = OracleGenericUNet(*TOY_CTOR); onet.load_state_dict(init_sd)
+            oopt = train.make_optimizer(onet)
+            w = losses.ds_loss_weights(2)
+            ob = batches(1000, 6)
+            ol = [train.run_iteration(onet, oopt, torch.from_numpy(b["data"]), [torch.from_numpy(t) for t in b["target"]], w)[0] for b in ob[:3]]
+            assert np.allclose(ol, ewc["lossesA"], rtol=1e-6), (ol, ewc["lossesA"])
+            ofi, opa = train.ewc_after_train(onet, oopt, [(torch.from_numpy(b["data"]), [torch.from_numpy(t) for t in b["target"]]) for b in ob[3:]], w)
+            for n in names:
+                assert torch.allclose(ofi[n].reshape(-1), fA[n].reshape(-1).float(), rtol=1e-5, atol=1e-12), n
+                assert torch.equal(opa[n], pA[n]), n
+            ewc["fisher_shapes"] = {n: list(fA[n].shape) for n in names}
+            # ---- task B: EWC.reinitialize (EWC.py:142-177) runs verbatim from the run_training stand-in
+            tr.run_training("taskB", td)
+            ewc["lossesB"] = tr.loop_losses
+            fB = tr.fisher["taskB"]
+            ewc["names"] = names
+        put(arrs, "ewc::fisherA", fA, names); put(arrs, "ewc::paramsA", pA, names)
+        put(arrs, "ewc::fisherB", fB, names); put(arrs, "ewc::paramsB", tr.params["taskB"], names)
+        put(arrs, "ewc::final_theta", dict(net.named_parameters()), names)
+        for k, v in init_sd.items():
+            arrs["init::" + k] = v.numpy()
+        meta["ewc_flow"] = ewc
+
+        # ------------------------------------------------------------------ RW flow: two tasks, statistics every iteration
+        with tempfile.TemporaryDirectory() as td, ref_shim.cuda_as_cpu():
+            torch.manual_seed(12345)
+            net = OracleGenericUNet(*TOY_CTOR); net.load_state_dict(init_sd)
+            tr = new_trainer(RefRW, net, "taskA", rw_lambda=0.4, alpha=0.9, fisher_update_after=2, fisher=dict(), params=dict(),
+                             scores=dict(), num_batches_per_epoch=5, prev_param=None, prev_fisher=None, count=0,
+                             already_trained_on={"0": {"finished_training_on": [], "fisher_at": None, "params_at": None, "scores_at": None}},
+                             rw_data_path=os.path.join(td, "rw_data"), trained_on_path=td, extension="rw", output_folder=td)
+            tr.update_init_args = lambda: None
+            tr.save_init_args = lambda *a, **k: None
+            tr.initialize_optimizer_and_scheduler()
+            tr._update_loss_after_plans_change([[2, 2, 2]] * 2, PATCH)
+            base = rw_mod.DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {})
+            tr.loss = MultipleOutputLossRW(base, tr.ds_loss_weights, tr.rw_lambda, tr.fisher, tr.params, tr.scores, tr.network.named_parameters())
+            tr.mh_network.heads = OrderedDict()
+            rw = {"alpha": 0.9, "fisher_update_after": 2, "iters": 5, "names": names}
+            tr.gens = {"taskA": iter(batches(3000, 5)), "taskB": iter(batches(4000, 5))}
+            tr.tr_gen = tr.gens["taskA"]
+            tr.run_training("taskA", td)
+            rw["lossesA"] = tr.loop_losses
+            gnames = [n for n in names if n in tr.fisher["taskA"]]
+            put(arrs, "rw::fisherA", tr.fisher["taskA"], gnames); put(arrs, "rw::scoresA", tr.scores["taskA"], gnames)
+            put(arrs, "rw::paramsA", tr.params["taskA"], names)
+            rw["stat_names"] = gnames
+            tr.run_training("taskB", td)          # RW.reinitialize (RW.py:100-126) runs verbatim from the stand-in
+            rw["lossesB"] = tr.loop_losses
+            put(arrs, "rw::fisherB", tr.fisher["taskB"], gnames); put(arrs, "rw::scoresB", tr.scores["taskB"], gnames)
+            put(arrs, "rw::final_theta", dict(net.named_parameters()), names)
+        rw["sub"] = SUB
+        meta["rw_flow"] = rw
+    finally:
+        RefMH.run_training, RefMH.reinitialize = orig_run_training, orig_reinitialize
+
+    np.savez_compressed(os.path.join(OUT, "trainer_reference.npz"), **arrs)
+    with open(os.path.join(OUT, "trainer_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", os.path.join(OUT, "trainer_reference.npz"), os.path.getsize(os.path.join(OUT, "trainer_reference.npz")))
+    print("wrote", os.path.join(OUT, "trainer_reference.json"), os.path.getsize(os.path.join(OUT, "trainer_reference.json")))
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,24 @@ def rw_finish_task(net, st, n_finished, prev_scores=None):
     return fisher, params, scores
 
 
+def per_subject_dice(tp_batches, fp_batches, fn_batches, names_per_batch):
+    """multihead/nnUNetTrainerMultiHead.py:963-1049: hard TP / FP / FN of all samples carrying the same subject name are
+    summed, then IoU = TP/(TP+FP+FN) and Dice = 2TP/(2TP+FP+FN) per subject and foreground class (0/0 -> NaN)."""
+    import numpy as np
+    tp = np.concatenate([np.asarray(t) for t in tp_batches], 0)
+    fp = np.concatenate([np.asarray(t) for t in fp_batches], 0)
+    fn = np.concatenate([np.asarray(t) for t in fn_batches], 0)
+    raw = np.array(names_per_batch).flatten()
+    out = {}
+    for subject in np.unique(raw):
+        idx = np.where(raw == subject)
+        i, j, k = tp[idx].sum(0), fp[idx].sum(0), fn[idx].sum(0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            iou, dc = i / (i + j + k), 2 * i / (2 * i + j + k)
+        out[str(subject)] = {f"mask_{c + 1}": {"IoU": float(iou[c]), "Dice": float(dc[c])} for c in range(len(iou))}
+    return out
+
+
 def lwf_loss_value(base_loss, pred_logits, target_logits, temperature=2.0):
     """deep_supervision.py:201-214 -- KL terms are added to the value; they carry no gradient because
     the predictions are detached (lwf/nnUNetTrainerLWF.py:343)."""

@@ -101,7 +101,8 @@ def test_multihead_module_matches_reference_naming_and_semantics(golden_dir):
 def test_trainer_plugin_surface():
     for ext, cls_name, hp in (("sequential", "nnUNetTrainerSequential", {}), ("ewc", "nnUNetTrainerEWC", {"ewc_lambda": float}),
                               ("lwf", "nnUNetTrainerLWF", {"lwf_temperature": float}),
-                              ("rehearsal", "nnUNetTrainerRehearsal", {"samples_in_perc": float, "seed": int})):
+                              ("rehearsal", "nnUNetTrainerRehearsal", {"samples_in_perc": float, "seed": int}),
+                              ("rehearsal_ewc", "nnUNetTrainerRehearsalEWC", {"ewc_lambda": float, "samples_in_perc": float, "seed": int})):
         cls = pkg.get_trainer_class(ext)
         assert cls.__name__ == cls_name
         mod = __import__(cls.__module__, fromlist=["HYPERPARAMS"])
@@ -117,19 +118,26 @@ def test_trainer_plugin_surface():
 
 
 def test_rehearsal_sampling_semantics(golden_dir):
+    """Default (synthetic) provider: the fused training list = the current task's fold-0 training cases followed by a
+    seeded 25 % sample of each previous head's training cases, drawn in head order from ONE random.seed(3299) stream
+    (REH.py:73,132; the reference-generated fixture is checked in tests/test_reference_trainer_goldens.py)."""
     import random
+    from collections import OrderedDict
+    from lifelong_nnunet_amd.dataloading import do_split
     from lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal import nnUNetTrainerRehearsal, task_cases
 
     class _MH:
-        heads = {"taskA": None, "taskB": None, "taskC": None}
+        heads = OrderedDict([("taskA", None), ("taskB", None)])
     tr = nnUNetTrainerRehearsal("seg_outputs", "taskC", device="cpu")
     tr.mh_network = _MH()
     tr.tr_gen, tr.val_gen = tr.get_basic_generators()
+    split = lambda t: list(do_split(OrderedDict((k, 0) for k in task_cases(t, 40)), 0)[0].keys())
     random.seed(3299)
-    expA = random.sample(task_cases("taskA", 40), 10)
-    expB = random.sample(task_cases("taskB", 40), 10)
+    expA = random.sample(split("taskA"), 8)
+    expB = random.sample(split("taskB"), 8)
     assert tr.sampled == {"taskA": expA, "taskB": expB}
-    assert tr.dataset_tr == task_cases("taskC", 40) + expA + expB
+    assert list(tr.dataset_tr.keys()) == split("taskC") + expA + expB
+    assert len(tr.dataset_val) == 8 and not set(tr.dataset_val) & set(tr.dataset_tr)
     batch = next(tr.tr_gen)
     assert tuple(batch["data"].shape) == (2, 1, 40, 56, 40) and len(batch["target"]) == 3 and len(batch["keys"]) == 2
 
