@@ -237,7 +237,8 @@ def main():
             self.reinitialize(task)
             self.task = task
         if task not in self.mh_network.heads:       # MH.py:551-552
-            self.mh_network.heads[task] = None
+            self.mh_network.add_new_task(task, use_init=not self.transfer_heads)
+        self.network = self.mh_network.assemble_model(task)        # MH.py:566
         self.network.train()
         out = [float(self.run_iteration(self.tr_gen, True)) for _ in range(self.num_batches_per_epoch)]
         self.already_trained_on[str(self.fold)]['finished_training_on'].append(task)
@@ -248,15 +249,25 @@ def main():
         """Stand-in for nnUNetTrainerMultiHead.reinitialize (MH.py:458-518: new data loaders from files)."""
         self.tr_gen = self.gens[task]
 
+    def fresh_mh():
+        """The reference's MultiHead_Module around the oracle network.  Its splitting helper has mutable default arguments
+        (MHM.py:159-160), so the module is reloaded per instance exactly as the reference's own tests do (TMHM.py:136-137)."""
+        import importlib
+        import nnunet_ext.network_architecture.MultiHead_Module as mhm
+        importlib.reload(mhm)
+        return mhm.MultiHead_Module(OracleGenericUNet, "seg_outputs", "taskA", None, *TOY_CTOR)
+
     orig_run_training, orig_reinitialize = RefMH.run_training, RefMH.reinitialize
     RefMH.run_training, RefMH.reinitialize = light_run_training, light_reinitialize
     try:
         with tempfile.TemporaryDirectory() as td, ref_shim.cuda_as_cpu():
             torch.manual_seed(12345)
-            net = OracleGenericUNet(*TOY_CTOR)
+            mh = fresh_mh()
+            net = mh.model
             init_sd = {k: v.clone() for k, v in net.state_dict().items()}
             names = [n for n, _ in net.named_parameters()]
             tr = new_trainer(RefEWC, net, "taskA", ewc_lambda=0.4, fisher=dict(), params=dict(), num_batches_per_epoch=3,
+                             mh_network=mh, transfer_heads=False,
                              already_trained_on={"0": {"finished_training_on": [], "fisher_at": None, "params_at": None}},
                              ewc_data_path=os.path.join(td, "ewc_data"), trained_on_path=td, extension="ewc", output_folder=td)
             tr.update_init_args = lambda: None
@@ -267,7 +278,6 @@ def main():
             tr.loss = MultipleOutputLossEWC(base, tr.ds_loss_weights, tr.ewc_lambda, tr.fisher, tr.params, tr.network.named_parameters())
             tr.gens = {"taskA": iter(batches(1000, 6)), "taskB": iter(batches(2000, 6))}   # 3 training batches + the 3 of after_train
             tr.tr_gen = tr.gens["taskA"]
-            tr.mh_network.heads = OrderedDict()
             tr.run_training("taskA", td)
             ewc = {"lossesA": tr.loop_losses}
             fA, pA = tr.fisher["taskA"], tr.params["taskA"]
@@ -289,6 +299,7 @@ def main():
             ewc["lossesB"] = tr.loop_losses
             fB = tr.fisher["taskB"]
             ewc["names"] = names
+            ewc["head_names"] = [n for n in names if n.startswith("seg_outputs.")]
         put(arrs, "ewc::fisherA", fA, names); put(arrs, "ewc::paramsA", pA, names)
         put(arrs, "ewc::fisherB", fB, names); put(arrs, "ewc::paramsB", tr.params["taskB"], names)
         put(arrs, "ewc::final_theta", dict(net.named_parameters()), names)
@@ -299,8 +310,11 @@ def main():
         # ------------------------------------------------------------------ RW flow: two tasks, statistics every iteration
         with tempfile.TemporaryDirectory() as td, ref_shim.cuda_as_cpu():
             torch.manual_seed(12345)
-            net = OracleGenericUNet(*TOY_CTOR); net.load_state_dict(init_sd)
+            mh = fresh_mh()
+            net = mh.model
+            assert all(torch.equal(v, init_sd[k]) for k, v in net.state_dict().items())      # same seed -> same initial weights
             tr = new_trainer(RefRW, net, "taskA", rw_lambda=0.4, alpha=0.9, fisher_update_after=2, fisher=dict(), params=dict(),
+                             mh_network=mh, transfer_heads=False,
                              scores=dict(), num_batches_per_epoch=5, prev_param=None, prev_fisher=None, count=0,
                              already_trained_on={"0": {"finished_training_on": [], "fisher_at": None, "params_at": None, "scores_at": None}},
                              rw_data_path=os.path.join(td, "rw_data"), trained_on_path=td, extension="rw", output_folder=td)
@@ -310,7 +324,6 @@ def main():
             tr._update_loss_after_plans_change([[2, 2, 2]] * 2, PATCH)
             base = rw_mod.DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {})
             tr.loss = MultipleOutputLossRW(base, tr.ds_loss_weights, tr.rw_lambda, tr.fisher, tr.params, tr.scores, tr.network.named_parameters())
-            tr.mh_network.heads = OrderedDict()
             rw = {"alpha": 0.9, "fisher_update_after": 2, "iters": 5, "names": names}
             tr.gens = {"taskA": iter(batches(3000, 5)), "taskB": iter(batches(4000, 5))}
             tr.tr_gen = tr.gens["taskA"]

@@ -187,6 +187,14 @@ def _check(arr, key, d, names, sub, rtol):
         assert abs(float(d[n].double().norm()) - stats[i, 1]) <= rtol * max(stats[i, 1], 1e-12) + 1e-12, (key, n)
 
 
+def _fresh_head(net, arr):
+    """add_new_task(task, use_init=True) + assemble_model (MHM.py:435-458,326-377): head tensors <- the initial head state."""
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.startswith("seg_outputs."):
+                p.copy_(torch.from_numpy(arr["init::" + n]))
+
+
 def test_oracle_ewc_flow_equals_reference(ref):
     """EWC.py:179-310 + MH.py:598-656 executed by the reference == oracle.train (losses of both tasks, Fisher / theta* of both)."""
     meta, arr = ref
@@ -202,7 +210,9 @@ def test_oracle_ewc_flow_equals_reference(ref):
     fA, pA = otrain.ewc_after_train(net, opt, [(b["data"], b["target"]) for b in bA[3:]], w)
     _check(arr, "ewc::fisherA", fA, names, 7, 1e-6)
     _check(arr, "ewc::paramsA", pA, names, 7, 1e-7)
-    # task B: penalty of task A with a fresh named_parameters() generator per iteration (EWC.py:247)
+    # task B: MH.py:551-566 registers a NEW head initialised from the very first head state (use_init) and assembles it;
+    # penalty of task A with a fresh named_parameters() generator per iteration (EWC.py:247)
+    _fresh_head(net, arr)
     fisher, params = {"taskA": fA}, {"taskA": pA}
     pen = lambda: olosses.ewc_penalty(net.named_parameters(), fisher, params, 0.4)
     bB = ref_batches(2000, 6)
@@ -235,7 +245,9 @@ def test_oracle_rw_flow_equals_reference(ref):
     _check(arr, "rw::fisherA", fA, gnames, 7, 1e-5)
     _check(arr, "rw::scoresA", sA, gnames, 7, 1e-5)
     _check(arr, "rw::paramsA", pA, names, 7, 1e-7)
-    fisher, params, scores = OrderedDict(taskA=fA), OrderedDict(taskA=pA), OrderedDict(taskA=sA)
+    # RW.py:163-169: the dictionaries already hold the (zero) entry of the task being trained, which the loss omits (DS.py:106)
+    fisher, params, scores = OrderedDict(taskA=fA, taskB=None), OrderedDict(taskA=pA, taskB=None), OrderedDict(taskA=sA, taskB=None)
+    _fresh_head(net, arr)
     st = otrain.rw_new_task_state(net)
     # the reference hands named_parameters() over ONCE (RW.py:95-98): the penalty is live for the first forward only
     gen = [net.named_parameters()]

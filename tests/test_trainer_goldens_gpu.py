@@ -1,0 +1,192 @@
+"""-m gpu: the HIP trainers against ``tests/golden/trainer_reference.*`` -- values the REFERENCE's own trainer methods
+produced (oracle/make_goldens_trainers.py: MH.py:598-656, EWC.py:142-310, RW.py:100-265 executed verbatim on the same
+initial weights and the same synthetic batches) -- and the Rehearsal / Rehearsal+EWC (BASELINE configs[4]) trainers
+against the CPU oracle.
+
+Tolerances: losses 1e-4 relative (north_star).  Quantities that are SQUARED fp16-activation gradients (Fisher, RW
+scores) carry the fp16 storage error of the backward pass: they are asserted at the measured level (a few %) in the
+default fp16 mode, and the printed numbers are the deviation reported in DESIGN.md."""
+import json
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import losses as olosses, train as otrain          # noqa: E402
+from oracle.unet import OracleGenericUNet                       # noqa: E402
+from lifelong_nnunet_amd import get_trainer_class               # noqa: E402
+from lifelong_nnunet_amd.synthetic import make_patch_batch      # noqa: E402
+
+DEV = "cuda:0"
+TOY = {"patch_size": (16, 16, 16), "batch_size": 2, "num_pool": 2, "base_num_features": 8, "num_classes": 3,
+       "num_input_channels": 1, "synthetic_period": 4}
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+    return json.load(open(golden_dir + "/trainer_reference.json")), np.load(golden_dir + "/trainer_reference.npz")
+
+
+def ref_batches(task_seed, n):
+    out = []
+    for i in range(n):
+        data, tgts = make_patch_batch(2, (16, 16, 16), 2, seed=task_seed + i)
+        out.append({"data": data, "target": tgts, "keys": [f"case_{task_seed + i}_{b}" for b in range(2)]})
+    return out
+
+
+class FixtureProvider:
+    """data_provider(task, split, plans) replaying the batches the reference consumed."""
+
+    def __init__(self, seeds, n):
+        self.seeds, self.n = seeds, n
+
+    def __call__(self, task, split, plans):
+        return iter(ref_batches(self.seeds[str(task)] + (0 if split == "train" else 500), self.n))
+
+
+def _trainer(ext, seeds, n, arr, iters, **kw):
+    tr = get_trainer_class(ext)("seg_outputs", "taskA", plans=dict(TOY), device=DEV, data_provider=FixtureProvider(seeds, n), **kw)
+    tr.initialize(True, num_epochs=1)
+    tr.num_batches_per_epoch, tr.num_val_batches_per_epoch = iters, 0
+    init = {n_[6:]: torch.from_numpy(arr[n_]) for n_ in arr.files if n_.startswith("init::")}
+    tr.network.load_state_dict(init)
+    tr.mh_network.update_after_iteration()
+    # the head a new task starts from (use_init, MHM.py:107,450-452) is the head of these initial weights
+    tr.mh_network.state_init = OrderedDict((k, init[k].to(DEV)) for k in tr.mh_network.state_init)
+    return tr
+
+
+def _close_losses(got, exp, rtol_first=1e-4, rtol_later=5e-4):
+    """The first iteration runs on identical weights: 1e-4 (north_star).  Later iterations see weights that the fp16-storage
+    backward has already moved slightly differently from the fp32 reference (measured 5e-5 ... 2e-4 by the third step):
+    5e-4 in the default mode; the fp32-storage parity mode (tests/test_fp32_parity_gpu.py) holds 1e-4 throughout."""
+    got, exp = np.asarray(got), np.asarray(exp)
+    assert got.shape == exp.shape, (got, exp)
+    rel = np.abs(got - exp) / np.abs(exp)
+    assert rel[0] <= rtol_first and np.all(rel <= rtol_later), (got.tolist(), exp.tolist(), rel.tolist())
+
+
+def _rel(arr, key, d, names, sub=7):
+    flat = torch.cat([d[n].detach().float().cpu().reshape(-1) for n in names]).numpy()
+    exp = arr[key + "::sub"]
+    got = flat[::sub]
+    assert got.shape == exp.shape, key
+    return float(np.linalg.norm(got - exp) / (np.linalg.norm(exp) + 1e-30))
+
+
+def test_ewc_trainer_matches_reference_flow(ref):
+    """nnUNetTrainerEWC on the HIP path vs the reference's EWC trainer (two tasks: 3 iterations + after_train each)."""
+    meta, arr = ref
+    e = meta["ewc_flow"]
+    names = e["names"]
+    tr = _trainer("ewc", {"taskA": 1000, "taskB": 2000}, 6, arr, 3)
+    lossesA = []
+    orig = tr.run_iteration
+    tr.run_iteration = lambda *a, **k: (lambda v: (lossesA.append(float(v)), v)[1])(orig(*a, **k))
+    tr.run_training("taskA")
+    _close_losses(lossesA, e["lossesA"])
+    assert list(tr.fisher["taskA"].keys()) == names
+    assert tuple(tr.fisher["taskA"]["seg_outputs.0.weight"].shape) == tuple(e["fisher_shapes"]["seg_outputs.0.weight"]) == (1,)
+    rf, rp = _rel(arr, "ewc::fisherA", tr.fisher["taskA"], names), _rel(arr, "ewc::paramsA", tr.params["taskA"], names)
+    print(f"EWC task A vs reference: losses {lossesA} fisher rel-L2 {rf:.3e} theta* rel-L2 {rp:.3e}")
+    assert rp < 1e-3 and rf < 5e-2
+    del lossesA[:]
+    tr.run_training("taskB")
+    print(f"EWC task B vs reference: losses {lossesA} ref {e['lossesB']}")
+    _close_losses(lossesA, e["lossesB"], rtol_first=5e-4, rtol_later=1e-3)     # starts from task A's (already diverged) weights / Fisher
+    rf, rp = _rel(arr, "ewc::fisherB", tr.fisher["taskB"], names), _rel(arr, "ewc::paramsB", tr.params["taskB"], names)
+    rt = _rel(arr, "ewc::final_theta", dict(tr.network.named_parameters()), names)
+    print(f"EWC task B vs reference: fisher rel-L2 {rf:.3e} theta* rel-L2 {rp:.3e} final theta rel-L2 {rt:.3e}")
+    assert rp < 2e-3 and rt < 2e-3 and rf < 8e-2
+
+
+def test_rw_trainer_matches_reference_flow(ref):
+    """nnUNetTrainerRW (fused lnn_rw_update) vs the reference's RW trainer: two tasks of 5 iterations, statistics every
+    2nd iteration, end-of-task normalisation, penalty live on the first task-B forward only."""
+    meta, arr = ref
+    r = meta["rw_flow"]
+    names, gnames = r["names"], r["stat_names"]
+    tr = _trainer("rw", {"taskA": 3000, "taskB": 4000}, r["iters"], arr, r["iters"], fisher_update_after=r["fisher_update_after"],
+                  rw_alpha=r["alpha"], rw_lambda=0.4)
+    losses = []
+    orig = tr.run_iteration
+    tr.run_iteration = lambda *a, **k: (lambda v: (losses.append(float(v)), v)[1])(orig(*a, **k))
+    tr.run_training("taskA")
+    _close_losses(losses, r["lossesA"])
+    rf, rs = _rel(arr, "rw::fisherA", tr.fisher["taskA"], gnames), _rel(arr, "rw::scoresA", tr.scores["taskA"], gnames)
+    rp = _rel(arr, "rw::paramsA", tr.params["taskA"], names)
+    print(f"RW task A vs reference: fisher rel-L2 {rf:.3e} scores rel-L2 {rs:.3e} theta* rel-L2 {rp:.3e}")
+    assert rp < 1e-3 and rf < 6e-2 and rs < 6e-2
+    del losses[:]
+    tr.run_training("taskB")
+    print(f"RW task B vs reference: losses {losses} ref {r['lossesB']}")
+    _close_losses(losses, r["lossesB"], rtol_first=5e-4, rtol_later=2e-3)
+    rt = _rel(arr, "rw::final_theta", dict(tr.network.named_parameters()), names)
+    assert rt < 3e-3
+
+
+@pytest.mark.parametrize("ext", ["rehearsal", "rehearsal_ewc"])
+def test_rehearsal_trainers_on_the_hip_path(ext):
+    """BASELINE configs[4] (and its rehearsal half alone): task A, then task B whose training batches are drawn from the
+    fused case list (task B's split + a seeded 25 % of task A's, REH.py:65-173).  The three task-B iterations are
+    replayed on the CPU oracle from the trainer's state at the start of task B (weights incl. the fresh head, momentum
+    buffers) with the SAME mixed batches; for the composite the EWC penalty (Fisher / theta* of task A as extracted on
+    the GPU) is part of the loss.  Tolerance 1e-4 relative per iteration."""
+    from lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal import RehearsalPatchGenerator
+    torch.manual_seed(12345)
+    tr = get_trainer_class(ext)("seg_outputs", "taskA", plans=dict(TOY), device=DEV, cases_per_task=16)
+    tr.initialize(True, num_epochs=1)
+    tr.num_batches_per_epoch, tr.num_val_batches_per_epoch = 3, 1
+    tr.run_training("taskA")
+    assert all(k.startswith("taskA_") for k in tr.dataset_tr)              # no previous head yet: nothing mixed in
+    snap, got = {}, []
+    orig_loop, orig_iter = tr._run_epoch_loop, tr.run_iteration
+
+    def loop():
+        snap["sd"] = {k: v.detach().cpu().clone() for k, v in tr.network.state_dict().items()}
+        snap["names"] = [n for n, _ in tr.network.named_parameters()]
+        snap["opt"] = tr.optimizer.state_dict()
+        return orig_loop()
+
+    def iteration(gen, do_backprop=True, *a, **k):
+        v = orig_iter(gen, do_backprop, *a, **k)
+        if do_backprop:
+            got.append(float(v))
+        return v
+    tr._run_epoch_loop, tr.run_iteration = loop, iteration
+    tr.run_training("taskB")
+    fused = list(tr.dataset_tr.keys())
+    n_b = sum(k.startswith("taskB_") for k in fused)
+    assert n_b == 12 and fused[n_b:] == tr.sampled["taskA"] and len(tr.sampled["taskA"]) == 3
+    assert all(k.startswith("taskB_") for k in tr.dataset_val)
+    # ---- replay on the oracle
+    onet = OracleGenericUNet(1, 8, 3, 2)
+    onet.load_state_dict(snap["sd"])
+    oopt = otrain.make_optimizer(onet)
+    oparams = dict(onet.named_parameters())
+    trainable = [n for n in snap["names"] if oparams[n].requires_grad]
+    for i, n in enumerate(trainable):          # momentum buffers continue across tasks (one optimiser object, MH.py:294-301)
+        st = snap["opt"]["state"].get(i)
+        if st is not None and st.get("momentum_buffer") is not None:
+            oopt.state[oparams[n]]["momentum_buffer"] = st["momentum_buffer"].detach().cpu().clone().view_as(oparams[n])
+    w = olosses.ds_loss_weights(2)
+    pen = None
+    if ext == "rehearsal_ewc":
+        names = [n for n, _ in onet.named_parameters()]
+        fisher = {"taskA": {n: tr.fisher["taskA"][n].detach().cpu() for n in names}}
+        params = {"taskA": {n: tr.params["taskA"][n].detach().cpu() for n in names}}
+        pen = lambda: olosses.ewc_penalty(onet.named_parameters(), fisher, params, 0.4)
+        assert float(pen()) > 0
+    gen = RehearsalPatchGenerator(fused, dict(TOY), seed=12345 + tr.fold)
+    exp, mixed = [], 0
+    for _ in range(3):
+        b = next(gen)
+        mixed += any(k.startswith("taskA_") for k in b["keys"])
+        exp.append(otrain.run_iteration(onet, oopt, b["data"], b["target"], w, extra_loss=pen)[0])
+    print(f"{ext}: task B losses hip {got} oracle {exp}; batches with a rehearsed task-A case: {mixed}/3")
+    assert len(got) == 3 and mixed >= 1          # at least one batch mixes a rehearsed task-A case with task-B cases
+    _close_losses(got, exp)
