@@ -234,8 +234,12 @@ int lnn_fisher_ema(lnn_stream_t s, const float* grad, float* fisher, long n, flo
 int lnn_rw_update(lnn_stream_t s, const float* theta, float* prev, const float* grad, float* fisher, float* score,
                   long n, float inv_scale, float max_norm, const double* ctrl, float alpha, float eps, int have_prev);
 /* out2[0] += sum (g*unscale)^2 (double), out2[1] += number of non-finite elements (double);
- * zero_first != 0 clears out2 before (several arena ranges can accumulate into one pair) */
+ * zero_first != 0 clears the pair before (several arena ranges can accumulate into one pair).  Deterministic two-stage
+ * reduction (fixed summation order, no atomics: data-parallel ranks holding identical gradients get identical clip
+ * coefficients): out2 must have room for lnn_flat_reduce_ws_doubles() doubles -- the pair first, block partials after. */
 int lnn_gradnorm_sumsq(lnn_stream_t s, const float* grad, long n, float unscale, double* out2, int zero_first);
+/* doubles the `ws` / `out2` argument of lnn_ewc_penalty_fwd / lnn_gradnorm_sumsq must hold */
+long lnn_flat_reduce_ws_doubles(void);
 int lnn_sgd_nesterov_step(lnn_stream_t s, float* theta, float* momentum_buf, const float* grad, long n,
                           float lr, float momentum, float weight_decay, float grad_scale, int first_step);
 

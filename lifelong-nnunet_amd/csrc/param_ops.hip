@@ -28,6 +28,11 @@ extern "C" int lnn_device_info(int* cu_count, int* clock_khz, char* name, int na
 namespace {
 constexpr int NT = 256;
 
+int red_blocks(long n) {                 // blocks of a two-stage reduction: <= RED_BLOCKS partial sums
+    long b = (n + (long)NT * 16 - 1) / ((long)NT * 16);
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
 int flat_blocks(long n, int per_thread) {
     long b = (n + (long)NT * per_thread - 1) / ((long)NT * per_thread);
     if (b > 2048) b = 2048;
@@ -126,38 +131,91 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
     }
 }
 
+// Flat-arena reductions are deterministic: every block writes its partial sum to the caller's scratch and ONE block adds
+// the partials in a fixed order (fp64 atomics from ~2000 blocks onto one address serialise in L2, 50-100 ns each, and
+// make the clip coefficient differ between data-parallel ranks in the last bit).  All flat kernels move 16 bytes per lane.
+constexpr int RED_BLOCKS = 512;          // partial sums per reduction = what lnn_flat_reduce_ws_doubles() reports
+
+__device__ __forceinline__ void block_sum_d(double (&v)[2], double* sm) {      // fixed-order block reduction (256 threads)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = wave_sum_d(v[i]);
+    __syncthreads();
+    if (lane == 0) { sm[wid * 2] = v[0]; sm[wid * 2 + 1] = v[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v[0] = v[1] = 0.0;
+        for (int w = 0; w < NT / 64; ++w) { v[0] += sm[w * 2]; v[1] += sm[w * 2 + 1]; }
+    }
+}
+
+// out[k] (+)= sum_b partial[2 b + k], k = 0, 1
+__global__ __launch_bounds__(NT) void reduce_partials_kernel(const double* __restrict__ partial, int nblocks, double* out, int accumulate) {
+    __shared__ double sm[2 * (NT / 64)];
+    double v[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += NT) { v[0] += partial[2 * b]; v[1] += partial[2 * b + 1]; }
+    block_sum_d(v, sm);
+    if (threadIdx.x == 0) {
+        out[0] = (accumulate ? out[0] : 0.0) + v[0];
+        out[1] = (accumulate ? out[1] : 0.0) + v[1];
+    }
+}
+
 __global__ __launch_bounds__(NT) void ewc_fwd_kernel(const float* __restrict__ th, const float* __restrict__ ts,
-                                                     const float* __restrict__ f, long n, double* ws) {
-    __shared__ float sm[NT / 64];
-    float acc[1] = {0.f};
+                                                     const float* __restrict__ f, long n, double* partial) {
+    __shared__ double sm[2 * (NT / 64)];
+    float acc = 0.f;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
         const floatx4 a = reinterpret_cast<const floatx4*>(th)[i], b = reinterpret_cast<const floatx4*>(ts)[i],
                       c = reinterpret_cast<const floatx4*>(f)[i];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = a[e] - b[e]; acc[0] += c[e] * d * d; }
+        for (int e = 0; e < 4; ++e) { const float d = a[e] - b[e]; acc += c[e] * d * d; }
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
         const float d = th[i] - ts[i];
-        acc[0] += f[i] * d * d;
+        acc += f[i] * d * d;
     }
-    block_sum<1>(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(ws, (double)acc[0]);
+    double v[2] = {(double)acc, 0.0};
+    block_sum_d(v, sm);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = v[0]; partial[2 * blockIdx.x + 1] = 0.0; }
 }
 __global__ void ewc_finalize_kernel(const double* ws, float lambda, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(0.5 * (double)lambda * ws[0]);
 }
 __global__ __launch_bounds__(NT) void ewc_bwd_kernel(const float* __restrict__ th, const float* __restrict__ ts,
                                                      const float* __restrict__ f, long n, float coef,
-                                                     const float* __restrict__ coef_dev, float* __restrict__ g) {
+                                                     const float* __restrict__ coef_dev, float* __restrict__ g, int vec) {
     if (coef_dev) coef *= coef_dev[0];
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) g[i] += coef * f[i] * (th[i] - ts[i]);
+    const long n4 = vec ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        const floatx4 a = reinterpret_cast<const floatx4*>(th)[i], b = reinterpret_cast<const floatx4*>(ts)[i],
+                      c = reinterpret_cast<const floatx4*>(f)[i];
+        floatx4 o = reinterpret_cast<floatx4*>(g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += coef * c[e] * (a[e] - b[e]);
+        reinterpret_cast<floatx4*>(g)[i] = o;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) g[i] += coef * f[i] * (th[i] - ts[i]);
 }
 
 template <int MODE>  // 0 square, 1 accumulate, 2 ema
 __global__ __launch_bounds__(NT) void fisher_kernel(const float* __restrict__ g, float* __restrict__ f, long n, float unscale,
-                                                    float a) {
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+                                                    float a, int vec) {
+    const long n4 = vec ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        const floatx4 gv = reinterpret_cast<const floatx4*>(g)[i];
+        floatx4 fv = MODE == 0 ? floatx4{0, 0, 0, 0} : reinterpret_cast<floatx4*>(f)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = gv[e] * unscale, sq = x * x;
+            if (MODE == 0) fv[e] = sq;
+            else if (MODE == 1) fv[e] += a * sq;
+            else fv[e] = a * sq + (1.f - a) * fv[e];
+        }
+        reinterpret_cast<floatx4*>(f)[i] = fv;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
         const float x = g[i] * unscale, sq = x * x;
         if (MODE == 0) f[i] = sq;
         else if (MODE == 1) f[i] += a * sq;
@@ -165,15 +223,25 @@ __global__ __launch_bounds__(NT) void fisher_kernel(const float* __restrict__ g,
     }
 }
 
-__global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ g, long n, float unscale, double* out2) {
-    __shared__ float sm[2 * (NT / 64)];
+__global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ g, long n, float unscale, double* partial, int vec) {
+    __shared__ double sm[2 * (NT / 64)];
     float acc[2] = {0.f, 0.f};
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const long n4 = vec ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        const floatx4 gv = reinterpret_cast<const floatx4*>(g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = gv[e] * unscale;
+            if (!isfinite(x)) acc[1] += 1.f; else acc[0] += x * x;
+        }
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
         const float x = g[i] * unscale;
         if (!isfinite(x)) acc[1] += 1.f; else acc[0] += x * x;
     }
-    block_sum<2>(acc, sm);
-    if (threadIdx.x == 0) { atomicAdd(out2, (double)acc[0]); atomicAdd(out2 + 1, (double)acc[1]); }
+    double v[2] = {(double)acc[0], (double)acc[1]};
+    block_sum_d(v, sm);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = v[0]; partial[2 * blockIdx.x + 1] = v[1]; }
 }
 
 // torch.optim.SGD(nesterov=True, dampening=0): g += wd*theta; buf = g (first) | mu*buf + g; theta -= lr*(g + mu*buf)
@@ -194,14 +262,27 @@ __global__ __launch_bounds__(NT) void sgd_kernel(float* __restrict__ th, float* 
 //   any non-finite gradient -> the whole step is skipped (GradScaler.step semantics, MH.py:630)
 __global__ __launch_bounds__(NT) void sgd_clipped_kernel(float* __restrict__ th, float* __restrict__ buf,
                                                          const float* __restrict__ g, long n, float lr, float mu, float wd,
-                                                         float inv_scale, float max_norm, const double* __restrict__ ctrl) {
+                                                         float inv_scale, float max_norm, const double* __restrict__ ctrl, int vec) {
     if (ctrl[1] > 0.0) return;
     float gs = inv_scale;
     if (max_norm > 0.f) {
         const float coef = max_norm / ((float)sqrt(ctrl[0]) + 1e-6f);
         if (coef < 1.f) gs *= coef;
     }
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const long n4 = vec ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        floatx4 t = reinterpret_cast<floatx4*>(th)[i], b = reinterpret_cast<floatx4*>(buf)[i];
+        const floatx4 gv = reinterpret_cast<const floatx4*>(g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = gv[e] * gs + wd * t[e];
+            b[e] = mu * b[e] + d;
+            t[e] = t[e] - lr * (d + mu * b[e]);
+        }
+        reinterpret_cast<floatx4*>(buf)[i] = b;
+        reinterpret_cast<floatx4*>(th)[i] = t;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
         const float t = th[i];
         const float d = g[i] * gs + wd * t;
         const float b = mu * buf[i] + d;
@@ -298,9 +379,10 @@ extern "C" int lnn_ewc_penalty_fwd(lnn_stream_t s_, const float* theta, const fl
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(theta && theta_star && fisher && out && ws, "lnn_ewc_penalty_fwd: null pointer");
     LNN_REQUIRE(lnn_aligned16(theta) && lnn_aligned16(theta_star) && lnn_aligned16(fisher), "lnn_ewc_penalty_fwd: arenas must be 16-byte aligned");
-    hipMemsetAsync(ws, 0, sizeof(double), s);
-    hipLaunchKernelGGL(ewc_fwd_kernel, dim3(flat_blocks(n, 16)), dim3(NT), 0, s, theta, theta_star, fisher, n, ws);
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(ewc_fwd_kernel, dim3(nb), dim3(NT), 0, s, theta, theta_star, fisher, n, ws + 2);
     LNN_CHECK_LAUNCH("lnn_ewc_penalty_fwd");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(NT), 0, s, ws + 2, nb, ws, 0);
     hipLaunchKernelGGL(ewc_finalize_kernel, dim3(1), dim3(64), 0, s, ws, lambda, out);
     LNN_CHECK_LAUNCH("lnn_ewc_penalty_fwd(finalize)");
     return LNN_OK;
@@ -310,8 +392,9 @@ extern "C" int lnn_ewc_penalty_bwd(lnn_stream_t s_, const float* theta, const fl
                                    float lambda, float gscale, const float* gscale_dev, float* grad) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(theta && theta_star && fisher && grad, "lnn_ewc_penalty_bwd: null pointer");
-    hipLaunchKernelGGL(ewc_bwd_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, theta_star, fisher, n, lambda * gscale,
-                       gscale_dev, grad);
+    const int vec = lnn_aligned16(theta) && lnn_aligned16(theta_star) && lnn_aligned16(fisher) && lnn_aligned16(grad);
+    hipLaunchKernelGGL(ewc_bwd_kernel, dim3(flat_blocks(n, 16)), dim3(NT), 0, s, theta, theta_star, fisher, n, lambda * gscale,
+                       gscale_dev, grad, vec);
     LNN_CHECK_LAUNCH("lnn_ewc_penalty_bwd");
     return LNN_OK;
 }
@@ -319,31 +402,38 @@ extern "C" int lnn_ewc_penalty_bwd(lnn_stream_t s_, const float* theta, const fl
 extern "C" int lnn_fisher_square(lnn_stream_t s_, const float* grad, float* fisher, long n, float unscale) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(grad && fisher, "lnn_fisher_square: null pointer");
-    hipLaunchKernelGGL((fisher_kernel<0>), dim3(flat_blocks(n, 8)), dim3(NT), 0, s, grad, fisher, n, unscale, 0.f);
+    hipLaunchKernelGGL((fisher_kernel<0>), dim3(flat_blocks(n, 16)), dim3(NT), 0, s, grad, fisher, n, unscale, 0.f,
+                       (int)(lnn_aligned16(grad) && lnn_aligned16(fisher)));
     LNN_CHECK_LAUNCH("lnn_fisher_square");
     return LNN_OK;
 }
 extern "C" int lnn_fisher_accumulate(lnn_stream_t s_, const float* grad, float* fisher, long n, float unscale, float weight) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(grad && fisher, "lnn_fisher_accumulate: null pointer");
-    hipLaunchKernelGGL((fisher_kernel<1>), dim3(flat_blocks(n, 8)), dim3(NT), 0, s, grad, fisher, n, unscale, weight);
+    hipLaunchKernelGGL((fisher_kernel<1>), dim3(flat_blocks(n, 16)), dim3(NT), 0, s, grad, fisher, n, unscale, weight,
+                       (int)(lnn_aligned16(grad) && lnn_aligned16(fisher)));
     LNN_CHECK_LAUNCH("lnn_fisher_accumulate");
     return LNN_OK;
 }
 extern "C" int lnn_fisher_ema(lnn_stream_t s_, const float* grad, float* fisher, long n, float unscale, float alpha) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(grad && fisher, "lnn_fisher_ema: null pointer");
-    hipLaunchKernelGGL((fisher_kernel<2>), dim3(flat_blocks(n, 8)), dim3(NT), 0, s, grad, fisher, n, unscale, alpha);
+    hipLaunchKernelGGL((fisher_kernel<2>), dim3(flat_blocks(n, 16)), dim3(NT), 0, s, grad, fisher, n, unscale, alpha,
+                       (int)(lnn_aligned16(grad) && lnn_aligned16(fisher)));
     LNN_CHECK_LAUNCH("lnn_fisher_ema");
     return LNN_OK;
 }
 
+extern "C" long lnn_flat_reduce_ws_doubles(void) { return 2 + 2 * 512; }
+
 extern "C" int lnn_gradnorm_sumsq(lnn_stream_t s_, const float* grad, long n, float unscale, double* out2, int zero_first) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(grad && out2, "lnn_gradnorm_sumsq: null pointer");
-    if (zero_first) hipMemsetAsync(out2, 0, 2 * sizeof(double), s);
-    hipLaunchKernelGGL(gradnorm_kernel, dim3(flat_blocks(n, 16)), dim3(NT), 0, s, grad, n, unscale, out2);
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(nb), dim3(NT), 0, s, grad, n, unscale, out2 + 2, (int)lnn_aligned16(grad));
     LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(NT), 0, s, out2 + 2, nb, out2, zero_first ? 0 : 1);
+    LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq(reduce)");
     return LNN_OK;
 }
 
@@ -362,8 +452,8 @@ extern "C" int lnn_sgd_nesterov_step_clipped(lnn_stream_t s_, float* theta, floa
                                              const double* ctrl) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(theta && buf && grad && ctrl, "lnn_sgd_nesterov_step_clipped: null pointer");
-    hipLaunchKernelGGL(sgd_clipped_kernel, dim3(flat_blocks(n, 8)), dim3(NT), 0, s, theta, buf, grad, n, lr, momentum,
-                       weight_decay, inv_scale, max_norm, ctrl);
+    hipLaunchKernelGGL(sgd_clipped_kernel, dim3(flat_blocks(n, 16)), dim3(NT), 0, s, theta, buf, grad, n, lr, momentum,
+                       weight_decay, inv_scale, max_norm, ctrl, (int)(lnn_aligned16(theta) && lnn_aligned16(buf) && lnn_aligned16(grad)));
     LNN_CHECK_LAUNCH("lnn_sgd_nesterov_step_clipped");
     return LNN_OK;
 }

@@ -108,7 +108,7 @@ class _EWCPenaltyFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, arena, fishers, stars, ewc_lambda):
-        ws = torch.empty(2, dtype=torch.float64, device=arena.theta.device)
+        ws = torch.empty(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=arena.theta.device)
         total = torch.zeros((), device=arena.theta.device)
         out = torch.empty(1, device=arena.theta.device)
         for f, s in zip(fishers, stars):

@@ -157,8 +157,15 @@ class MultiHead_Module(nn.Module):
         self.assemble_model(activate_with)
 
     def head_weights(self, task):
-        """seg-head tensors of ``task`` in engine order (used for multi-head evaluation on one body pass)."""
-        return [p for _, p in self.heads[str(task)].named_parameters()]
+        """seg-head tensors of ``task`` in engine order (used for multi-head evaluation on one body pass).  Only valid when
+        the head IS the segmentation layers (split ``seg_outputs``, the split the reference's tests and docs use,
+        test_multi_head_trainer.py:149): for a deeper split the head also holds decoder blocks, which a different set of
+        1x1x1 weights on shared body activations cannot express -- refuse instead of silently mis-reading tensors."""
+        named = list(self.heads[str(task)].named_parameters())
+        assert all(n.startswith("seg_outputs.") for n, _ in named), \
+            "multi-head evaluation on one body pass needs split_at='seg_outputs' (head of task '{}' holds {}); " \
+            "assemble_model(task) + a full forward per head is required for deeper splits".format(task, [n for n, _ in named][:3])
+        return [p for _, p in sorted(named, key=lambda kv: int(kv[0].split('.')[1]))]
 
     def get_model_type(self):
         return self.model.__class__.__name__

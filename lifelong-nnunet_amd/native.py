@@ -63,6 +63,7 @@ SIGNATURES = {
     "lnn_softmax_accumulate": (_i, [_p, _p, _p, _p, _p] + [_i] * 11 + [_f, _i]),
     "lnn_softmax_finalize": (_i, [_p, _p, _p, _i, _l, _p]),
     "lnn_gradnorm_sumsq": (_i, [_p, _p, _l, _f, _p, _i]),
+    "lnn_flat_reduce_ws_doubles": (_sz, []),
     "lnn_sgd_nesterov_step_clipped": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p]),
     "lnn_sgd_nesterov_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
     "lnn_cast_f32_to_h": (_i, [_p, _p, _p, _l]),

@@ -91,7 +91,9 @@ class FusedSGD:
         self.net = net
         self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "momentum": momentum, "nesterov": True,
                               "params": [p for _, p in net._named if p.requires_grad]}]
-        self.ctrl = torch.zeros(2, dtype=torch.float64, device=net.arena.theta.device)
+        # ctrl[0:2] = {sum g^2, #non-finite}; the rest is the scratch of the deterministic two-stage reduction
+        self._ctrl_buf = torch.zeros(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=net.arena.theta.device)
+        self.ctrl = self._ctrl_buf[:2]
         self._ctrl_valid = False
 
     def zero_grad(self, set_to_none=False):
@@ -103,7 +105,7 @@ class FusedSGD:
         a = self.net.arena
         first = 1
         for lo, hi in _ranges(self.net):
-            nat.call("lnn_gradnorm_sumsq", _Off(a.grad, lo), hi - lo, float(inv_scale), self.ctrl, first)
+            nat.call("lnn_gradnorm_sumsq", _Off(a.grad, lo), hi - lo, float(inv_scale), self._ctrl_buf, first)
             first = 0
         self._ctrl_valid = True
 

@@ -5,13 +5,19 @@ Mirror of nnunet_ext/training/network_training/lwf/nnUNetTrainerLWF.py: ``initia
 teacher logits for every head :244-251, phase 3 LwF loss :253-261), ``run_iteration`` :298-370; and of
 ``calculate_target_logits`` (nnunet_ext/utilities/helpful_functions.py:207-266).
 
-Reference behaviour kept in parity mode: the distillation term enters the loss VALUE only -- predictions are
-detached (LWF.py:343), so it carries no gradient; targets are looked up by ``batch_idx % 250`` (:349).
+Reference behaviour kept in parity mode (pinned by tests/golden/trainer_reference.json:lwf_flow, which the reference's
+own ``run_iteration`` / ``calculate_target_logits`` produced):
+  * the distillation term enters the loss VALUE only -- predictions are detached (LWF.py:343), so it carries no
+    gradient; targets are looked up by ``batch_idx % 250`` (:349);
+  * ``tee(data_generator, 1)[0]`` (LWF.py:328,357) does not copy a generator, it ADVANCES it: head j is evaluated on
+    batch k+j, the network trains on batch k+T, batch k+T+1 is dropped (:361) -- T+2 batches per iteration, and the KL
+    compares predictions and teacher logits of unrelated patches.  ``same_batch_predictions=True`` is the fix behind a
+    flag (what the reference's comments intend): every head is evaluated on the training batch, which lets the old heads'
+    1x1x1 convs run on the body activations the training forward just produced (``engine.forward(body=False)``) instead
+    of T extra full forwards;
+  * the LwF branch also runs for the no-backprop iterations of the epoch loop (only ``freeze_run`` / ``do_val`` select the
+    plain branch, LWF.py:303), so ``batch_idx`` advances there too.
 MI355X-first differences that do not change results:
-  * the reference runs one complete eval forward per head per iteration (deepcopy + load_state_dict of the
-    model each time, MHM.py:343-359).  InstanceNorm keeps no running statistics and dropout is p=0, so the
-    body activations of those passes equal the training pass': the old heads' 1x1x1 convs are evaluated on
-    the body activations the training forward just produced (``engine.forward(body=False)``).
   * teacher logits and predictions stay in HBM (288 GB) instead of round-tripping through host memory
     (``.cpu()`` at LWF.py:343, HF.py:254); the KL is one fused device reduction instead of CPU fp32 ops.
 """
@@ -39,10 +45,11 @@ def calculate_target_logits(mh_network, gen, num_batches_per_epoch, fp16=True, g
 
 
 class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
-    def __init__(self, split, task, *args, lwf_temperature=2.0, **kwargs):
+    def __init__(self, split, task, *args, lwf_temperature=2.0, same_batch_predictions=False, **kwargs):
         kwargs.setdefault("extension", "lwf")
         super().__init__(split, task, *args, **kwargs)
         self.lwf_temperature = lwf_temperature
+        self.same_batch_predictions = same_batch_predictions
         self.freeze_run = True
         self.do_val = False
         self.batch_idx = 0
@@ -89,13 +96,17 @@ class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
         self.freeze_run = True
         return ret
 
-    def _lwf_active(self, do_backprop):
-        return not (self.freeze_run or self.do_val or not do_backprop or len(self.mh_network.heads) <= 1
-                    or self.loss is not self.LwFloss)
+    def _lwf_active(self):
+        """LWF.py:303,309: the LwF branch runs unless freeze_run / do_val, and only with more than one head."""
+        return not (self.freeze_run or self.do_val or len(self.mh_network.heads) <= 1 or self.loss is not self.LwFloss)
+
+    def _targets(self, heads):
+        return [self.target_logits[t][self.batch_idx % len(self.target_logits[t])] for t in heads[:-1]]
 
     def on_forward_done(self, data, output, do_backprop):
-        """LWF.py:315-353: predictions of every head on the CURRENT batch + stored teacher logits -> loss."""
-        if not self._lwf_active(do_backprop):
+        """``same_batch_predictions`` mode: predictions of every head on the CURRENT batch, the old heads evaluated on
+        the body activations the training forward just produced."""
+        if not (self._lwf_active() and self.same_batch_predictions):
             return
         heads = list(self.mh_network.heads.keys())
         eng = self.network.engine_for(data)
@@ -104,13 +115,25 @@ class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
             for t in heads:
                 if t == str(self.mh_network.active_task):
                     all_pred_logits.append(output[0].detach())
-                else:   # old head on the body activations the training forward just produced
+                else:
                     all_pred_logits.append(eng.forward(data, seg_weights=self.mh_network.head_weights(t), body=False)[-1])
-        all_target_logits = [self.target_logits[t][self.batch_idx % self.num_batches_per_epoch] for t in heads[:-1]]
-        self.loss.update_logits(all_pred_logits, all_target_logits)
+        self.loss.update_logits(all_pred_logits, self._targets(heads))
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, *args, **kwargs):
-        ret = super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
-        if self._lwf_active(do_backprop):
-            self.batch_idx += 1       # LWF.py:364
+        if not self._lwf_active():
+            return super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
+        if self.same_batch_predictions:
+            ret = super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
+        else:
+            # LWF.py:315-361 as the code runs: one batch PER HEAD for the predictions, the next one trains, one more is dropped
+            heads = list(self.mh_network.heads.keys())
+            preds = []
+            with torch.no_grad():
+                for t in heads:
+                    x = torch.as_tensor(next(data_generator)['data']).to(self.device, non_blocking=True)
+                    preds.append(self.network.forward_heads(x, [self.mh_network.head_weights(t)])[0])
+            self.loss.update_logits(preds, self._targets(heads))
+            ret = super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
+            next(data_generator)
+        self.batch_idx += 1       # LWF.py:364
         return ret

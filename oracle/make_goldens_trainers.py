@@ -339,6 +339,62 @@ def main():
             put(arrs, "rw::final_theta", dict(net.named_parameters()), names)
         rw["sub"] = SUB
         meta["rw_flow"] = rw
+        # ------------------------------------------------------------------ LwF: teacher logits + phase-3 iterations
+        # (phase 1, the frozen-body warm-up, runs upstream nnUNetTrainer.run_iteration which is not in the reference tree:
+        #  the flow starts phase 2 right after the new head was registered)
+        lwf_mod, RefLWF = ref_shim.import_trainer("lwf", "nnUNetTrainerLWF")
+        from nnunet_ext.training.loss_functions.deep_supervision import MultipleOutputLossLWF
+        from nnunet_ext.utilities.helpful_functions import calculate_target_logits
+
+        class Counting:
+            """The generator object the trainer holds; counts how many batches the reference's tee() copies pull (LWF.py:328,357,361)."""
+            def __init__(self, items):
+                self.items, self.n = items, 0
+
+            def __iter__(self):
+                return self
+
+            def __next__(self):
+                b = self.items[self.n % len(self.items)]
+                self.n += 1
+                return b
+
+        with tempfile.TemporaryDirectory() as td, ref_shim.cuda_as_cpu():
+            torch.manual_seed(12345)
+            mh = fresh_mh()
+            net = mh.model
+            tr = new_trainer(RefLWF, net, "taskA", num_batches_per_epoch=2, mh_network=mh, transfer_heads=False, freeze_run=False,
+                             do_val=False, use_vit=False, ViT_task_specific_ln=False, batch_idx=0, lwf_temperature=2.0,
+                             already_trained_on={"0": {"finished_training_on": []}})
+            tr.initialize_optimizer_and_scheduler()
+            tr._update_loss_after_plans_change([[2, 2, 2]] * 2, PATCH)
+            tr.loss_orig = tr.loss
+            base = lwf_mod.DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {})
+            tr.LwFloss = MultipleOutputLossLWF(base, tr.ds_loss_weights, list(), list(), tr.lwf_temperature)
+            lwf = {"T": 2.0}
+            gA = Counting(batches(5000, 2))
+            tr.network.train()
+            lwf["lossesA"] = [float(tr.run_iteration(gA, True)) for _ in range(2)]          # one head: plain branch (LWF.py:366-367)
+            lwf["batches_consumed_A"] = gA.n
+            mh.add_new_task("taskB", use_init=True)                                          # MH.py:551-552
+            tr.network = mh.assemble_model("taskB", freeze_body=False)                       # LWF.py:244
+            gT = Counting(batches(6000, 6))
+            tr.target_logits = calculate_target_logits(mh, gT, 3, False, gpu_id=-1)          # LWF.py:250 / HF.py:207-266
+            lwf["teacher_batches_consumed"] = gT.n
+            lwf["teacher_tasks"] = list(tr.target_logits.keys())
+            for t_, lst in tr.target_logits.items():
+                for i_, lg in enumerate(lst):
+                    arrs[f"lwf::teacher_{t_}_{i_}"] = lg.numpy()[:, :, ::2, ::2, ::2].copy()     # every 2nd voxel per axis
+            tr.network.train()                                                                # LWF.py:253-256
+            tr.loss = tr.LwFloss
+            tr.task = "taskB"
+            gB = Counting(batches(7000, 12))
+            lwf["lossesB"] = [float(tr.run_iteration(gB, True)) for _ in range(3)]
+            lwf["batches_consumed_B"] = gB.n
+            lwf["batch_idx"] = tr.batch_idx
+            lwf["active_task_after"] = mh.active_task
+            put(arrs, "lwf::final_theta", dict(net.named_parameters()), names)
+        meta["lwf_flow"] = lwf
     finally:
         RefMH.run_training, RefMH.reinitialize = orig_run_training, orig_reinitialize
 

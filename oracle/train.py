@@ -140,6 +140,59 @@ def lwf_loss_value(base_loss, pred_logits, target_logits, temperature=2.0):
     return l
 
 
+def _with_head(net, head_state):
+    """Load one task's head tensors (``seg_outputs.*``) into the running model (MultiHead_Module.assemble_model)."""
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n in head_state:
+                p.copy_(head_state[n])
+
+
+def lwf_target_logits(net, heads, gen, num_batches):
+    """utilities/helpful_functions.py:207-266: for each head IN TURN, ``num_batches`` consecutive batches of ``gen`` go
+    through body + that head; the full-resolution logits are kept.  ``heads``: OrderedDict task -> {name: tensor}."""
+    keep = {n: p.detach().clone() for n, p in net.named_parameters() if n.startswith("seg_outputs.")}
+    out = OrderedDict()
+    for task, hs in heads.items():
+        _with_head(net, hs)
+        out[task] = []
+        for _ in range(num_batches):
+            b = next(gen)
+            with torch.no_grad():
+                out[task].append(net(torch.as_tensor(b["data"]))[0].detach().clone())
+    _with_head(net, keep)
+    return out
+
+
+def lwf_iteration(net, opt, gen, heads, target_logits, batch_idx, weights, temperature=2.0, clip=12.0):
+    """lwf/nnUNetTrainerLWF.py:298-370, the LwF branch (not freeze_run, not do_val, more than one head), as the code runs:
+    every ``tee(data_generator, 1)[0]`` copy pulls from the generator ITSELF, so head j is evaluated on batch k+j, the
+    network is trained on batch k+T, and batch k+T+1 is skipped (:361) -- T+2 batches per iteration.  ``heads``: OrderedDict
+    task -> head state, the LAST one being the task in training, whose tensors live in ``net``.  The KL terms add to the
+    value only (predictions detached, :343).  Returns the loss value."""
+    tasks = list(heads.keys())
+    cur = {n: p.detach().clone() for n, p in net.named_parameters() if n.startswith("seg_outputs.")}
+    preds, targets = [], []
+    for task in tasks:
+        _with_head(net, cur if task == tasks[-1] else heads[task])
+        b = next(gen)
+        with torch.no_grad():
+            preds.append(net(torch.as_tensor(b["data"]))[0].detach())
+        if task != tasks[-1]:
+            targets.append(target_logits[task][batch_idx % 250])
+    _with_head(net, cur)
+    b = next(gen)
+    data, target = torch.as_tensor(b["data"]), [torch.as_tensor(t) for t in b["target"]]
+    opt.zero_grad()
+    out = net(data)
+    l = lwf_loss_value(losses.multiple_output_loss(out, target, weights), preds, targets, temperature)
+    l.backward()
+    torch.nn.utils.clip_grad_norm_(net.parameters(), clip)
+    opt.step()
+    next(gen)
+    return float(l.detach())
+
+
 def rehearsal_sample(train_keys_per_prev_task, samples_in_perc=0.25, seed=3299):
     """rehearsal/nnUNetTrainerRehearsal.py:73,132 -- one ``random.seed(seed)`` then, per previous task in
     head order, ``random.sample(items, round(len * perc))`` over the (sorted) train keys."""

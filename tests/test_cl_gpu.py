@@ -162,7 +162,7 @@ def test_lwf_trainer_flow():
     tr.run_training("taskB")
     assert seen["frozen"] and seen["head_moved"]               # phase 1: body frozen, new head trained
     assert set(tr.target_logits.keys()) == {"taskA", "taskB"} and all(len(v) == 3 for v in tr.target_logits.values())
-    assert tr.batch_idx == 3
+    assert tr.batch_idx == 3 + 1          # 3 training iterations + the epoch's validation iteration (LWF.py:303: only freeze_run / do_val bypass)
     # phase 3 value = base + KL(old head on the current body || stored teacher), recomputed with the oracle
     loss = tr.LwFloss
     assert len(loss.target_logits) == 1 and len(loss.pred_logits) == 2

@@ -259,7 +259,7 @@ def test_param_kernels():
     th, ts, f, gr = (torch.randn(n, generator=g) for _ in range(4))
     f = f.abs()
     thd, tsd, fd, grd = th.to(DEV), ts.to(DEV), f.to(DEV), gr.to(DEV)
-    out = torch.zeros(1, device=DEV); ws = torch.zeros(2, dtype=torch.float64, device=DEV)
+    out = torch.zeros(1, device=DEV); ws = torch.zeros(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=DEV)
     nat.call("lnn_ewc_penalty_fwd", thd, tsd, fd, n, 0.4, out, ws)
     exp = 0.2 * (f.double() * (th.double() - ts.double()) ** 2).sum()
     assert abs(float(out) - float(exp)) <= 1e-6 * float(exp)
@@ -276,6 +276,11 @@ def test_param_kernels():
     nat.call("lnn_gradnorm_sumsq", grd, n, 0.5, ws, 1)
     assert abs(float(ws[0]) - float((0.5 * gr.double()).pow(2).sum())) <= 1e-6 * float(ws[0])
     assert float(ws[1]) == 0
+    first = ws[:2].clone()
+    nat.call("lnn_gradnorm_sumsq", grd, n, 0.5, ws, 1)
+    assert torch.equal(first, ws[:2])        # deterministic reduction: bit-identical on repetition
+    nat.call("lnn_gradnorm_sumsq", grd[1:], n - 1, 0.5, ws, 0)      # misaligned range, accumulating
+    assert abs(float(ws[0]) - float((0.5 * gr.double()).pow(2).sum() + (0.5 * gr[1:].double()).pow(2).sum())) <= 1e-6 * float(ws[0])
     bad = grd.clone(); bad[5] = float("inf"); bad[7] = float("nan")
     nat.call("lnn_gradnorm_sumsq", bad, n, 1.0, ws, 1)
     assert float(ws[1]) == 2

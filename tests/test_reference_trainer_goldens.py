@@ -264,3 +264,47 @@ def test_oracle_rw_flow_equals_reference(ref):
     _check(arr, "rw::fisherB", fB, gnames, 7, 1e-5)
     _check(arr, "rw::scoresB", sB, gnames, 7, 1e-5)
     _check(arr, "rw::final_theta", dict(net.named_parameters()), names, 7, 1e-6)
+
+
+class _Counting:
+    def __init__(self, items):
+        self.items, self.n = items, 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b = self.items[self.n % len(self.items)]
+        self.n += 1
+        return b
+
+
+def test_oracle_lwf_flow_equals_reference(ref):
+    """HF.py:207-266 + LWF.py:298-370 executed by the reference == oracle.train.lwf_*: teacher logits of both heads, three
+    phase-3 iterations (each consuming T + 2 = 4 batches of the generator), loss values (base + KL), updated weights."""
+    meta, arr = ref
+    f = meta["lwf_flow"]
+    names = meta["ewc_flow"]["names"]
+    net = OracleGenericUNet(1, 8, 3, 2)
+    net.load_state_dict({n[6:]: torch.from_numpy(arr[n]) for n in arr.files if n.startswith("init::")})
+    opt = otrain.make_optimizer(net)
+    w = olosses.ds_loss_weights(2)
+    lA = [otrain.run_iteration(net, opt, b["data"], b["target"], w)[0] for b in ref_batches(5000, 2)]
+    assert np.allclose(lA, f["lossesA"], rtol=1e-6)
+    head = lambda: OrderedDict((n, p.detach().clone()) for n, p in net.named_parameters() if n.startswith("seg_outputs."))
+    heads = OrderedDict(taskA=head())
+    _fresh_head(net, arr)                                  # add_new_task("taskB", use_init=True) + assemble_model
+    heads["taskB"] = head()
+    gT = _Counting(ref_batches(6000, 6))
+    teach = otrain.lwf_target_logits(net, heads, gT, 3)
+    assert gT.n == f["teacher_batches_consumed"] and list(teach.keys()) == f["teacher_tasks"]
+    for t in teach:
+        for i, lg in enumerate(teach[t]):
+            exp = arr[f"lwf::teacher_{t}_{i}"]
+            got = lg.numpy()[:, :, ::2, ::2, ::2]
+            assert np.allclose(got, exp, rtol=1e-5, atol=1e-6), (t, i)
+    gB = _Counting(ref_batches(7000, 12))
+    lB = [otrain.lwf_iteration(net, opt, gB, heads, teach, i, w, f["T"]) for i in range(3)]
+    assert gB.n == f["batches_consumed_B"] == 12
+    assert np.allclose(lB, f["lossesB"], rtol=1e-5), (lB, f["lossesB"])
+    _check(arr, "lwf::final_theta", dict(net.named_parameters()), names, 7, 1e-6)
