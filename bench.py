@@ -5,10 +5,13 @@ synthetic 160x192x160 patches -- BASELINE.json configs[1] -- one process per GPU
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --workload c3|c4|c5        (the continual-learning configurations of BASELINE.json, see WORKLOADS)
 
 A "step" is one complete optimisation step (H2D-free: the patches are resident in HBM): forward, deep-supervised
-Dice+CE, scaled backward, gradient all-reduce (N > 1), clip 12, SGD-Nesterov, head re-sync, loss fetch.
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+Dice+CE (+ the trainer's regulariser), scaled backward, gradient all-reduce (N > 1), clip 12, SGD-Nesterov, head re-sync,
+loss fetch.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"); `config.h2d_inclusive` is the same loop with the
+batches arriving from pinned host memory (copy of batch i+1 overlapped with step i), `regulariser_kernels` the HBM
+roofline of the flat-arena / logits kernels at the workload's sizes.
 """
 import argparse
 import json
@@ -22,11 +25,17 @@ if ROOT not in sys.path:
 
 PEAK_MFMA_F16_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level table)
 
-WORKLOADS = {
-    "c2": {"patch_size": (160, 192, 160), "batch_size": 2, "num_pool": 5, "base_num_features": 32,
-           "num_classes": 3, "num_input_channels": 1, "synthetic_period": 1},
-    "c1": {"patch_size": (40, 56, 40), "batch_size": 2, "num_pool": 3, "base_num_features": 32,
-           "num_classes": 3, "num_input_channels": 1, "synthetic_period": 1},
+_C2 = {"patch_size": (160, 192, 160), "batch_size": 2, "num_pool": 5, "base_num_features": 32,
+       "num_classes": 3, "num_input_channels": 1, "synthetic_period": 1}
+WORKLOADS = {       # BASELINE.json configs[...]: (plans, trainer extension, description)
+    "c2": (_C2, "sequential", "BASELINE configs[1]: nnUNetTrainerSequential.run_iteration"),
+    "c1": ({**_C2, "patch_size": (40, 56, 40), "num_pool": 3}, "sequential", "BASELINE configs[0] shapes on the GPU (plumbing size)"),
+    "c3": (_C2, "ewc", "BASELINE configs[2]: nnUNetTrainerEWC.run_iteration on the SECOND task (Dice+CE + EWC penalty over "
+                       "P parameters, forward and backward)"),
+    "c4": ({**_C2, "patch_size": (160, 160, 160)}, "lwf", "BASELINE configs[3]: nnUNetTrainerLWF.run_iteration, phase 3, one "
+           "old head (reference semantics: one extra eval forward per head on its own batch, KL against the stored teacher logits)"),
+    "c5": (_C2, "rehearsal_ewc", "BASELINE configs[4]: nnUNetTrainerRehearsalEWC.run_iteration on the second task "
+           "(mixed-task batches from the fused case list + EWC penalty)"),
 }
 
 
@@ -46,6 +55,49 @@ class ResidentBatches:
     def __next__(self):
         self.i += 1
         return self.items[self.i % len(self.items)]
+
+
+class PrefetchingBatches:
+    """H2D-inclusive variant (the reference's run_iteration starts with to_cuda, MH.py:606-617): batches live in PINNED host
+    memory; the copy of batch i+1 runs on a side stream while step i computes (two device buffers, HIP events both ways)."""
+
+    def __init__(self, items, device):
+        import torch
+        self.torch = torch
+        self.host = [{"data": d["data"].cpu().pin_memory(), "target": [t.cpu().pin_memory() for t in d["target"]], "keys": d["keys"]}
+                     for d in items]
+        self.dev = [{"data": torch.empty_like(items[0]["data"], device=device),
+                     "target": [torch.empty_like(t, device=device) for t in items[0]["target"]]} for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.i = 0
+        self._issue(0, None)
+
+    def _issue(self, i, after):
+        torch = self.torch
+        h, d = self.host[i % len(self.host)], self.dev[i % 2]
+        if after is not None:
+            self.copy_stream.wait_event(after)          # the buffer's previous consumer (step i-2) has been enqueued before `after`
+        with torch.cuda.stream(self.copy_stream):
+            d["data"].copy_(h["data"], non_blocking=True)
+            for a, b in zip(d["target"], h["target"]):
+                a.copy_(b, non_blocking=True)
+            self.ready[i % 2].record(self.copy_stream)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        torch = self.torch
+        i = self.i
+        main = torch.cuda.current_stream()
+        main.wait_event(self.ready[i % 2])
+        done_prev = torch.cuda.Event()
+        done_prev.record(main)                           # everything of step i-1 (the other buffer's reader) is before this
+        self._issue(i + 1, done_prev)
+        self.i += 1
+        d = self.dev[i % 2]
+        return {"data": d["data"], "target": d["target"], "keys": self.host[i % len(self.host)]["keys"]}
 
 
 def time_kernel(fn, iters=5):
@@ -91,6 +143,51 @@ def kernel_rooflines(trainer):
             "kernels": {k: {"tflops": f / t / 1e12, "ms": t * 1e3, "gflop": f / 1e9} for k, (f, t) in res.items()}}
 
 
+def regulariser_rooflines(trainer, plans):
+    """HIP-event timing of the HBM-bound regulariser / optimiser kernels at this workload's sizes (P = flat arena size;
+    logits of the full-resolution level), algorithmic bytes as SURVEY.md 8(d) counts them, against the 8 TB/s HBM peak."""
+    import torch
+    from lifelong_nnunet_amd import native as nat
+    arena = trainer.network.arena
+    P, dev = arena.size, arena.theta.device
+    th, g = arena.theta, arena.grad
+    ts, f, prev, score = (torch.rand(P, device=dev) for _ in range(4))
+    out, ws = torch.zeros(1, device=dev), torch.zeros(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=dev)
+    gs = torch.ones(1, device=dev)
+    mom = torch.zeros(P, device=dev)
+    thc, gc = th.clone(), torch.randn(P, device=dev) * 1e-3
+    B, K = plans["batch_size"], plans["num_classes"]
+    V = 1
+    for d in plans["patch_size"]:
+        V *= d
+    lg = torch.randn((B, K, V), device=dev)
+    lt = torch.randn((B, K, V), device=dev)
+    lab = torch.randint(0, K, (B, V), device=dev).float()
+    kl_out, kl_ws = torch.zeros(1, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    dws = torch.zeros(nat.query("lnn_dice_ce_ws_doubles", B, K), dtype=torch.float64, device=dev)
+    dl = torch.empty_like(lg)
+    cases = {
+        "ewc_penalty_fwd": (12 * P, lambda: nat.call("lnn_ewc_penalty_fwd", thc, ts, f, P, 0.4, out, ws)),
+        "ewc_penalty_bwd": (20 * P, lambda: nat.call("lnn_ewc_penalty_bwd", thc, ts, f, P, 0.4, 1.0, gs, gc)),
+        "fisher_square": (8 * P, lambda: nat.call("lnn_fisher_square", gc, f, P, 1.0)),
+        "fisher_ema": (12 * P, lambda: nat.call("lnn_fisher_ema", gc, f, P, 1.0, 0.9)),
+        "rw_update": (32 * P, lambda: nat.call("lnn_rw_update", thc, prev, gc, f, score, P, 1.0, 12.0, ws, 0.9, 1e-8, 1)),
+        "gradnorm_sumsq": (4 * P, lambda: nat.call("lnn_gradnorm_sumsq", gc, P, 1.0, ws, 1)),
+        "sgd_nesterov_clipped": (20 * P, lambda: nat.call("lnn_sgd_nesterov_step_clipped", thc, mom, gc, P, 1e-3, 0.99, 3e-5, 1.0, 12.0, ws)),
+        "kl_logits (LwF, full-res logits)": (2 * 4 * B * K * V, lambda: nat.call("lnn_kl_logits", lg, lt, B, K, V, 2.0, kl_out, kl_ws)),
+        "dice_ce_fwd (full-res level)": ((4 * K + 4) * B * V, lambda: nat.call("lnn_dice_ce_fwd", lg, lab, B, K, V, 0, 1e-5, out, dws)),
+        "dice_ce_bwd (full-res level)": ((8 * K + 4) * B * V, lambda: nat.call("lnn_dice_ce_bwd", lg, lab, B, K, V, 0, 1e-5, dws, 1.0, None, 1.0, dl)),
+    }
+    res = {}
+    for name, (nbytes, fn) in cases.items():
+        try:
+            t = time_kernel(fn, iters=10)
+            res[name] = {"ms": t * 1e3, "algorithmic_MB": nbytes / 1e6, "GBps": nbytes / t / 1e9, "frac_of_8TBps": nbytes / t / 8e12}
+        except Exception as e:                     # an entry this build does not export must not hide the others
+            res[name] = {"error": repr(e)}
+    return {"P": P, "logits_elems": B * K * V, "kernels": res}
+
+
 def cpu_baseline(plans, flops_full):
     """The oracle (pure PyTorch CPU fp32 restatement of the reference's step) on the GPU box's host cores, on a
     bounded sample: the SAME 5-level network on a 128x128x128 sub-patch (43 % of the voxels), B=1, one warm-up and
@@ -124,7 +221,7 @@ def cpu_baseline(plans, flops_full):
                 break
     except OSError:
         pass
-    return {"value": ratio / dt, "unit": "patches/s", "cores": cores, "kind": "port", "cpu": cpu_name,
+    return {"value": ratio / dt, "unit": "patches/s", "cores": cores, "kind": "port", "extrapolated": True, "cpu": cpu_name,
             "sample": f"oracle.train.run_iteration, same {plans['num_pool']}-level U-Net, ONE {sub[0]}x{sub[1]}x{sub[2]} "
                       f"patch (B=1, {ratio:.4f} of the voxels of a {'x'.join(map(str, plans['patch_size']))} patch) in "
                       f"{dt:.1f} s, scaled by the voxel ratio",
@@ -162,19 +259,56 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from lifelong_nnunet_amd import get_trainer_class, native as nat
-    plans = dict(WORKLOADS[args.workload])
-    Trainer = get_trainer_class("sequential")
+    plans, ext, wl_desc = WORKLOADS[args.workload]
+    plans = dict(plans)
+    Trainer = get_trainer_class(ext)
 
     def provider(task, split, p):
         from lifelong_nnunet_amd.training.network_training.multihead.nnUNetTrainerMultiHead import default_data_provider
         return ResidentBatches(default_data_provider(task, split, p, seed=12345 + 7919 * rank), device)
 
-    tr = Trainer("seg_outputs", "synthetic_task_A", plans=plans, data_provider=provider, device=device, fold=0)
+    kw = {"cases_per_task": 8} if ext == "rehearsal_ewc" else {}
+    tr = Trainer("seg_outputs", "synthetic_task_A", plans=plans, data_provider=provider, device=device, fold=0, **kw)
     tr.initialize(True, num_epochs=1000)
     tr.network.train()
+    extra_cfg = {}
+    if ext in ("ewc", "rehearsal_ewc"):
+        # a finished first task: Fisher / theta* dictionaries over all P parameters (values are irrelevant for the timing)
+        g = torch.Generator(device=device).manual_seed(1)
+        named = list(tr.network.named_parameters())
+        tr.fisher["synthetic_task_A"] = {n: torch.rand(p.shape, device=device, generator=g) for n, p in named}
+        tr.params["synthetic_task_A"] = {n: p.detach().clone() + 1e-3 * torch.randn(p.shape, device=device, generator=g) for n, p in named}
+        tr.mh_network.add_new_task("synthetic_task_B", use_init=True)
+        tr.network = tr.mh_network.assemble_model("synthetic_task_B")
+        tr.task = "synthetic_task_B"
+        if ext == "rehearsal_ewc":
+            gen, _ = tr.get_basic_generators()            # fused case list: task B + a seeded 25 % of task A
+            tr.tr_gen = ResidentBatches(gen, device, n=4)
+            extra_cfg["fused_train_cases"] = len(tr.dataset_tr)
+            extra_cfg["batches_with_a_rehearsed_case"] = sum(any(str(k).startswith("synthetic_task_A") for k in it["keys"]) for it in tr.tr_gen.items)
+        tr.loss.update_ewc_params(tr.fisher, tr.params)
+        tr.loss.update_network_params(tr.network.named_parameters())
+        extra_cfg["penalty_params"] = tr.network.arena.size
+    if ext == "lwf":
+        from lifelong_nnunet_amd.training.network_training.lwf.nnUNetTrainerLWF import calculate_target_logits
+        tr.mh_network.add_new_task("synthetic_task_B", use_init=True)
+        tr.network = tr.mh_network.assemble_model("synthetic_task_B", freeze_body=False)
+        tr.task, tr.num_batches_per_epoch = "synthetic_task_B", 2
+        tr.target_logits = calculate_target_logits(tr.mh_network, tr.tr_gen, tr.num_batches_per_epoch, True)   # teacher store stays in HBM
+        tr.network.train()
+        tr.freeze_run, tr.loss, tr.batch_idx = False, tr.LwFloss, 0
+        extra_cfg["teacher_store_MB"] = sum(t.numel() * t.element_size() for v in tr.target_logits.values() for t in v) / 1e6
 
     def step():
         return tr.run_iteration(tr.tr_gen, True)
+
+    def timed(nsteps):
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for _ in range(nsteps):
+            l_ = step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0_, l_
 
     for _ in range(args.warmup):
         step()
@@ -210,23 +344,52 @@ def main():
                    "conv_stack_tflops": patches_per_s / world * flops_patch / 1e12,
                    "conv_stack_frac_of_mfma_peak": patches_per_s / world * flops_patch / 1e12 / PEAK_MFMA_F16_TFLOPS},
     }
+    out["config"].update(extra_cfg)
+    if ext == "lwf":          # the fix behind a flag: every head evaluated on the training batch (one batch, one body pass)
+        tr.same_batch_predictions = True
+        timed(2)
+        dt_sb, _ = timed(args.steps)
+        tr.same_batch_predictions = False
+        out["config"]["same_batch_predictions_patches_per_s"] = B * args.steps / dt_sb
+        out["config"]["note"] = ("value = reference semantics (T+2 batches per iteration, one extra eval forward per head); "
+                                 "conv_stack_* count the training pass only")
+    if world == 1 and ext != "lwf":
+        # H2D-inclusive variant of the same loop (MH.py:606-617 includes to_cuda in the iteration)
+        try:
+            items = tr.tr_gen.items if isinstance(tr.tr_gen, ResidentBatches) else None
+            if items:
+                keep = tr.tr_gen
+                tr.tr_gen = PrefetchingBatches(items, device)
+                timed(2)
+                dt_h, _ = timed(args.steps)
+                tr.tr_gen = keep
+                nbytes = sum(t.numel() * t.element_size() for t in [items[0]["data"]] + list(items[0]["target"]))
+                out["config"]["h2d_inclusive"] = {"ms_per_step": dt_h / args.steps * 1e3, "value": B * args.steps / dt_h,
+                                                  "host_bytes_per_step": nbytes,
+                                                  "how": "pinned host buffers, copy of batch i+1 on a side stream during step i"}
+        except Exception as e:
+            out["config"]["h2d_inclusive"] = {"error": repr(e)}
     if rank == 0 and not args.no_roofline:
         kr = kernel_rooflines(tr)
         dom = min(kr["kernels"].items(), key=lambda kv: kv[1]["tflops"])     # the slowest family bounds the stack
         fwd = kr["kernels"]["igemm_conv_fwd"]
         traffic, traffic_note = None, None
         try:      # HBM bytes per launch of the same kernel/launch from the committed PMC passes (separate rocprofv3 runs)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic, traffic_note = tj["hbm_bytes_per_launch_corrected"], "profiles/r01_pmc_traffic.json: " + tj["note"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            traffic, traffic_note = tj["hbm_bytes_per_launch_corrected"], "profiles/r02_pmc_traffic.json: " + tj["note"]
         except Exception:
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_conv_s1_v5_kernel (stride-1 3x3x3 conv fwd) on " + kr["layer"], "achieved": fwd["tflops"],
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_conv_s1_v9_kernel<4,1,2> (stride-1 3x3x3 conv fwd, z-streaming) on " + kr["layer"], "achieved": fwd["tflops"],
                            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": fwd["tflops"] / PEAK_MFMA_F16_TFLOPS,
                            "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_note,
                            "launch_ms": fwd["ms"], "algorithmic_gflop_per_launch": fwd["gflop"],
                            "other_kernels": {k: {"achieved": v["tflops"], "frac": v["tflops"] / PEAK_MFMA_F16_TFLOPS,
                                                  "launch_ms": v["ms"]} for k, v in kr["kernels"].items()},
                            "slowest_family": dom[0]}
+        try:
+            out["regulariser_kernels"] = regulariser_rooflines(tr, plans)
+        except Exception as e:
+            out["regulariser_kernels"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(plans, flops_patch)
