@@ -256,7 +256,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # NO device_id: with it the RCCL communicator is created eagerly, BEFORE the engine allocates its buffers, and every
+        # step then runs 6-7 % slower on this stack (ROCm 7.0 / RCCL 2.26.6; tools/dp_ab.py: 27.6 vs 25.9 ms, plain 25.9).
+        # Created lazily by the first collective (the first warm-up step's gradient all-reduce) it costs nothing.
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from lifelong_nnunet_amd import get_trainer_class, native as nat
     plans, ext, wl_desc = WORKLOADS[args.workload]

@@ -481,7 +481,10 @@ class UNetEngine:
         # each lane already overlaps the other, both accumulate into the same fp32 panels (atomics) and the panels
         # are folded into the gradient arena once, after the lanes have joined.
         main = torch.cuda.current_stream()
-        side = self._side_stream() if (self.overlap_wgrad and progress is None and not multi) else None
+        # data parallel (progress given): the weight gradients stay on the side stream; a layer's panel is folded into the
+        # gradient arena there too, and the all-reduce of every bucket that became final is launched FROM the side stream
+        # (parallel.GradAllReducer.progress): two streams share the chip, as in the single-GPU plan
+        side = self._side_stream() if (self.overlap_wgrad and not multi) else None
 
         def on_side(fn):
             if side is None:
@@ -513,7 +516,9 @@ class UNetEngine:
             seg_u = len(self.segs)
             for item in reversed(self.order):
                 if progress is not None and not multi and item is not self.order[-1]:
-                    progress(self._watermark[id(item)])   # everything after this item in the arena is final
+                    # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
+                    # (weight gradients + their unpack) have run what is enqueued so far
+                    progress(self._watermark[id(item)], side)
                 if isinstance(item, SegHead):
                     seg_u -= 1
                     dl = dls[seg_u]

@@ -27,19 +27,19 @@ def ds_loss_weights(net_numpool: int) -> np.ndarray:
     return weights / weights.sum()
 
 
-def _world_size():
+def _world_size(group=None):
     import torch.distributed as dist
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
-def _all_reduce_sum(t):
+def _all_reduce_sum(t, group=None):
     import torch.distributed as dist
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 class _DiceCEFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, batch_dice, smooth):
+    def forward(ctx, logits, target, batch_dice, smooth, group=None):
         logits = logits.contiguous()
         N, K = logits.shape[:2]
         V = logits[0, 0].numel()
@@ -51,9 +51,9 @@ class _DiceCEFunction(torch.autograd.Function):
         if batch_dice:
             # with batch Dice the tp/fp/fn sums run over the GLOBAL batch: one small all-reduce inside
             # the loss forward; the same global sums are reused by backward
-            world = _world_size()
+            world = _world_size(group)           # the trainer's process group, not the default one
             if world > 1:
-                _all_reduce_sum(ws[:N * K * 3])
+                _all_reduce_sum(ws[:N * K * 3], group)
                 nat.call("lnn_dice_ce_loss_from_totals", ws, N, K, V, 1, float(smooth), out)
         ctx.save_for_backward(logits, labels, ws)
         ctx.cfg = (N, K, V, int(batch_dice), float(smooth), float(world))
@@ -67,7 +67,7 @@ class _DiceCEFunction(torch.autograd.Function):
         # the upstream scalar gradient (deep-supervision weight x loss scale) rides in as gscale; the global Dice term's
         # gradient is scaled by the world size because the gradient all-reduce averages over the ranks
         nat.call("lnn_dice_ce_bwd", logits, labels, N, K, V, bd, smooth, ws, 1.0, g.reshape(1).float().contiguous(), world, dl)
-        return dl, None, None, None
+        return dl, None, None, None, None
 
 
 class DC_and_CE_loss(nn.Module):
@@ -79,9 +79,10 @@ class DC_and_CE_loss(nn.Module):
         assert aggregate == "sum" and not soft_dice_kwargs.get("do_bg", False)
         self.batch_dice = bool(soft_dice_kwargs.get("batch_dice", False))
         self.smooth = float(soft_dice_kwargs.get("smooth", 1e-5))
+        self.process_group = None      # set by the trainer: the ranks a batch-Dice exchange runs over
 
     def forward(self, net_output, target):
-        return _DiceCEFunction.apply(net_output, target, self.batch_dice, self.smooth)
+        return _DiceCEFunction.apply(net_output, target, self.batch_dice, self.smooth, self.process_group)
 
 
 class MultipleOutputLoss2(nn.Module):

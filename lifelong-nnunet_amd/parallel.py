@@ -39,6 +39,7 @@ class GradAllReducer:
         self.overlap = overlap and grad.is_cuda
         self.stream = torch.cuda.Stream() if grad.is_cuda else None
         self.next = 0
+        self._used = set()
         self.defer = False
 
     @property
@@ -47,34 +48,41 @@ class GradAllReducer:
 
     def begin(self):
         self.next = 0
+        self._used = set()
 
-    def _launch(self, lo, hi):
+    def _launch(self, lo, hi, stream=None):
         if not self.active:
             return
         view = self.grad[lo:hi]
-        if self.stream is not None:
+        stream = stream if stream is not None else self.stream
+        if stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            self.stream.wait_event(ev)
-            with torch.cuda.stream(self.stream):
+            stream.wait_event(ev)
+            with torch.cuda.stream(stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+            self._used.add(stream)
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
 
-    def progress(self, watermark: int):
-        """All gradient elements at offsets >= watermark are final."""
+    def progress(self, watermark: int, stream=None):
+        """All gradient elements at offsets >= watermark are final once the work enqueued so far on the CURRENT stream
+        and on ``stream`` has run.  ``stream``: the engine's weight-gradient side stream -- the bucket is all-reduced
+        FROM that stream (after an event of the current one), so the exchange queues behind the weight gradients it
+        needs and no third stream competes with the two that already share the chip."""
         if not self.overlap or self.defer:
             return
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= watermark:
-            self._launch(*self.buckets[self.next])
+            self._launch(*self.buckets[self.next], stream=stream)
             self.next += 1
 
     def finish(self):
         while self.next < len(self.buckets):
             self._launch(*self.buckets[self.next])
             self.next += 1
-        if self.stream is not None and self.active:
-            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.active:
+            for st in (self._used | ({self.stream} if self.stream is not None else set())):
+                torch.cuda.current_stream().wait_stream(st)
 
 
 def all_reduce_stats(t: torch.Tensor, process_group=None):

@@ -195,6 +195,7 @@ class nnUNetTrainerMultiHead:
         self.on_forward_done(data, output, do_backprop)
         l = None
         if not no_loss:
+            self._bind_process_group(self.loss)
             l = self.loss(output, target)
         if do_backprop:
             scale = self.amp_grad_scaler.get_scale()
@@ -225,6 +226,26 @@ class nnUNetTrainerMultiHead:
                 return np.float32(vals[0])
             return l.detach().cpu().numpy()
         return l
+
+    def _bind_process_group(self, loss):
+        """The batch-Dice exchange inside DC_and_CE_loss must run over THIS trainer's ranks (``process_group``), not the
+        default group: hand it to whatever Dice+CE object the (possibly wrapped) loss holds.  Done once per loss object."""
+        if getattr(loss, "_lnn_group_bound", None) is self.process_group and hasattr(loss, "_lnn_group_bound"):
+            return
+        seen, todo = set(), [loss]
+        while todo:
+            m = todo.pop()
+            if id(m) in seen or m is None:
+                continue
+            seen.add(id(m))
+            if isinstance(m, DC_and_CE_loss):
+                m.process_group = self.process_group
+            for attr in ("loss", "base_loss"):
+                todo.append(getattr(m, attr, None))
+        try:
+            loss._lnn_group_bound = self.process_group
+        except AttributeError:
+            pass
 
     def on_forward_done(self, data, output, do_backprop):
         """Hook between forward and loss (used by LwF to read the old heads on the fresh body activations)."""
