@@ -88,6 +88,15 @@ int lnn_conv3d_wgrad(lnn_stream_t s, const void* x_h, int ld_x, const void* dy_h
  * as two 64-byte-per-voxel tensors the live set halves and the chunk pairs share their lines. */
 int lnn_conv3d_fwd_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int ld_x, int c_a, const void* wp_fwd_h,
                        const float* bias, void* y_h, int ld_y, int N, int Di, int Hi, int Wi, int C, int K);
+/* Conv3d (3x3x3, padding 1) -> dense output y (ld_y == K) AND the InstanceNorm statistics of that output in one call
+ * (ConvDropoutNormNonlin = instnorm(conv(x)), test_MultiHead_Module.py:287-291; statistics as lnn_instnorm_stats: biased
+ * variance over D*H*W per (n, c) of the fp16-stored values).  x_b may be NULL (single input tensor; c_a ignored).  Where the
+ * stride-1 z-streaming kernel applies (C = 32 / 64) the sums are taken in its epilogue from the values it stores -- the
+ * separate 2 B/element statistics pass disappears; otherwise the call runs the convolution followed by lnn_instnorm_stats.
+ * ws >= lnn_instnorm_ws_doubles(N, K). */
+int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
+                            const float* bias, void* y, int N, int Di, int Hi, int Wi, int C, int K, int stride,
+                            float eps, float* mean, float* rstd, double* ws);
 int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp_dgrad_h, void* dx_a_h, void* dx_b_h,
                          int ld_dx, int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate);
 int lnn_conv3d_wgrad_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int ld_x, int c_a, const void* dy_h, int ld_dy,

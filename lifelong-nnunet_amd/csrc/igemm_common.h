@@ -26,6 +26,8 @@ struct ConvParams {
     int os, par_z, par_y, par_x;
     int pad_lo;
     int accumulate;
+    float* stats_pws = nullptr;   // v9 only: fused InstanceNorm statistics partials [2][stats_nblk][N][M] (see igemm_conv_v9.hip)
+    int stats_nblk = 0;
     unsigned long long* dbg;   // optional phase-cycle accumulators (LNN_DEBUG_PHASES), null in production
     TapTable taps;
 };
@@ -46,6 +48,9 @@ int lnn_launch_conv_s1_v7(hipStream_t s, ConvParams& p, const char* name);
 int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name);
 // v9 (igemm_conv_v9.hip): z-streaming, register-resident weights, direct-to-LDS input ring (C = 32 / 64, M % 32 == 0)
 bool lnn_conv_s1_v9_supported(const ConvParams& p);
+int lnn_conv_s1_v9_stats_slots(const ConvParams& p);
+// norm_act.hip: mean / rstd from per-slot partial sums pws[a][slot][n*C + c] (the finalize half of lnn_instnorm_stats)
+int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd);
 int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name);
 // single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,
 // all eight output parity classes per block

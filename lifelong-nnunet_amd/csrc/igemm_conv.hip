@@ -420,7 +420,8 @@ extern "C" int lnn_debug_force_conv_kernel(int which) {
 
 namespace {
 int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int ld_x, const void* wp, const float* bias, void* y,
-                    int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride) {
+                    int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride, float* stats_pws = nullptr,
+                    int* stats_slots = nullptr) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_fwd: stride %d unsupported", stride);
     LNN_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0, "lnn_conv3d_fwd: bad dims");
@@ -454,6 +455,12 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
             p.taps.slot[t] = (unsigned char)t;
         }
         p.dbg = g_dbg;
+        if (stats_pws && use_v2() && use_v9(p) && ld_y == K) {      // fused InstanceNorm statistics (dense output tensor only)
+            p.stats_pws = stats_pws;
+            const int rc = lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9,stats)");
+            *stats_slots = p.stats_nblk;
+            return rc;
+        }
         if (use_v2() && use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9)");
         if (use_v2() && use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_fwd(s1,v8)");
         if (use_v2() && use_v7(p.C)) return lnn_launch_conv_s1_v7(s, p, "lnn_conv3d_fwd(s1,v7)");
@@ -492,6 +499,22 @@ extern "C" int lnn_conv3d_fwd_cat(lnn_stream_t s, const void* x_a, const void* x
     if (int e = check_cat(x_b, c_a, C, 1, "lnn_conv3d_fwd_cat")) return e;
     LNN_REQUIRE(ld_x >= c_a && ld_x >= C - c_a, "lnn_conv3d_fwd_cat: ld_x %d smaller than a part (%d / %d)", ld_x, c_a, C - c_a);
     return conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, 1);
+}
+
+extern "C" int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
+                                       const float* bias, void* y, int N, int Di, int Hi, int Wi, int C, int K, int stride,
+                                       float eps, float* mean, float* rstd, double* ws) {
+    LNN_REQUIRE(mean && rstd && ws, "lnn_conv3d_fwd_in_stats: null output/workspace");
+    if (x_b) {
+        if (int e = check_cat(x_b, c_a, C, stride, "lnn_conv3d_fwd_in_stats")) return e;
+        LNN_REQUIRE(ld_x >= c_a && ld_x >= C - c_a, "lnn_conv3d_fwd_in_stats: ld_x %d smaller than a part (%d / %d)", ld_x, c_a, C - c_a);
+    }
+    const long V = (long)((Di - 1) / stride + 1) * ((Hi - 1) / stride + 1) * ((Wi - 1) / stride + 1);
+    float* pws = reinterpret_cast<float*>(ws + (size_t)N * K * 3);          // same region lnn_instnorm_stats uses
+    int slots = 0;
+    if (int e = conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, K, N, Di, Hi, Wi, C, K, stride, pws, &slots)) return e;
+    if (slots > 0) return lnn_launch_in_stats_finalize((hipStream_t)s, pws, slots, N, K, V, eps, mean, rstd);
+    return lnn_instnorm_stats(s, y, N, V, K, eps, mean, rstd, ws);          // kernel without the fused epilogue: separate pass
 }
 
 namespace {

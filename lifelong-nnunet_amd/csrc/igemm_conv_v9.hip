@@ -98,7 +98,11 @@ struct V9Launch {
     int items, S, L, tiles_y, tiles_x, nslots, ipx;
 };
 
-template <int NCK_, int NMB_, int NF_>
+// STATS: the epilogue also accumulates sum / sum of squares of the STORED (fp16-rounded) outputs per (sample, channel) --
+// the InstanceNorm statistics pass of the next op (norm_act.hip:in_stats_kernel) without re-reading the tensor.  Partials
+// go to p.stats_pws[a][slot][n][c] (a = 0 sum, 1 sum of squares; slot = block * NF + footprint: every slot row is owned by
+// one wave, so the accumulation is a plain read-modify-write and the result is deterministic).
+template <int NCK_, int NMB_, int NF_, bool STATS>
 __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvParams p, const V9Launch q) {
     using K = V9<NCK_, NMB_, NF_>;
     constexpr int NCK = K::NCK, NMB = K::NMB, NFX = K::NFX, PXS = K::PXS, PY = K::PY, PX = K::PX;
@@ -200,6 +204,9 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         }
 
         // ---- per-item lane offsets ----
+        float ssum[4 * QN], ssq[4 * QN];
+#pragma unroll
+        for (int i = 0; i < 4 * QN; ++i) ssum[i] = ssq[i] = 0.f;
         int dvoff[DPW];
 #pragma unroll
         for (int k = 0; k < DPW; ++k) {
@@ -269,6 +276,16 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 const half2v a1 = {(half_t)(fin[2] + biasv[2]), (half_t)(fin[3] + biasv[3])};
                 const half2v b0 = {(half_t)(fin[4] + biasv[4]), (half_t)(fin[5] + biasv[5])};
                 const half2v b1 = {(half_t)(fin[6] + biasv[6]), (half_t)(fin[7] + biasv[7])};
+                if constexpr (STATS) {
+                    const float r[8] = {(float)a0[0], (float)a0[1], (float)a1[0], (float)a1[1],
+                                        (float)b0[0], (float)b0[1], (float)b1[0], (float)b1[1]};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float m = ov ? r[i] : 0.f;
+                        ssum[i] += m;
+                        ssq[i] = __builtin_fmaf(m, m, ssq[i]);
+                    }
+                }
                 const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
                 const uint4v o = {s0[0], s1[0], s0[1], s1[1]};
@@ -277,6 +294,14 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 half4 o4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o4[i] = (half_t)(fin[i] + biasv[i]);
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float m = ov ? (float)o4[i] : 0.f;
+                        ssum[i] += m;
+                        ssq[i] = __builtin_fmaf(m, m, ssq[i]);
+                    }
+                }
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2v, o4), rs, svoff, 0, 0);
             }
         };
@@ -338,6 +363,24 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             step(IC<1>{}, t + 1);
             step(IC<2>{}, t + 2);
         }
+        if constexpr (STATS) {
+            // this wave's 32 voxel lanes per half-wave hold the same channels: butterfly over the half, then lanes 0 / 32
+            // add the item's sums to the wave's own slot row (out-of-volume voxel columns contribute nothing)
+            const bool lane_ok = svoff != (int)0x80000000;
+            float* const prow0 = p.stats_pws + (((long)(blockIdx.x * K::NF + f)) * p.N + n) * p.M;
+            const long astride = (long)p.stats_nblk * p.N * p.M;
+#pragma unroll
+            for (int i = 0; i < 4 * QN; ++i) {
+                float a = lane_ok ? ssum[i] : 0.f, b2 = lane_ok ? ssq[i] : 0.f;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64); }
+                if ((lane & 31) == 0) {
+                    const int ch = m0 + 8 * QN * ck + 8 * (i >> 2) + 4 * hk + (i & 3);
+                    prow0[ch] += a;
+                    prow0[astride + ch] += b2;
+                }
+            }
+        }
         wait_vm<0, true>();
         __builtin_amdgcn_s_barrier();
     }
@@ -345,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
 
 int g_v9_zseg = 0;     // lnn_debug_set_v9_zseg (parity tests): 0 = automatic
 
-template <class K>
+template <class K, bool STATS>
 int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
     const int tiles_y = lnn_cdiv(p.Lh, K::FY), tiles_x = lnn_cdiv(p.Lw, K::FX);
     const int mgroups = p.M / (32 * K::NMB);
@@ -372,12 +415,16 @@ int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
     q.nslots = G / 8;
     if (q.nslots > q.ipx) q.nslots = q.ipx;
     const int grid = q.nslots * 8;
-    static bool attr_set = false;
+    static bool attr_set = false;     // per instantiation; idempotent attribute of the code object
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF>), dim3(grid), dim3(512), K::LDS, s, p, q);
+    if (STATS) {
+        p.stats_nblk = grid * K::NF;
+        hipMemsetAsync(p.stats_pws, 0, sizeof(float) * 2 * (size_t)p.stats_nblk * p.N * p.M, s);
+    }
+    hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, STATS>), dim3(grid), dim3(512), K::LDS, s, p, q);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }
@@ -401,17 +448,34 @@ bool lnn_conv_s1_v9_supported(const ConvParams& p) {
     return true;
 }
 
-int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name) {
-    static int num_cu = 0;
+static int v9_num_cu() {
+    static int num_cu = 0;        // device property, read once (immutable for the process)
     if (!num_cu) {
         int dev = 0;
         hipDeviceProp_t prop;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    if (p.C == 32) {
-        if (p.M % 64 == 0) return launch_v9<V9<2, 2, 2>>(s, p, num_cu, name);
-        return launch_v9<V9<2, 1, 4>>(s, p, num_cu, name);
+    return num_cu;
+}
+
+// slots of the fused-statistics partials (rows of N * M floats per accumulator): grid blocks x footprints per block
+int lnn_conv_s1_v9_stats_slots(const ConvParams& p) {
+    const int nf = p.C == 32 ? (p.M % 64 == 0 ? 2 : 4) : (p.M % 64 == 0 ? 1 : 2);
+    return (v9_num_cu() / 8 * 8 < 8 ? 8 : v9_num_cu() / 8 * 8) * nf;
+}
+
+int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name) {
+    const int num_cu = v9_num_cu();
+    if (p.stats_pws) {
+        // 32 -> 64 (the data-gradient shape of the top decoder conv) never feeds an InstanceNorm: no STATS instance for it
+        if (p.C == 32) return launch_v9<V9<2, 1, 4>, true>(s, p, num_cu, name);
+        if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>, true>(s, p, num_cu, name);
+        return launch_v9<V9<4, 1, 2>, true>(s, p, num_cu, name);
     }
-    if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>>(s, p, num_cu, name);
-    return launch_v9<V9<4, 1, 2>>(s, p, num_cu, name);
+    if (p.C == 32) {
+        if (p.M % 64 == 0) return launch_v9<V9<2, 2, 2>, false>(s, p, num_cu, name);
+        return launch_v9<V9<2, 1, 4>, false>(s, p, num_cu, name);
+    }
+    if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>, false>(s, p, num_cu, name);
+    return launch_v9<V9<4, 1, 2>, false>(s, p, num_cu, name);
 }

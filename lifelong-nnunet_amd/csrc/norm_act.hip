@@ -7,7 +7,7 @@
 // workspace, summed in fp64 by a tiny finalize kernel.  (The first version used fp64 atomics across blocks: 1024
 // blocks x N x C x 2 atomics onto N*C*2 addresses serialise in L2 -- the statistics pass of a 64-channel layer took
 // 1.5x as long as the normalise pass that moves twice the bytes -- and needed a memset per call.)
-#include "lnn_common.h"
+#include "igemm_common.h"
 
 namespace {
 
@@ -329,6 +329,12 @@ int check_common(const void* y, int N, long V, int C, const char* what) {
 }
 
 }  // namespace
+
+int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd) {
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nslots, N * C, V, eps, mean, rstd);
+    LNN_CHECK_LAUNCH("lnn_instnorm_stats(finalize, fused partials)");
+    return LNN_OK;
+}
 
 // [N*C*3 doubles: s1, s2, (unused)] [2 * MAX_BLOCKS * N * C floats: per-block partial sums]
 extern "C" size_t lnn_instnorm_ws_doubles(int N, int C) { return (size_t)N * C * 3 + (size_t)MAX_BLOCKS * N * C; }

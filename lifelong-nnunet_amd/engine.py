@@ -344,6 +344,7 @@ class UNetEngine:
         self._side = None
         self._lstreams, self._lws = [], []
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
+        self.fuse_in_stats = os.environ.get("LNN_NO_FUSED_IN_STATS", "0") != "1"     # A/B switch (measurements only)
         # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
         # little room), kept because it is the natural hook for per-sample pipelining across GPUs / larger batches
         self.sample_lanes = os.environ.get("LNN_SAMPLE_LANES", "0") == "1"
@@ -442,15 +443,21 @@ class UNetEngine:
                     xin = at(self.image, n0) if item.x is None else at(item.x, n0)
                     ldx = 1 if item.x is None else item.x.ld
                     C = item.cout
-                    if item.x2 is not None:
-                        nat.call("lnn_conv3d_fwd_cat", xin, at(item.x2, n0), ldx, item.x.C, self._wp(item.wp_fwd),
-                                 self.pview(item.b), at(item.y, n0), C, nn, D, H, W, item.cin, C)
-                    else:
-                        nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
-                                 nn, D, H, W, item.cin, C, item.stride)
                     V = item.z.V
                     mean, rstd = item.mean[n0 * C:], item.rstd[n0 * C:]
-                    nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
+                    if item.x is not None and self.fuse_in_stats:
+                        # conv + InstanceNorm statistics in one call (the z-streaming kernel sums in its epilogue)
+                        nat.call("lnn_conv3d_fwd_in_stats", xin, None if item.x2 is None else at(item.x2, n0), ldx,
+                                 item.x.C if item.x2 is not None else 0, self._wp(item.wp_fwd), self.pview(item.b),
+                                 at(item.y, n0), nn, D, H, W, item.cin, C, item.stride, IN_EPS, mean, rstd, ws)
+                    else:
+                        if item.x2 is not None:
+                            nat.call("lnn_conv3d_fwd_cat", xin, at(item.x2, n0), ldx, item.x.C, self._wp(item.wp_fwd),
+                                     self.pview(item.b), at(item.y, n0), C, nn, D, H, W, item.cin, C)
+                        else:
+                            nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
+                                     nn, D, H, W, item.cin, C, item.stride)
+                        nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
                     nat.call("lnn_instnorm_lrelu_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
                              self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE)
                 elif isinstance(item, UpBlock):

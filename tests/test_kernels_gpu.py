@@ -400,6 +400,37 @@ def test_every_stride1_conv_kernel_variant(which):
         nat.lib().lnn_debug_force_conv_kernel(-1)
 
 
+@pytest.mark.parametrize("N,C,K,D,H,W,cat", [(2, 32, 32, 9, 8, 17, 0), (1, 64, 32, 6, 10, 9, 1), (2, 64, 64, 5, 12, 9, 0),
+                                              (1, 16, 32, 5, 9, 11, 0), (1, 32, 32, 37, 5, 21, 0)])
+def test_conv3d_fwd_in_stats(N, C, K, D, H, W, cat):
+    """lnn_conv3d_fwd_in_stats == lnn_conv3d_fwd followed by lnn_instnorm_stats: the output bit for bit, mean / rstd to
+    fp32 summation order (the z-streaming kernel takes the sums in its epilogue from the values it stores; for shapes it
+    does not cover the entry runs the two passes itself), and both equal the statistics of the stored fp16 tensor."""
+    x = _rand((N, C, D, H, W), 1)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3)).to(DEV)
+    xb, _ = to_cl_h(x)
+    wp = pack_conv_fwd(w.to(DEV))
+    V = D * H * W
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    y1 = torch.zeros((N, D, H, W, K), dtype=torch.float16, device=DEV); y2 = torch.zeros_like(y1)
+    m1, r1, m2, r2 = (torch.zeros(N * K, device=DEV) for _ in range(4))
+    nat.call("lnn_conv3d_fwd", xb, C, wp, b, y1, K, N, D, H, W, C, K, 1)
+    nat.call("lnn_instnorm_stats", y1, N, V, K, 1e-5, m1, r1, ws)
+    if cat:
+        xa = xb[..., :C // 2].contiguous(); xc = xb[..., C // 2:].contiguous()
+        nat.call("lnn_conv3d_fwd_in_stats", xa, xc, C // 2, C // 2, wp, b, y2, N, D, H, W, C, K, 1, 1e-5, m2, r2, ws)
+    else:
+        nat.call("lnn_conv3d_fwd_in_stats", xb, None, C, 0, wp, b, y2, N, D, H, W, C, K, 1, 1e-5, m2, r2, ws)
+    assert torch.equal(y1, y2)
+    yf = y1.float().reshape(N, V, K)
+    mean = yf.mean(1).reshape(-1); var = yf.var(1, unbiased=False).reshape(-1)
+    for m, r in ((m1, r1), (m2, r2)):
+        assert float((m - mean).abs().max()) <= 1e-5 * float(mean.abs().max()) + 1e-6
+        assert float((r - (var + 1e-5).rsqrt()).abs().max()) <= 1e-5 * float(r.abs().max())
+    assert float((m1 - m2).abs().max()) <= 2e-6 * float(m1.abs().max()) + 1e-7 and float((r1 - r2).abs().max()) <= 2e-6 * float(r1.abs().max())
+
+
 @pytest.mark.parametrize("zseg", [2, 3, 5])
 def test_v9_z_segments(zseg):
     """v9 walks a column of output planes; long columns can be cut into z segments (item = column x segment): every cut
