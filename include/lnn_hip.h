@@ -264,6 +264,35 @@ int lnn_sgd_nesterov_step_clipped(lnn_stream_t s, float* theta, float* momentum_
                                   float lr, float momentum, float weight_decay, float inv_scale, float max_norm,
                                   const double* ctrl);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp32-STORAGE path (the reference's fp16=False branch, multihead/nnUNetTrainerMultiHead.py:632-641; --fp32 at
+ * run/run_training.py:71): direct fp32 kernels with fp64 accumulation in a fixed order (bit-reproducible).  A parity
+ * mode, not a fast path.  Activations NDHWC fp32 with channel stride ld; weights in PyTorch's layouts straight from the
+ * parameter arena (Conv3d (K,C,3,3,3); ConvTranspose3d (Cin,Cout,2,2,2); 1x1x1 (K,C)); *_wgrad ADD into dw; logits NCDHW.
+ * lnn_f32_instnorm_lrelu_bwd overwrites y with dL/dy and adds dgamma / dbeta (ws >= 2*N*C doubles); the conv-bias
+ * gradient under InstanceNorm is identically zero and is not written.
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_f32_conv3d_fwd(lnn_stream_t s, const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y,
+                       int N, int Di, int Hi, int Wi, int C, int K, int stride);
+int lnn_f32_conv3d_dgrad(lnn_stream_t s, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N, int Di,
+                         int Hi, int Wi, int C, int K, int stride, int accumulate);
+int lnn_f32_conv3d_wgrad(lnn_stream_t s, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N, int Di,
+                         int Hi, int Wi, int C, int K, int stride);
+int lnn_f32_convT3d_k2s2_fwd(lnn_stream_t s, const float* x, int ld_x, const float* w, float* y, int ld_y, int N, int D,
+                             int H, int W, int C, int K);
+int lnn_f32_convT3d_k2s2_dgrad(lnn_stream_t s, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N,
+                               int D, int H, int W, int C, int K, int accumulate);
+int lnn_f32_convT3d_k2s2_wgrad(lnn_stream_t s, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N,
+                               int D, int H, int W, int C, int K);
+int lnn_f32_instnorm_lrelu_fwd(lnn_stream_t s, const float* y, int ld_y, float* z, int ld_z, int N, long V, int C, float eps,
+                               float* mean, float* rstd, const float* gamma, const float* beta, float slope);
+int lnn_f32_instnorm_lrelu_bwd(lnn_stream_t s, float* y, int ld_y, const float* dz, int ld_dz, int N, long V, int C,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                               float* dgamma, float* dbeta, double* ws);
+int lnn_f32_seg1x1_fwd(lnn_stream_t s, const float* z, int ld_z, const float* w, float* logits, int N, long V, int C, int K);
+int lnn_f32_seg1x1_bwd(lnn_stream_t s, const float* z, int ld_z, const float* w, const float* dlogits, float* gz, int ld_gz,
+                       float* dw, int N, long V, int C, int K, int accumulate);
+
 /* debug: when set to a zeroed device buffer of 6 uint64, the stride-1 conv kernel accumulates shader-clock cycles
  * per phase {issue loads, MFMA, barrier, LDS stores, barrier} and the step count; pass NULL to disable. */
 int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64);

@@ -68,6 +68,16 @@ SIGNATURES = {
     "lnn_sgd_nesterov_step_clipped": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p]),
     "lnn_sgd_nesterov_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
     "lnn_cast_f32_to_h": (_i, [_p, _p, _p, _l]),
+    "lnn_f32_conv3d_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "lnn_f32_conv3d_dgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "lnn_f32_conv3d_wgrad": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i]),
+    "lnn_f32_convT3d_k2s2_fwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
+    "lnn_f32_convT3d_k2s2_dgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "lnn_f32_convT3d_k2s2_wgrad": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
+    "lnn_f32_instnorm_lrelu_fwd": (_i, [_p, _p, _i, _p, _i, _i, _l, _i, _f, _p, _p, _p, _p, _f]),
+    "lnn_f32_instnorm_lrelu_bwd": (_i, [_p, _p, _i, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "lnn_f32_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),
+    "lnn_f32_seg1x1_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _l, _i, _i, _i]),
     "lnn_debug_tr16_probe": (_i, [_p, _p]),
     "lnn_debug_set_phase_buffer": (_i, [_p]),
     "lnn_debug_force_conv_kernel": (_i, [_i]),

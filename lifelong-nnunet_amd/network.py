@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from .engine import ParamArena, UNetEngine, param_slots
+from .engine_f32 import UNetEngineF32
 
 
 class _ParamHolder(nn.Module):
@@ -79,6 +80,7 @@ class Generic_UNet(nn.Module):
         self.inference_apply_nonlin = lambda x: torch.softmax(x, 1)
         self.convolutional_pooling = self.convolutional_upsampling = True
         self.device_ = torch.device(device)
+        self.storage = "fp16"      # "fp32": the reference's fp16=False branch (MH.py:632-641) on the direct fp32 kernels
 
         slots = param_slots(input_channels, base_num_features, num_classes, num_pool, self.MAX_NUM_FILTERS_3D)
         self.arena = ParamArena(slots, self.device_)
@@ -159,11 +161,12 @@ class Generic_UNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------ engine
     def engine_for(self, x) -> UNetEngine:
-        key = (x.shape[0],) + tuple(x.shape[2:])
+        key = (x.shape[0],) + tuple(x.shape[2:]) + ((self.storage,) if self.storage != "fp16" else ())
         eng = self._engines.get(key)
         if eng is None:
-            eng = UNetEngine(self.arena, self.input_channels, self.base_num_features, self.num_classes, self.num_pool,
-                             tuple(x.shape[2:]), x.shape[0], self.device_, self.MAX_NUM_FILTERS_3D)
+            cls = UNetEngineF32 if self.storage == "fp32" else UNetEngine
+            eng = cls(self.arena, self.input_channels, self.base_num_features, self.num_classes, self.num_pool,
+                      tuple(x.shape[2:]), x.shape[0], self.device_, self.MAX_NUM_FILTERS_3D)
             self._engines[key] = eng
         return eng
 

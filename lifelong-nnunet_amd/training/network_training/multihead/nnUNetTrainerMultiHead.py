@@ -102,7 +102,9 @@ class nnUNetTrainerMultiHead:
             self.tr_gen = self.data_provider(self.task, "train", self.plans)
             self.val_gen = self.data_provider(self.task, "val", self.plans)
         self.initialize_optimizer_and_scheduler()
-        self.amp_grad_scaler = GradScaler()
+        # fp16=False (MH.py:632-641, --fp32): fp32 activation storage on the direct fp32 kernels, no loss scaling
+        self.network.storage = "fp16" if self.fp16 else "fp32"
+        self.amp_grad_scaler = GradScaler(enabled=bool(self.fp16))
         import os
         force_dp = os.environ.get("LNN_FORCE_DP", "0") == "1"
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
