@@ -221,6 +221,36 @@ int lnn_kl_logits(lnn_stream_t s, const float* pred, const float* teach, int N, 
                   float* out, double* ws);
 
 /* ------------------------------------------------------------------------------------------------
+ * PLOP / POD (plop/nnUNetTrainerPLOP.py, pod/nnUNetTrainerPOD.py; deep_supervision.py:217-381, embeddings.py:3-41).
+ * Both value-only (the reference's hooks store detached conv outputs, PLOP.py:352-357).
+ *
+ * lnn_plop_pseudo_labels  (MultipleOutputLossPLOP._pseudo_label_loss, DS.py:292-318): per voxel of the OLD model's
+ *   logits x_old (N,K,D,H,W fp32): probs = softmax, pseudo = argmax, valid = entropy(probs)/max_entropy <
+ *   thresholds[pseudo] (entropy as crossentropy.py:6-16), bg = (y == 0).
+ *     labels_not_pseudo = y, 255 where bg & valid       (target of the first CE term, DS.py:306-309)
+ *     labels_pseudo     = 255, pseudo where bg & valid  (target of the second CE term, DS.py:313-317)
+ *     num / den (N*W ints): counts of bg & valid / bg voxels per (sample, last-axis column) -- the reference sums
+ *     the (B,D,H,W) masks over dims (1,2) only (DS.py:299,301), so its adaptive factor is a (B,W) table.
+ *   y: (N,D*H*W) fp32 labels.
+ *
+ * lnn_local_pod  (embeddings.local_POD, embeddings.py:9-41) on two equally strided 5-D views h, h_old of logical
+ *   shape (N,C,D,S,S) (fp16 when is_fp16 else fp32; element strides sn,sc,sd,sy,sx):
+ *     pod = mean over (n, 2C, d) of the L2 norm, over all windows of scales 1..scales-1 (scale 0 yields no window:
+ *           range(0, W-w, w) is empty for w == W, embeddings.py:30) and their in-window offsets, of the width- /
+ *           height-pooled window means of (h - h_old);
+ *     if dist_inout: dist = (dist + pod_lambda * pod) / num_layers   (DS.py:270-276: the division is inside the loop);
+ *     if pod_out:    pod_out[0] = pod.
+ *   ws: >= 2*N*C*D floats.  The last two dims must be equal (the reference's torch.cat fails otherwise) and
+ *   S >> (scales-1) must be > 0 (its assert, embeddings.py:26-27).
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_plop_pseudo_labels(lnn_stream_t s, const float* x_old, const float* y, const float* thresholds, float max_entropy,
+                           int N, int K, int D, int H, int W, float* labels_not_pseudo, float* labels_pseudo, int* num,
+                           int* den);
+int lnn_local_pod(lnn_stream_t s, const void* h, const void* h_old, int is_fp16, int N, int C, int D, int S, long sn, long sc,
+                  long sd, long sy, long sx, int scales, float pod_lambda, int num_layers, float* ws, float* dist_inout,
+                  float* pod_out);
+
+/* ------------------------------------------------------------------------------------------------
  * Flat-arena parameter kernels (fp32, n elements).
  *   EWC penalty  (deep_supervision.py:80):  out = lambda/2 * sum F (theta-theta*)^2 ;
  *                 bwd: grad += gscale * lambda * F (theta-theta*)

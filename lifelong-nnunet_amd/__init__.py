@@ -13,6 +13,8 @@ TRAINER_MAP = {
     "ewc": "lifelong_nnunet_amd.training.network_training.ewc.nnUNetTrainerEWC:nnUNetTrainerEWC",
     "rw": "lifelong_nnunet_amd.training.network_training.rw.nnUNetTrainerRW:nnUNetTrainerRW",
     "mib": "lifelong_nnunet_amd.training.network_training.mib.nnUNetTrainerMiB:nnUNetTrainerMiB",
+    "plop": "lifelong_nnunet_amd.training.network_training.plop.nnUNetTrainerPLOP:nnUNetTrainerPLOP",
+    "pod": "lifelong_nnunet_amd.training.network_training.pod.nnUNetTrainerPOD:nnUNetTrainerPOD",
     "lwf": "lifelong_nnunet_amd.training.network_training.lwf.nnUNetTrainerLWF:nnUNetTrainerLWF",
     "rehearsal": "lifelong_nnunet_amd.training.network_training.rehearsal.nnUNetTrainerRehearsal:nnUNetTrainerRehearsal",
     "rehearsal_ewc": "lifelong_nnunet_amd.training.network_training.rehearsal_ewc.nnUNetTrainerRehearsalEWC:nnUNetTrainerRehearsalEWC",

@@ -474,6 +474,23 @@ class UNetEngine:
         self._fork(lane)
         return logits
 
+    def conv_outputs(self, logits):
+        """name -> (N,C,D,H,W) strided VIEW of the output of every conv / transposed conv / seg head of the LAST forward,
+        in execution order -- what the reference's forward hooks on every ``conv.Conv*`` module record
+        (plop/nnUNetTrainerPLOP.py:335-358).  ``logits``: the list that forward returned (low resolution first).  The views
+        alias the engine's buffers: read them before the next forward / backward."""
+        from collections import OrderedDict
+        out, u = OrderedDict(), 0
+        for item in self.order:
+            if isinstance(item, ConvBlock):
+                out[item.prefix + ".conv"] = item.y.permute(0, 4, 1, 2, 3)
+            elif isinstance(item, UpBlock):
+                out[item.prefix] = item.y.tensor().permute(0, 4, 1, 2, 3)
+            else:
+                out[item.prefix] = logits[u]
+                u += 1
+        return out
+
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dlogits: List[Optional[torch.Tensor]], skip_body: bool = False, progress=None):
         """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.

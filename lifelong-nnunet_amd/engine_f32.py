@@ -130,6 +130,20 @@ class UNetEngineF32:
                 u += 1
         return logits
 
+    def conv_outputs(self, logits):
+        """Same contract as UNetEngine.conv_outputs (fp32 views)."""
+        from collections import OrderedDict
+        out, u = OrderedDict(), 0
+        for it in self.order:
+            if it.kind == "conv":
+                out[it.prefix + ".conv"] = it.y.permute(0, 4, 1, 2, 3)
+            elif it.kind == "up":
+                out[f"tu.{u}"] = it.y.tensor().permute(0, 4, 1, 2, 3)
+            else:
+                out[f"seg_outputs.{u}"] = logits[u]
+                u += 1
+        return out
+
     def backward(self, dlogits, skip_body: bool = False, progress=None):
         N = self.N
         grad = self.arena.grad

@@ -342,3 +342,108 @@ class MultipleOutputLossLWF(MultipleOutputLoss2):
         for idx, t_logit in enumerate(self.target_logits):
             loss = loss + self._distillation_loss(self.pred_logits[idx], t_logit)
         return loss
+
+
+# ------------------------------------------------------------------------------------------------- PLOP / POD
+def local_POD(h_, h_old, scales, _dist=None, _pod_lambda=0., _num_layers=1):
+    """embeddings.py:9-41 on two 5-D device views (any strides; fp16 or fp32): one fused pass, value only.  The
+    reference's failure modes are kept: non-square last two dims raise (its ``torch.cat`` of the width- and height-pooled
+    halves does), a window of size 0 at the last scale is its AssertionError.  With ``_dist`` (a 1-element device
+    tensor) the kernel also folds ``dist = (dist + lambda * pod) / num_layers`` (DS.py:270-276) into the same launch."""
+    assert h_.size() == h_old.size(), "The embedding tensors of the current and old model should have the same shape.."
+    assert h_.dim() == 5 and h_.dtype == h_old.dtype and h_.stride() == h_old.stride() and h_.is_cuda and h_old.is_cuda
+    N, C, D, H, W = h_.shape
+    if H != W:
+        raise RuntimeError(f"Sizes of tensors must match except in dimension 1 (local POD pools {W // 2}-wide rows with "
+                           f"{H // 2}-wide columns; only H == W works, embeddings.py:31-34)")
+    for scale in range(scales):
+        assert int(W / 2 ** scale) > 0 and int(H / 2 ** scale) > 0, \
+            "The number of scales ({}) are too big in such a way that during scale {} either the step size for H ({}) or W ({}) is 0..".format(
+                scales, scale, int(H / 2 ** scale), int(W / 2 ** scale))
+    ws = torch.empty(2 * N * C * D, device=h_.device)
+    out = torch.empty(1, device=h_.device)
+    nat.call("lnn_local_pod", h_, h_old, int(h_.dtype == torch.float16), N, C, D, W, *[int(s) for s in h_.stride()], int(scales),
+             float(_pod_lambda), int(_num_layers), ws, _dist, out)
+    return out[0]
+
+
+def _dist_loss(old_interm_results, interm_results, pod_lambda, scales, device):
+    """DS.py:268-276 / :370-376: ``dist = (dist + lambda * local_POD(layer)) / num_layers`` per layer IN THE LOOP, in the
+    order the old model's hooks fired."""
+    dist = torch.zeros(1, device=device)
+    L = len(old_interm_results)
+    for name, h_old in old_interm_results.items():
+        local_POD(interm_results[name], h_old, scales, dist, pod_lambda, L)
+    return dist[0]
+
+
+class _NaNIfEmptyCE(RobustCrossEntropyLoss):
+    """``F.cross_entropy(..., ignore_index=255, reduction='mean')`` over ZERO counted voxels is 0/0 = NaN in torch; the
+    fused kernel reports 0 there (right for MiB, where the case cannot occur).  PLOP reaches it whenever no voxel passes
+    the entropy threshold (tests/golden/plop_reference.json:plop_flow_unconfident), and the reference's loss is NaN."""
+
+    def forward(self, input, target):
+        out = super().forward(input, target)
+        counted = (target != self.ignore_index).any()
+        return out + torch.where(counted, torch.zeros_like(out), torch.full_like(out, float("nan")))
+
+
+class MultipleOutputLossPLOP(nn.Module):
+    """deep_supervision.py:217-334.  Per weighted level: pseudo labels of the old model's background-confident voxels
+    (one fused kernel: softmax / argmax / entropy / threshold / the two label volumes / num-den counts), then the two
+    ignore-index CE terms on the fused CE kernels; plus the value-only local-POD term over every conv output."""
+
+    def __init__(self, nr_classes=1, pod_lambda=1e-2, scales=3, weight_factors=None):
+        super().__init__()
+        self.scales, self.nr_classes, self.pod_lambda, self.weight_factors = scales, nr_classes, pod_lambda, weight_factors
+        self.ce = _NaNIfEmptyCE(ignore_index=255)
+
+    def update_plop_params(self, old_interm_results, interm_results, thresholds, max_entropy):
+        self.thresholds, self.max_entropy = thresholds, max_entropy
+        self.interm_results, self.old_interm_results = interm_results, old_interm_results
+        self.num_layers = len(self.old_interm_results.keys())
+
+    def forward(self, x, x_o, y):
+        assert isinstance(x, (tuple, list)), "x must be either tuple or list"
+        assert isinstance(x_o, (tuple, list)), "x_o must be either tuple or list"
+        assert isinstance(y, (tuple, list)), "y must be either tuple or list"
+        weights = [1] * len(x) if self.weight_factors is None else self.weight_factors
+        pseudo_loss = weights[0] * self._pseudo_label_loss(x[0], x_o[0], y[0], idx=0)
+        for i in range(1, len(x)):
+            if weights[i] != 0:
+                pseudo_loss = pseudo_loss + weights[i] * self._pseudo_label_loss(x[i], x_o[i], y[i], idx=i)
+        dist_loss = _dist_loss(self.old_interm_results, self.interm_results, self.pod_lambda, self.scales, x[0].device)
+        del self.thresholds, self.max_entropy, self.interm_results, self.old_interm_results
+        return pseudo_loss + dist_loss
+
+    def _pseudo_label_loss(self, x, x_o, y, idx):
+        N, K = x.shape[:2]
+        assert N > 1, "batch size 1: y.squeeze() drops the batch axis and the reference's CE fails on the shape (DS.py:265)"
+        D, H, W = x.shape[2:]
+        dev = x.device
+        xo = x_o.detach().to(dev, torch.float32).contiguous()
+        yy = y.detach().to(dev, torch.float32).contiguous()
+        thr = torch.as_tensor(self.thresholds[idx], dtype=torch.float32, device=dev).contiguous()
+        lab, pse = torch.empty((N, 1, D, H, W), device=dev), torch.empty((N, 1, D, H, W), device=dev)
+        cnt = torch.empty((2, N, W), dtype=torch.int32, device=dev)
+        nat.call("lnn_plop_pseudo_labels", xo, yy, thr, float(self.max_entropy), N, K, D, H, W, lab, pse, cnt[0], cnt[1])
+        # DS.py:299-304: masks summed over dims (1,2) of (B,D,H,W) -> a (B,W) table of ratios; it multiplies two SCALAR CE
+        # terms, so only its mean matters
+        factor = (cnt[0].float() / cnt[1].float()).mean()
+        return factor * (self.ce(x, pse) + self.ce(x, lab))
+
+
+class MultipleOutputLossPOD(MultipleOutputLoss2):
+    """deep_supervision.py:337-381: the deep-supervised base loss + the value-only local-POD term."""
+
+    def __init__(self, loss, weight_factors=None, pod_lambda=1e-2, scales=3):
+        super().__init__(loss, weight_factors)
+        self.pod_lambda, self.scales = pod_lambda, scales
+
+    def update_plop_params(self, old_interm_results, interm_results):
+        self.old_interm_results, self.interm_results = old_interm_results, interm_results
+        self.num_layers = len(self.old_interm_results.keys())
+
+    def forward(self, x, y):
+        loss = super().forward(x, y)
+        return loss + _dist_loss(self.old_interm_results, self.interm_results, self.pod_lambda, self.scales, x[0].device)

@@ -13,7 +13,6 @@ one launch per deep-supervision level and direction.
 import torch
 
 from ....losses import MultipleOutputLossMiB as MiBLoss
-from ....network import Generic_UNet
 from ..multihead.nnUNetTrainerMultiHead import nnUNetTrainerMultiHead
 
 HYPERPARAMS = {'mib_alpha': float, 'mib_lkd': float}
@@ -37,14 +36,7 @@ class nnUNetTrainerMiB(nnUNetTrainerMultiHead):
         if not self.was_initialized:
             self.initialize(True, num_epochs=self.max_num_epochs)
         if str(task) not in self.mh_network.heads:
-            # copy.deepcopy(self.network) of the reference (:96): a second network object with the current weights
-            p = self.plans
-            self.network_old = Generic_UNet(p["num_input_channels"], p["base_num_features"], p["num_classes"], p["num_pool"],
-                                            device=self.device)
-            self.network_old.load_state_dict(self.network.state_dict())
-            for prm in self.network_old.parameters():
-                prm.requires_grad = False
-            self.network_old.eval()
+            self.network_old = self.frozen_copy_of_network()         # copy.deepcopy(self.network), MiB.py:96
         return super().run_training(task, output_folder, build_folder)
 
     def on_forward_done(self, data, output, do_backprop):

@@ -61,6 +61,7 @@ class nnUNetTrainerMultiHead:
                           transfer_heads, ViT_task_specific_ln, do_LSA, do_SPT)
         self.split, self.task, self.fold = split, task, fold
         self.plans = dict(DEFAULT_PLANS if plans is None else plans)
+        self.num_classes = self.plans["num_classes"]      # logit channels, background included (upstream process_plans)
         self.batch_dice = batch_dice          # False for single-stage 3d_fullres (run/default_configuration.py:93-100)
         self.deterministic, self.fp16 = deterministic, fp16
         self.save_interval, self.extension = save_interval, extension
@@ -139,6 +140,20 @@ class nnUNetTrainerMultiHead:
         self.task = task
         self.tr_gen = self.data_provider(task, "train", self.plans)
         self.val_gen = self.data_provider(task, "val", self.plans)
+
+    def frozen_copy_of_network(self):
+        """``copy.deepcopy(self.network)`` of the distillation trainers (MiB.py:96, PLOP.py:181, POD.py:66): a second network
+        object with the current weights (own parameter arena, weight panels and activation buffers), same storage mode,
+        evaluated without autograd."""
+        from ....network import Generic_UNet
+        p = self.plans
+        old = Generic_UNet(p["num_input_channels"], p["base_num_features"], p["num_classes"], p["num_pool"], device=self.device)
+        old.storage = self.network.storage
+        old.load_state_dict(self.network.state_dict())
+        for prm in old.parameters():
+            prm.requires_grad = False
+        old.eval()
+        return old
 
     def maybe_update_lr(self, epoch=None):
         ep = self.epoch + 1 if epoch is None else epoch

@@ -220,7 +220,7 @@ def _is_cuda_dev(d):
 @contextlib.contextmanager
 def cuda_as_cpu():
     """Run reference lines that name CUDA devices explicitly on the CPU (values are device independent)."""
-    orig_to, orig_tensor, orig_zeros_like = torch.Tensor.to, torch.tensor, torch.zeros_like
+    orig_to, orig_tensor, orig_zeros_like, orig_cuda = torch.Tensor.to, torch.tensor, torch.zeros_like, torch.Tensor.cuda
 
     def to(self, *a, **k):
         a = tuple(x for x in a if not _is_cuda_dev(x))
@@ -238,12 +238,13 @@ def cuda_as_cpu():
         return wrapped
 
     torch.Tensor.to = to
+    torch.Tensor.cuda = lambda self, *a, **k: self
     torch.tensor = _strip(orig_tensor)
     torch.zeros_like = _strip(orig_zeros_like)
     try:
         yield
     finally:
-        torch.Tensor.to, torch.tensor, torch.zeros_like = orig_to, orig_tensor, orig_zeros_like
+        torch.Tensor.to, torch.tensor, torch.zeros_like, torch.Tensor.cuda = orig_to, orig_tensor, orig_zeros_like, orig_cuda
 
 
 def import_trainer(ext, cls):
