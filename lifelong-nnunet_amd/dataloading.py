@@ -20,6 +20,10 @@ in tests/test_host_logic.py):
 NOT built: the batchgenerators augmentation pipeline (spatial / intensity transforms), the
 2-D loader, cascade inputs.  ``PreprocessedDataProvider`` adapts the loader to the trainers' ``data_provider(task, split,
 plans)`` contract and yields the dictionary the iteration consumes (MH.py:606-608).
+
+Attribution: the algorithms restated in this file (function names kept so that callers read like upstream's) are those of
+nnU-Net v1 (https://github.com/MIC-DKFZ/nnUNet, commit 77bc485, Apache License 2.0, Isensee et al., Nature Methods 2021);
+no upstream source text is included.
 """
 from __future__ import annotations
 

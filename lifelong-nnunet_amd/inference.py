@@ -18,6 +18,10 @@ upstream nnU-Net v1 (``SegmentationNetwork.predict_3D`` -> ``_internal_predict_3
 
 The network forward is the HIP engine (batch 1, ``do_ds`` off); softmax, flip-back, weighting and accumulation are ONE
 fused launch per mirrored pass (``lnn_softmax_accumulate``); normalisation + argmax one more (``lnn_softmax_finalize``).
+
+Attribution: the algorithms restated in this file (function names kept so that callers read like upstream's) are those of
+nnU-Net v1 (https://github.com/MIC-DKFZ/nnUNet, commit 77bc485, Apache License 2.0, Isensee et al., Nature Methods 2021);
+no upstream source text is included.
 """
 from functools import lru_cache
 from typing import Sequence, Tuple
