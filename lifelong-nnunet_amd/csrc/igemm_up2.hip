@@ -204,27 +204,55 @@ __global__ __launch_bounds__(NT, 2) void igemm_up2_kernel(const ConvParams p, in
         __syncthreads();
     }
 
-    // ---- epilogue: the eight parity classes of the lane's low-res voxel --------------------------------------
-    const int qz = qz0 + wz, qy = qy0 + wy, qx = qx0 + vx;
+    // ---- epilogue: through LDS, so that every global store instruction writes whole output ROWS -------------
+    // A lane's accumulators are 4-channel (8-byte) pieces of eight output voxels that lie two apart: stored directly, a
+    // wave-wide store touched 32 cache lines with 16 bytes each and the kernel was bound by the address pipe (2.4-2.9 TB/s
+    // of output).  The block's output tile (4 x 16 x 16 voxels x 32 channels) is staged per z parity (2 x 16 rows of
+    // 16 voxels x 64 B) and leaves as 16-byte-per-lane stores of complete 1 KB rows (8 full lines per instruction).
+    // Staging layout: row stride 1040 B, the 8-byte piece index p = 2 qq + hk XOR-keyed with (vx >> 1) & 3: the
+    // 32 lanes of a ds_write_b64 half hit 32 distinct bank pairs, the ds_read_b128 of 4 consecutive voxels is linear.
+    constexpr int RS = 1040;
+    char* const stg = smem;
+    const int qz = qz0 + wz, qy = qy0 + wy;
+    const int skey = (vx >> 1) & 3;
 #pragma unroll
-    for (int cls = 0; cls < 8; ++cls) {
-        const int oz = 2 * qz + (cls >> 2), oy = 2 * qy + ((cls >> 1) & 1), ox = 2 * qx + (cls & 1);
-        if (oz >= p.Do || oy >= p.Ho || ox >= p.Wo) continue;
-        half_t* yrow = p.y + ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.ld_y;
+    for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int m = m0 + qq * 8 + hk * 4;
-            if (m >= p.M) continue;
-            float r0 = acc[cls][qq * 4 + 0], r1 = acc[cls][qq * 4 + 1], r2 = acc[cls][qq * 4 + 2], r3 = acc[cls][qq * 4 + 3];
-            half4* dst = reinterpret_cast<half4*>(yrow + m);
-            if (p.accumulate) {
-                const half4 old = *dst;
-                r0 += (float)old[0]; r1 += (float)old[1]; r2 += (float)old[2]; r3 += (float)old[3];
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int cls = pz * 4 + c4, py = c4 >> 1, px = c4 & 1;
+            char* vb = stg + (wz * 16 + 2 * wy + py) * RS + (2 * vx + px) * 64;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const half4 o = {(half_t)acc[cls][qq * 4 + 0], (half_t)acc[cls][qq * 4 + 1], (half_t)acc[cls][qq * 4 + 2],
+                                 (half_t)acc[cls][qq * 4 + 3]};
+                *reinterpret_cast<half4*>(vb + (((2 * qq + hk) ^ skey) << 3)) = o;
             }
-            half4 o = {(half_t)r0, (half_t)r1, (half_t)r2, (half_t)r3};
-            *dst = o;
         }
+        __syncthreads();
+        {
+            const int ox = (lane >> 2) & 15, c = lane & 3;
+            const int rkey = (ox >> 2) & 3;                              // = skey of the low-res voxel ox >> 1
+            const int gx = 2 * qx0 + ox, m = m0 + c * 8;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = wave * 8 + rr, zl = row >> 4, oyl = row & 15;
+                const int oz = 2 * (qz0 + zl) + pz, oy = 2 * qy0 + oyl;
+                half8 v = *reinterpret_cast<const half8*>(stg + row * RS + ox * 64 + ((c ^ (rkey >> 1)) << 4));
+                if (rkey & 1) v = half8{v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                if (oz < p.Do && oy < p.Ho && gx < p.Wo && m < p.M) {
+                    half8* dst = reinterpret_cast<half8*>(p.y + ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + gx) * p.ld_y + m);
+                    if (p.accumulate) {
+                        const half8 old = *dst;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+                    }
+                    *dst = v;
+                }
+            }
+        }
+        if (pz == 0) __syncthreads();
     }
+    (void)qz; (void)qy;
 }
 
 template <int MODE>
@@ -233,7 +261,8 @@ int launch_up2(hipStream_t s, ConvParams& p, const char* name) {
     p.tiles_z = lnn_cdiv((p.Do + 1) / 2, TZ); p.tiles_y = lnn_cdiv((p.Ho + 1) / 2, TY); p.tiles_x = lnn_cdiv((p.Wo + 1) / 2, TX);
     const int mblocks = lnn_cdiv(p.M, MB);
     const long blocks = (long)p.N * p.tiles_z * p.tiles_y * p.tiles_x * mblocks;
-    const size_t lds = 2 * XBYTES + 2 * Cfg::WBYTES;
+    const size_t lds_main = 2 * XBYTES + 2 * Cfg::WBYTES, lds_stage = 32 * 1040;
+    const size_t lds = lds_main > lds_stage ? lds_main : lds_stage;
     auto kern = igemm_up2_kernel<MODE>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -33,8 +33,12 @@ struct WgradParams {
     int M, C, Mpad, Cpad;
     int tiles_z, tiles_y, tiles_x, tiles_total, tiles_per_block;
     int pad_lo;
+    int debug = 0;                    // LNN_WGRAD_DEBUG (measurements only): 1 = skip the epilogue atomics
     WTapTable taps;
 };
+
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ half4 lds_tr16(const char* addr) {
     fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
@@ -186,6 +190,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
 // in registers and written to LDS between two barriers afterwards; 54 KB LDS / block -> two blocks per CU,
 // so one block's staging and barriers are covered by the other block's MFMAs.
 // ------------------------------------------------------------------------------------------------
+// SHARE (default): the wave's taps are grouped by (dz, dy) ROWS so that the three dx taps of a row share their operand.
+// After the transposing read a lane holds one channel's 8 consecutive x positions of a halo row (4 dwords); the operand
+// of tap dx+1 is the same row shifted by one position.  One extra 8-byte read (positions 8..11) + 4 v_alignbit give all
+// three operands: 3 reads per 3 MFMAs instead of 6 (wave w: rows 2w, 2w+1, and tap dx = w of row 8 for w < 3:
+// 5 KB of LDS reads per 16-voxel chunk instead of 8 KB -- the kernel is LDS-bandwidth bound, 1.14 KB per MFMA before).
+template <bool SHARE>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradParams p) {
     constexpr int TZ = 4, TY = 8, TX = 8, TV = TZ * TY * TX, PZ = 6, PY = 10, PX = 10, P = PZ * PY * PX, TPW = 7;
     constexpr int QB = P * 64;
@@ -234,10 +244,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
     unsigned qok = 0, pok = 0;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     auto load_tile = [&](int tile) {
+        // z runs fastest: a block walks a column of tiles, so 2 of the 6 halo planes of a tile were fetched by the SAME
+        // block one tile earlier and come from the XCD's L2 instead of HBM (the level-0 layers move 3 TB/s here)
         int t = tile;
+        const int tz = t % p.tiles_z; t /= p.tiles_z;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int tz = t % p.tiles_z; t /= p.tiles_z;
         const int n = t;
         const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
         const long qbase = ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + cq;
@@ -289,10 +301,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
         }
     };
 
+    // accumulator ti -> tap: SHARE: rows 2w (ti 0..2), 2w+1 (ti 3..5), row 8 dx = w (ti 6, w < 3); else taps w + 4 ti
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    auto tap_of = [&](int ti) { return SHARE ? (ti < 6 ? (2 * uw + ti / 3) * 3 + ti % 3 : (uw < 3 ? 24 + uw : 27)) : uw + 4 * ti; };
     int tapaddr[TPW];   // per-lane halo-tile byte address of this wave's taps (no table gather in the loop)
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = __builtin_amdgcn_readfirstlane(wave) + 4 * ti;
+        const int tap = min(tap_of(ti), 26);
         tapaddr[ti] = q_lane + (((tap / 9) * PY + (tap / 3) % 3) * PX + tap % 3) * 64;
     }
     load_tile(t_begin);
@@ -309,13 +324,34 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
             const int qimm = (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64;
             const half4 a0 = lds_tr16(pl + pimm + p_addr), a1 = lds_tr16(pl + pimm + 256 + p_addr);
             const half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            if (SHARE) {
 #pragma unroll
-            for (int ti = 0; ti < TPW; ++ti) {
-                const int tap = wave + 4 * ti;
-                if (tap < 27) {
-                    const half4 b0 = lds_tr16(ql + qimm + tapaddr[ti]), b1 = lds_tr16(ql + qimm + 256 + tapaddr[ti]);
+                for (int rr = 0; rr < 2; ++rr) {
+                    const char* qa = ql + qimm + tapaddr[3 * rr];
+                    const uint2v d01 = __builtin_bit_cast(uint2v, lds_tr16(qa)), d23 = __builtin_bit_cast(uint2v, lds_tr16(qa + 256)),
+                                 d45 = __builtin_bit_cast(uint2v, lds_tr16(qa + 512));
+                    const uint4v w0 = {d01[0], d01[1], d23[0], d23[1]};
+                    const uint4v w1 = {__builtin_amdgcn_alignbit(d01[1], d01[0], 16), __builtin_amdgcn_alignbit(d23[0], d01[1], 16),
+                                       __builtin_amdgcn_alignbit(d23[1], d23[0], 16), __builtin_amdgcn_alignbit(d45[0], d23[1], 16)};
+                    const uint4v w2 = {d01[1], d23[0], d23[1], d45[0]};
+                    acc[3 * rr + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[3 * rr + 0], 0, 0, 0);
+                    acc[3 * rr + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w1), acc[3 * rr + 1], 0, 0, 0);
+                    acc[3 * rr + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w2), acc[3 * rr + 2], 0, 0, 0);
+                }
+                if (uw < 3) {
+                    const half4 b0 = lds_tr16(ql + qimm + tapaddr[6]), b1 = lds_tr16(ql + qimm + 256 + tapaddr[6]);
                     const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
+                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[6], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < TPW; ++ti) {
+                    const int tap = wave + 4 * ti;
+                    if (tap < 27) {
+                        const half4 b0 = lds_tr16(ql + qimm + tapaddr[ti]), b1 = lds_tr16(ql + qimm + 256 + tapaddr[ti]);
+                        const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -324,9 +360,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
         __syncthreads();
     }
     const int c = c0 + (lane & 31);
+    if (p.debug & 1) {
+        if (acc[0][0] == 12345.678f) p.dwp[0] = acc[1][0] + acc[2][0] + acc[3][0] + acc[4][0] + acc[5][0] + acc[6][0];
+        return;
+    }
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = wave + 4 * ti;
+        const int tap = tap_of(ti);
         if (tap < 27) {
             float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
 #pragma unroll
@@ -620,13 +660,22 @@ int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
     if (tpb > p.tiles_total) tpb = p.tiles_total;
     p.tiles_per_block = tpb;
     const size_t lds = (size_t)(600 + 256) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    static int share = -1;          // LNN_WGRAD_NOSHARE=1: the per-tap operand reads of round 1 (A/B measurements)
+    if (share < 0) {
+        const char* e = getenv("LNN_WGRAD_NOSHARE");
+        share = (e && e[0] == '1') ? 0 : 1;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("LNN_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; }
+    p.debug = dbg;
+    if (dbg & 2) { tpb = lnn_cdiv((long)p.tiles_total * panels, 256); if (tpb > p.tiles_total) tpb = p.tiles_total; p.tiles_per_block = tpb; }
     dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
-    hipLaunchKernelGGL(igemm_wgrad_s1_v2_kernel, grid, dim3(256), lds, s, p);
+    // operand sharing pays where the launch is LDS-bound (deeper layers: +5..10 %); the two level-0 shapes with 1-2 panels are
+    // bound by the halo traffic (PMC: 2.5x algorithmic at 3.3 TB/s) and lose 4-8 % to the extra VALU work
+    if (share && panels >= 4) hipLaunchKernelGGL((igemm_wgrad_s1_v2_kernel<true>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((igemm_wgrad_s1_v2_kernel<false>), grid, dim3(256), lds, s, p);
     LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v2)");
     return LNN_OK;
 }

@@ -108,7 +108,8 @@ class _EWCPenaltyFunction(torch.autograd.Function):
     g * lambda * F_t (theta - theta*_t) straight into the flat gradient arena."""
 
     @staticmethod
-    def forward(ctx, anchor, arena, fishers, stars, ewc_lambda):
+    def forward(ctx, anchor, arena, fishers, stars, ewc_lambda, net=None, touched=()):
+        ctx.net, ctx.touched = net, touched
         ws = torch.empty(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=arena.theta.device)
         total = torch.zeros((), device=arena.theta.device)
         out = torch.empty(1, device=arena.theta.device)
@@ -123,7 +124,12 @@ class _EWCPenaltyFunction(torch.autograd.Function):
         for f, s in zip(ctx.fishers, ctx.stars):
             nat.call("lnn_ewc_penalty_bwd", ctx.arena.theta, s, f, ctx.arena.size, ctx.lam, 1.0,
                      g.reshape(1).float().contiguous(), ctx.arena.grad)
-        return None, None, None, None, None
+        if ctx.net is not None:
+            # these parameters now HAVE a gradient (torch: .grad is not None), also the zero-weight deep-supervision head
+            # the network's own backward never touches: clip_grad_norm_ counts it and SGD steps it (weight decay, momentum,
+            # the pull towards theta*) -- optim._ranges must not skip it
+            ctx.net.penalty_grad_names = set(getattr(ctx.net, "penalty_grad_names", ())) | set(ctx.touched)
+        return None, None, None, None, None, None, None
 
 
 class MultipleOutputLossEWC(MultipleOutputLoss2):
@@ -171,7 +177,7 @@ class MultipleOutputLossEWC(MultipleOutputLoss2):
         """sum over ``self.tasks`` of lam/2 * sum F_t (theta - theta*_t)^2, or None when nothing applies."""
         if len(self.tasks) == 0 or self.network_params is None:
             return None
-        fishers, stars, arena, anchor = [], [], None, None
+        fishers, stars, arena, anchor, net, touched = [], [], None, None, None, set()
         for task in self.tasks:
             # deep_supervision.py:65-66: the task loop is outermost and ``network_params`` is whatever the
             # trainer handed over -- a *generator* for the base EWC trainer (ewc/nnUNetTrainerEWC.py:140,247),
@@ -179,14 +185,16 @@ class MultipleOutputLossEWC(MultipleOutputLoss2):
             named = [(n, p) for n, p in self.network_params]
             if not named:
                 continue
-            arena = named[0][1]._lnn_net.arena
+            net = named[0][1]._lnn_net
+            arena = net.arena
+            touched |= {n for n, p in named if p.requires_grad and self._selected(n)}
             anchor = next((p for _, p in named if p.requires_grad), named[0][1])
             F, S = self._flat_for(task, named, arena)
             fishers.append(F)
             stars.append(S)
         if not fishers:
             return None
-        return _EWCPenaltyFunction.apply(anchor, arena, fishers, stars, lam)
+        return _EWCPenaltyFunction.apply(anchor, arena, fishers, stars, lam, net, frozenset(touched))
 
     def forward(self, x, y, reg=True):
         loss = super().forward(x, y)

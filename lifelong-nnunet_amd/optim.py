@@ -18,7 +18,8 @@ def _ranges(net):
     """Contiguous arena ranges [lo, hi) of the parameters that require grad."""
     # torch.optim.SGD skips parameters whose .grad is None (no weight decay, no momentum): that is the case of
     # the zero-weight deep-supervision head, which the engine reports in net.params_without_grad
-    skip = getattr(net, "params_without_grad", ())
+    # ... unless a penalty node (EWC / RW) wrote a gradient into its slot this iteration (losses._EWCPenaltyFunction)
+    skip = set(getattr(net, "params_without_grad", ())) - set(getattr(net, "penalty_grad_names", ()))
     spans = sorted((p._lnn_slot.offset, p._lnn_slot.offset + (p._lnn_slot.numel + 3) // 4 * 4)
                    for n, p in net._named if p.requires_grad and n not in skip)
     out = []
@@ -98,6 +99,7 @@ class FusedSGD:
 
     def zero_grad(self, set_to_none=False):
         self.net.arena.grad.zero_()
+        self.net.penalty_grad_names = set()
         self.net.bind_grads()
 
     def grad_norm_pass(self, inv_scale=1.0):

@@ -9,9 +9,13 @@ Reference behaviours reproduced in parity mode:
   * "Fisher" is the squared gradient of the LAST after_train batch (zero_grad inside the loop), and the
     penalty is absent from that gradient when there are >= 2 batches (generator exhausted on batch 0);
   * a parameter whose ``.grad`` is None (the zero-weight deep-supervision head) gets Fisher ``tensor([1])``.
-The gradient is taken UNSCALED (the reference's fp32 / CPU path; its fp16 path leaves the GradScaler
-factor in, EWC.py:287).  ``fisher_mode='accumulate'`` is the optional true empirical Fisher (mean of g^2
-over the batches, all-reduced across ranks once per task).
+The gradient is taken UNSCALED by default (the reference's fp32 / CPU path, and what its docstrings describe).  Its
+fp16 path squares ``param.grad`` right after ``amp_grad_scaler.scale(loss).backward()`` (EWC.py:287,303) without
+``unscale_``: the stored Fisher is (loss_scale * g)^2, i.e. the same ``ewc_lambda`` regularises loss_scale^2
+(4.3e9 at the initial 65536) times harder and the value depends on the scaler's history.
+``fisher_keeps_loss_scale=True`` reproduces that, so that Fisher pickles of reference fp16 runs are comparable.
+``fisher_mode='accumulate'`` is the optional true empirical Fisher (mean of g^2 over the batches, all-reduced
+across ranks once per task).
 """
 from collections import OrderedDict
 
@@ -26,11 +30,13 @@ HYPERPARAMS = {'ewc_lambda': float}
 
 
 class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
-    def __init__(self, split, task, *args, ewc_lambda=0.4, fisher_mode="last_batch", **kwargs):
+    def __init__(self, split, task, *args, ewc_lambda=0.4, fisher_mode="last_batch", fisher_keeps_loss_scale=False,
+                 **kwargs):
         kwargs.setdefault("extension", "ewc")
         super().__init__(split, task, *args, **kwargs)
         self.ewc_lambda = ewc_lambda
         self.fisher_mode = fisher_mode
+        self.fisher_keeps_loss_scale = fisher_keeps_loss_scale
         self.fisher = OrderedDict()
         self.params = OrderedDict()
 
@@ -76,6 +82,7 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
         n = self.num_batches_per_epoch
         arena = self.network.arena
         scale = self.amp_grad_scaler.get_scale()
+        unscale = 1.0 if self.fisher_keeps_loss_scale else 1.0 / scale
         world_avg = self.dp.averaging_factor if self.dp is not None else 1.0
         if self.fisher_mode == "accumulate":
             facc = torch.zeros_like(arena.grad)
@@ -99,13 +106,13 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
             if self.dp is not None and self.fisher_mode != "accumulate":
                 self.dp.finish()                            # parity mode squares the ALL-REDUCED gradient
             if self.fisher_mode == "accumulate":
-                nat.call("lnn_fisher_accumulate", arena.grad, facc, arena.size, 1.0 / scale, 1.0 / n)
+                nat.call("lnn_fisher_accumulate", arena.grad, facc, arena.size, unscale, 1.0 / n)
         if self.fisher_mode == "accumulate":
             all_reduce_stats(facc, self.process_group)
             fflat = facc * world_avg
         else:
             fflat = torch.empty_like(arena.grad)
-            nat.call("lnn_fisher_square", arena.grad, fflat, arena.size, world_avg / scale)
+            nat.call("lnn_fisher_square", arena.grad, fflat, arena.size, world_avg * unscale)
         no_grad = self.network.params_without_grad
         for name, param in self.network.named_parameters():
             s = param._lnn_slot

@@ -323,3 +323,23 @@ def test_mib_trainer_flow_matches_oracle():
     o_val = float(olosses.mib_loss(out_new, [o.detach() for o in out_old], b['target'], w, 1.0, 10.0))
     print(f"MiB task B iter 0: oracle {o_val:.6f} hip {tr.all_tr_losses[-1]:.6f}")
     assert abs(tr.all_tr_losses[-1] - o_val) <= 2e-4 * abs(o_val)
+
+
+def test_ewc_fisher_keeps_loss_scale_flag():
+    """The reference's fp16 branch squares the SCALED gradient (EWC.py:287,303: no unscale_ before .pow(2)); the flag
+    reproduces it: Fisher = loss_scale^2 x the default (unscaled) Fisher."""
+    a = _make_trainer("ewc", "taskA")
+    b = _make_trainer("ewc", "taskA", fisher_keeps_loss_scale=True)
+    b.network.load_state_dict(a.network.state_dict())
+    b.mh_network.update_after_iteration()
+    for tr in (a, b):
+        tr.tr_gen = tr.data_provider("taskA", "train", tr.plans)        # same batches for both
+        tr.fisher["taskA"], tr.params["taskA"] = {}, {}
+        tr.after_train()
+    scale = a.amp_grad_scaler.get_scale()
+    assert scale == b.amp_grad_scaler.get_scale() == 65536.0
+    names = [n for n, f in a.fisher["taskA"].items() if f.numel() > 1]
+    fa, fb = _flat(a.fisher["taskA"], names), _flat(b.fisher["taskA"], names)
+    assert float(fa.sum()) > 0
+    assert float((fb / scale ** 2 - fa).norm() / fa.norm()) < 1e-3      # fp32 atomics of the weight-gradient kernels: order only
+    assert all(float(b.fisher["taskA"][n]) == 1.0 for n in b.fisher["taskA"] if b.fisher["taskA"][n].numel() == 1)

@@ -194,6 +194,13 @@ def test_fp32_ewc_flow_matches_reference(ref):
     print(f"fp32 EWC task B vs reference: loss rel {np.abs(np.array(losses) / np.array(e['lossesB']) - 1).max():.2e} "
           f"fisher rel-L2 {rf:.2e} final theta rel-L2 {rt:.2e}")
     assert rf < 1e-4 and rt < 1e-4
+    # the zero-weight deep-supervision head: the network's backward never gives it a gradient, the EWC penalty does (a zero
+    # one here: theta == theta*), so torch's SGD steps it -- weight decay + momentum shrink it by 2.6e-6 over the 3 steps.
+    # A trainer that leaves it frozen ends on theta*_A instead.
+    i = names.index("seg_outputs.0.weight")
+    got = float(dict(tr.network.named_parameters())["seg_outputs.0.weight"].double().norm())
+    exp, frozen = arr["ewc::final_theta::stats"][i, 1], arr["ewc::paramsA::stats"][i, 1]
+    assert abs(frozen - exp) > 1e-6 * exp and abs(got - exp) < 0.2 * abs(frozen - exp), (got, exp, frozen)
 
 
 def test_fp32_rw_flow_matches_reference(ref):
