@@ -33,7 +33,8 @@ struct WgradParams {
     int M, C, Mpad, Cpad;
     int tiles_z, tiles_y, tiles_x, tiles_total, tiles_per_block;
     int pad_lo;
-    int debug = 0;                    // LNN_WGRAD_DEBUG (measurements only): 1 = skip the epilogue atomics
+    int debug = 0;                    // LNN_WGRAD_DEBUG (measurements only): 1 = skip the epilogue atomics, 4 = phase timers
+    unsigned long long* dbgbuf = nullptr;   // LNN_WGRAD_PHASEBUF: 6 x u64 {issue, mfma, barrier1, store, barrier2, tiles}
     WTapTable taps;
 };
 
@@ -313,51 +314,97 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
     load_tile(t_begin);
     store_tile();
     __syncthreads();
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    const bool timed = (p.debug & 4) && p.dbgbuf;
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
         const bool more = tile + 1 < t_end;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (timed) t0 = __builtin_readcyclecounter();
         if (more) load_tile(tile + 1);
+        if (timed) t1 = __builtin_readcyclecounter();
+        // Software-pipelined operand reads.  hipcc schedules `ds_read; s_waitcnt lgkmcnt(0); v_mfma` back to back (the
+        // LDS latency of ~100 cycles then paces every 32-cycle MFMA: PMC showed the matrix pipe 43 % busy with 4 % LDS
+        // stalls and no HBM limit), so the reads are issued two MFMA groups ahead into rotating registers and pinned with
+        // sched_barrier.  The 7th accumulator of the wave that has only 6 taps runs on a duplicate tap and is dropped in
+        // the epilogue: no wave-dependent branches in the loop.
+        constexpr int NCH = TV / 16;
+        auto qrow = [&](int ch) { return (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64; };
+        half4 al[2], ah[2];
+        auto rdA = [&](int ch) {
+            al[ch & 1] = lds_tr16(pl + ch * 1024 + p_addr);
+            ah[ch & 1] = lds_tr16(pl + ch * 1024 + 256 + p_addr);
+        };
+        if (SHARE) {
+            // groups per chunk: row 2w (3 reads, 3 MFMAs), row 2w+1 (3, 3), single tap (2, 1)
+            uint2v g0[3], g1[3], g2[3];
+            auto rdG = [&](int g) {
+                const int ch = g / 3, k = g % 3, sl = g % 3;
+                const char* qa = ql + qrow(ch) + tapaddr[3 * k];
+                g0[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa));
+                g1[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 256));
+                if (k < 2) g2[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 512));
+            };
+            rdA(0);
+            rdG(0);
+            rdG(1);
 #pragma unroll
-        for (int ch = 0; ch < TV / 16; ++ch) {
-            // chunk rows 2ch, 2ch+1: immediates, the per-lane part lives in p_addr / tapaddr
-            const int pimm = ch * 1024;
-            const int qimm = (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64;
-            const half4 a0 = lds_tr16(pl + pimm + p_addr), a1 = lds_tr16(pl + pimm + 256 + p_addr);
-            const half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            if (SHARE) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const char* qa = ql + qimm + tapaddr[3 * rr];
-                    const uint2v d01 = __builtin_bit_cast(uint2v, lds_tr16(qa)), d23 = __builtin_bit_cast(uint2v, lds_tr16(qa + 256)),
-                                 d45 = __builtin_bit_cast(uint2v, lds_tr16(qa + 512));
-                    const uint4v w0 = {d01[0], d01[1], d23[0], d23[1]};
+            for (int g = 0; g < 3 * NCH; ++g) {
+                const int ch = g / 3, k = g % 3, sl = g % 3;
+                if (g + 2 < 3 * NCH) rdG(g + 2);
+                if (k == 1 && ch + 1 < NCH) rdA(ch + 1);
+                const half8 a = {al[ch & 1][0], al[ch & 1][1], al[ch & 1][2], al[ch & 1][3],
+                                 ah[ch & 1][0], ah[ch & 1][1], ah[ch & 1][2], ah[ch & 1][3]};
+                const uint2v d01 = g0[sl], d23 = g1[sl], d45 = g2[sl];
+                const uint4v w0 = {d01[0], d01[1], d23[0], d23[1]};
+                if (k < 2) {
                     const uint4v w1 = {__builtin_amdgcn_alignbit(d01[1], d01[0], 16), __builtin_amdgcn_alignbit(d23[0], d01[1], 16),
                                        __builtin_amdgcn_alignbit(d23[1], d23[0], 16), __builtin_amdgcn_alignbit(d45[0], d23[1], 16)};
                     const uint4v w2 = {d01[1], d23[0], d23[1], d45[0]};
-                    acc[3 * rr + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[3 * rr + 0], 0, 0, 0);
-                    acc[3 * rr + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w1), acc[3 * rr + 1], 0, 0, 0);
-                    acc[3 * rr + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w2), acc[3 * rr + 2], 0, 0, 0);
+                    acc[3 * k + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[3 * k + 0], 0, 0, 0);
+                    acc[3 * k + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w1), acc[3 * k + 1], 0, 0, 0);
+                    acc[3 * k + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w2), acc[3 * k + 2], 0, 0, 0);
+                } else {
+                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[6], 0, 0, 0);
                 }
-                if (uw < 3) {
-                    const half4 b0 = lds_tr16(ql + qimm + tapaddr[6]), b1 = lds_tr16(ql + qimm + 256 + tapaddr[6]);
-                    const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[6], 0, 0, 0);
-                }
-            } else {
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            half4 bl[3], bh[3];
+            auto rdB = [&](int j) {
+                const int ch = j / TPW, ti = j % TPW;
+                bl[j % 3] = lds_tr16(ql + qrow(ch) + tapaddr[ti]);
+                bh[j % 3] = lds_tr16(ql + qrow(ch) + 256 + tapaddr[ti]);
+            };
+            rdA(0);
+            rdB(0);
+            rdB(1);
 #pragma unroll
-                for (int ti = 0; ti < TPW; ++ti) {
-                    const int tap = wave + 4 * ti;
-                    if (tap < 27) {
-                        const half4 b0 = lds_tr16(ql + qimm + tapaddr[ti]), b1 = lds_tr16(ql + qimm + 256 + tapaddr[ti]);
-                        const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
-                    }
-                }
+            for (int j = 0; j < NCH * TPW; ++j) {
+                const int ch = j / TPW, ti = j % TPW;
+                if (j + 2 < NCH * TPW) rdB(j + 2);
+                if (ti == 3 && ch + 1 < NCH) rdA(ch + 1);
+                const half8 a = {al[ch & 1][0], al[ch & 1][1], al[ch & 1][2], al[ch & 1][3],
+                                 ah[ch & 1][0], ah[ch & 1][1], ah[ch & 1][2], ah[ch & 1][3]};
+                const half8 b = {bl[j % 3][0], bl[j % 3][1], bl[j % 3][2], bl[j % 3][3], bh[j % 3][0], bh[j % 3][1], bh[j % 3][2], bh[j % 3][3]};
+                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (timed) t2 = __builtin_readcyclecounter();
         __syncthreads();                 // every wave is done reading this tile
+        if (timed) t3 = __builtin_readcyclecounter();
         if (more) store_tile();
+        if (timed) t4 = __builtin_readcyclecounter();
         __syncthreads();
+        if (timed) {
+            const unsigned long long t5 = __builtin_readcyclecounter();
+            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4;
+        }
+    }
+    if (timed && lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(p.dbgbuf + i, ph[i]);
+        atomicAdd(p.dbgbuf + 5, (unsigned long long)(t_end - t_begin));
     }
     const int c = c0 + (lane & 31);
     if (p.debug & 1) {
@@ -649,6 +696,240 @@ int launch_wgrad(hipStream_t s, WgradParams& p, const char* name) {
     return LNN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stride-1 weight gradient, v4 (round 2).  The phase timers of v2 (tools/kbench.py --wgrad-phases) showed where its time
+// goes per wave and tile: 4.6 k cycles ISSUING the 14 register-prefetch loads (the wave blocks while the CU's L1 absorbs
+// 57 KB at ~18 B/clk), 4.9 k in the MFMA loop, 1.5 k writing the registers to LDS, 0.8 k in two barriers -- the matrix
+// pipe sits at 43 %, and neither HBM (a MALL-resident half-size problem: +5 %) nor LDS latency (pipelined reads: +0 %) nor
+// the epilogue atomics (-2 % without them) is the limit.  v4 removes the issue and store phases instead of hiding them:
+//   * tiles arrive by DMA (buffer_load ... lds, 16 B per lane straight into the linear [position][64 B] tile image; lanes
+//     outside the volume / channel range carry an out-of-range offset and the descriptor zero-fills them), 7 instructions
+//     per thread and tile, issued one at a time BETWEEN the MFMA groups of the current tile: no staging registers, no LDS
+//     store phase, the wave never waits for the address pipe;
+//   * two tile images (2 x 56 KB), ONE barrier per tile (vmcnt(0) + s_barrier);
+//   * one 8-wave block per CU: wave = (tap group 0..3, tile half 0..1), 8 chunks x 7 taps = 56 MFMAs per wave and tile,
+//     operand reads software-pipelined two groups ahead and shared between the three dx taps of a row (see v2).
+// ------------------------------------------------------------------------------------------------
+// The DMA is issued through inline asm: hipcc's waitcnt pass treats the transposing LDS read (an intrinsic without a
+// memory operand) like an LDS store and puts `s_waitcnt vmcnt(0)` in front of EVERY such read once an LDS-DMA load it knows
+// about is in flight (seen in the ISA of the builtin version) -- which serialises each DMA against the MFMA loop.  Hidden
+// VMEM operations only make compiler-generated vmcnt waits stricter, never wrong (loads return in order).
+// rs = raw buffer descriptor {base[31:0], base[47:32], num_records, flags}; lds_addr = byte address of the wave's 1 KB run.
+__device__ __forceinline__ void wg_dma16(uint4v rs, unsigned lds_addr, int voffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rs)
+                 : "memory");       // m0 is reserved by the backend (it never allocates it), so no clobber entry is needed
+}
+__device__ __forceinline__ uint4v wg_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    uint4v r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]);
+    r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    return r;
+}
+__device__ __forceinline__ void wg_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int STEP>
+__global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v4_kernel(const WgradParams p) {
+    constexpr int TZ = 4, TY = 8, TX = 8, PZ = 6, PY = 10, PX = 10, P = PZ * PY * PX, TPW = 7;
+    constexpr int NQ = 5, NP = 2, NT = 512;                 // DMA instructions per thread and tile: 5 x 512 >= 4 P, 2 x 512 = 4 TV
+    constexpr int QB = NQ * NT * 16, BUFB = QB + NP * NT * 16;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), tg = wave & 3, hf = wave >> 2;
+    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
+    const half_t* const qsrc = c0 >= p.csplit ? p.q2 : p.q;
+    const int cq = c0 >= p.csplit ? c0 - p.csplit : c0;
+    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
+    const int chb = (cb + 4 * sq) * 2;
+    // this wave's half of the tile = chunks 8 hf .. 8 hf + 7 = tile planes 2 hf, 2 hf + 1
+    const int p_addr = QB + (8 * hk + sj) * 64 + chb + hf * 8 * 1024;
+    const int q_lane = (hk * PX + sj) * 64 + chb + hf * 2 * PY * PX * 64;
+
+    floatx16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
+    if (t_begin >= t_end) return;
+
+    // per-thread DMA constants: byte offset relative to the tile origin and the packed tile coordinate of each piece
+    int qrel[NQ], qco[NQ], prel[NP], pco[NP];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int idx = i * NT + tid, pos = idx >> 2, c8 = idx & 3;
+        const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+        const bool st = pos < P;
+        qrel[i] = st ? (((pz * p.Qh + py) * p.Qw + px) * p.ld_q + c8 * 8) * 2 : OOB;
+        qco[i] = st ? (pz | (py << 8) | (px << 16) | (c8 << 24)) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int idx = j * NT + tid, vox = idx >> 2, c8 = idx & 3;
+        const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
+        prel[j] = (((z * p.Lh + y) * p.Lw + x) * p.ld_p + c8 * 8) * 2;
+        pco[j] = z | (y << 8) | (x << 16) | (c8 << 24);
+    }
+
+    // accumulator ti -> tap: rows 2 tg (ti 0..2), 2 tg + 1 (ti 3..5), row 8 dx = tg (ti 6, tg < 3; a dropped duplicate for tg = 3)
+    auto tap_of = [&](int ti) { return ti < 6 ? (2 * tg + ti / 3) * 3 + ti % 3 : (tg < 3 ? 24 + tg : 27); };
+    int tapaddr[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = min(tap_of(ti), 26);
+        tapaddr[ti] = q_lane + (((tap / 9) * PY + (tap / 3) % 3) * PX + tap % 3) * 64;
+    }
+
+    uint4v qrs, prs;
+    int qv[NQ], pv[NP];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    auto prep = [&](int tile) {            // descriptors + lane offsets of a tile (z runs fastest)
+        int t = tile;
+        const int tz = t % p.tiles_z; t /= p.tiles_z;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n = t;
+        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+        const long qbase = ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + cq;
+        const long pbase = ((((long)n * p.Ld + lz0) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
+        qrs = wg_rsrc(qsrc + qbase);
+        prs = wg_rsrc(p.p + pbase);
+        const bool interior = lz0 >= 1 && ly0 >= 1 && lx0 >= 1 && lz0 + TZ + 1 <= p.Qd && ly0 + TY + 1 <= p.Qh &&
+                              lx0 + TX + 1 <= p.Qw && c0 + 32 <= p.C && m0 + 32 <= p.M;
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) qv[i] = qrel[i];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) pv[j] = prel[j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int iz = lz0 - 1 + (qco[i] & 255), iy = ly0 - 1 + ((qco[i] >> 8) & 255), ix = lx0 - 1 + ((qco[i] >> 16) & 255);
+                const bool ok = qco[i] >= 0 && (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh &&
+                                (unsigned)ix < (unsigned)p.Qw && c0 + (qco[i] >> 24) * 8 < p.C;
+                qv[i] = ok ? qrel[i] : OOB;
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool ok = lz0 + (pco[j] & 255) < p.Ld && ly0 + ((pco[j] >> 8) & 255) < p.Lh && lx0 + ((pco[j] >> 16) & 255) < p.Lw &&
+                                m0 + (pco[j] >> 24) * 8 < p.M;
+                pv[j] = ok ? prel[j] : OOB;
+            }
+        }
+    };
+    auto issue = [&](int k, int nb) {      // k-th DMA instruction of the prepared tile into tile image nb
+        const unsigned base = lds0 + nb * BUFB + wave * 1024;
+        if (k < NQ) wg_dma16(qrs, base + k * (NT * 16), qv[k]);
+        else wg_dma16(prs, base + QB + (k - NQ) * (NT * 16), pv[k - NQ]);
+    };
+
+    prep(t_begin);
+#pragma unroll
+    for (int k = 0; k < NQ + NP; ++k) issue(k, 0);
+    wg_wait_all();
+    __syncthreads();
+
+    int cur = 0;
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool more = tile + 1 < t_end;
+        if (more) prep(tile + 1);
+        const char* const tb = smem + cur * BUFB;
+        constexpr int NCH = 8;
+        auto qrow = [&](int ch) { return (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64; };
+        half4 al[2], ah[2];
+        auto rdA = [&](int ch) {
+            al[ch & 1] = lds_tr16(tb + ch * 1024 + p_addr);
+            ah[ch & 1] = lds_tr16(tb + ch * 1024 + 256 + p_addr);
+        };
+        uint2v g0[3], g1[3], g2[3];
+        auto rdG = [&](int g) {
+            const int ch = g / 3, k = g % 3, sl = g % 3;
+            const char* qa = tb + qrow(ch) + tapaddr[3 * k];
+            g0[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa));
+            g1[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 256));
+            if (k < 2) g2[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 512));
+        };
+        rdA(0);
+        rdG(0);
+        rdG(1);
+#pragma unroll
+        for (int g = 0; g < 3 * NCH; ++g) {
+            const int ch = g / 3, k = g % 3, sl = g % 3;
+            if (g + 2 < 3 * NCH) rdG(g + 2);
+            if (k == 1 && ch + 1 < NCH) rdA(ch + 1);
+            if (g % STEP == STEP - 1 && g / STEP < NQ + NP) {
+                if (more) issue(g / STEP, cur ^ 1);
+            }
+            const half8 a = {al[ch & 1][0], al[ch & 1][1], al[ch & 1][2], al[ch & 1][3],
+                             ah[ch & 1][0], ah[ch & 1][1], ah[ch & 1][2], ah[ch & 1][3]};
+            const uint2v d01 = g0[sl], d23 = g1[sl], d45 = g2[sl];
+            const uint4v w0 = {d01[0], d01[1], d23[0], d23[1]};
+            if (k < 2) {
+                const uint4v w1 = {__builtin_amdgcn_alignbit(d01[1], d01[0], 16), __builtin_amdgcn_alignbit(d23[0], d01[1], 16),
+                                   __builtin_amdgcn_alignbit(d23[1], d23[0], 16), __builtin_amdgcn_alignbit(d45[0], d23[1], 16)};
+                const uint4v w2 = {d01[1], d23[0], d23[1], d45[0]};
+                acc[3 * k + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[3 * k + 0], 0, 0, 0);
+                acc[3 * k + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w1), acc[3 * k + 1], 0, 0, 0);
+                acc[3 * k + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w2), acc[3 * k + 2], 0, 0, 0);
+            } else {
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[6], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wg_wait_all();                   // the next tile image is complete ...
+        __syncthreads();                 // ... and every wave is done reading this one
+        cur ^= 1;
+    }
+    const int c = c0 + (lane & 31);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = tap_of(ti);
+        if (tap < 27) {
+            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
+                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
+            }
+        }
+    }
+}
+
+int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
+    constexpr int TZ = 4, TY = 8, TX = 8;
+    p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
+    p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
+    const int panels = (p.Mpad / 32) * (p.Cpad / 32);
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    static int step = 0;
+    if (!step) { const char* e = getenv("LNN_WGRAD_V4_STEP"); step = e ? atoi(e) : 2; if (step < 1 || step > 3) step = 2; }
+    // one block per CU: spread tiles x panels over ~num_cu blocks, >= 1 tile per block
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, num_cu);
+    if (tpb < 1) tpb = 1;
+    if (tpb > p.tiles_total) tpb = p.tiles_total;
+    p.tiles_per_block = tpb;
+    const size_t lds = (size_t)2 * (5 + 2) * 512 * 16;
+    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<1>), grid, dim3(512), lds, s, p);
+    else if (step == 2) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<2>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<3>), grid, dim3(512), lds, s, p);
+    LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v4)");
+    return LNN_OK;
+}
+
 int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
     constexpr int TZ = 4, TY = 8, TX = 8;
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
@@ -670,6 +951,9 @@ int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("LNN_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; }
     p.debug = dbg;
+    static unsigned long long* dbgbuf = nullptr;
+    if ((dbg & 4) && !dbgbuf) { const char* e = getenv("LNN_WGRAD_PHASEBUF"); if (e) dbgbuf = (unsigned long long*)strtoull(e, nullptr, 0); }
+    p.dbgbuf = dbgbuf;
     if (dbg & 2) { tpb = lnn_cdiv((long)p.tiles_total * panels, 256); if (tpb > p.tiles_total) tpb = p.tiles_total; p.tiles_per_block = tpb; }
     dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
     // operand sharing pays where the launch is LDS-bound (deeper layers: +5..10 %); the two level-0 shapes with 1-2 panels are
@@ -785,6 +1069,11 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
         if (use_v1 < 0) { const char* e = getenv("LNN_CONV_V1"); use_v1 = (e && e[0] == '1') ? 1 : 0; }
         LNN_REQUIRE(!(use_v1 && x2), "lnn_conv3d_wgrad_cat: not supported by the generic first-version kernel (LNN_CONV_V1)");
         if (use_v1) return launch_wgrad<1, 3, 4, 8, 7>(s, p, "lnn_conv3d_wgrad(s1)");
+        static int use_v2 = -1;          // LNN_WGRAD_V2=1: the register-prefetch kernel of round 1 (A/B measurements, tests)
+        if (use_v2 < 0) { const char* e = getenv("LNN_WGRAD_V2"); use_v2 = (e && e[0] == '1') ? 1 : 0; }
+        // the DMA descriptors address a tile with 32-bit offsets relative to its origin: 6 input planes must stay below 2 GB
+        const bool v4_ok = 6L * p.Qh * p.Qw * p.ld_q * 2 < 0x7fffffffL && 4L * p.Lh * p.Lw * p.ld_p * 2 < 0x7fffffffL;
+        if (!use_v2 && v4_ok) return launch_wgrad_s1_v4(s, p);
         return launch_wgrad_s1_v2(s, p);
     }
     if (use_wgrad_s2_v2()) return launch_wgrad_s2_v2<3>(s, p, "lnn_conv3d_wgrad(s2,v2)");

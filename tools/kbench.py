@@ -28,8 +28,14 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--phases", action="store_true", help="print the v3 conv kernel's per-phase cycle split")
     ap.add_argument("--check", default="", help="comma list of forced kernels (e.g. 5,9): run fwd/dgrad with each and compare outputs")
+    ap.add_argument("--wgrad-phases", action="store_true", help="print the stride-1 wgrad kernel's per-phase cycle split (LNN_WGRAD_DEBUG=4)")
     a = ap.parse_args()
     dev = "cuda:0"
+    wdbg = None
+    if a.wgrad_phases:
+        wdbg = torch.zeros(6, dtype=torch.int64, device=dev)
+        os.environ["LNN_WGRAD_DEBUG"] = "4"
+        os.environ["LNN_WGRAD_PHASEBUF"] = hex(wdbg.data_ptr())
     for name in a.layers.split(","):
         if name in UPS:
             N, C, K, D, H, W = UPS[name]
@@ -95,6 +101,11 @@ def main():
                 print(f"   check kernel {k} vs {ks[0]}: fwd max|diff| {dfy:.3e} (max|y| {float(res[ks[0]][0].abs().max()):.2f})  "
                       f"dgrad max|diff| {dfx:.3e} (max|dx| {float(res[ks[0]][1].abs().max()):.2f})", flush=True)
             del res
+        if wdbg is not None and s == 1 and "wgrad" in a.which:
+            wdbg.zero_(); fns["wgrad"](); torch.cuda.synchronize()
+            d = wdbg.cpu().tolist(); nt = max(d[5], 1)
+            print("   wgrad phases (cycles per wave-tile): " + ", ".join(f"{n} {d[i]/nt:7.0f}" for i, n in enumerate(["issue", "mfma", "barrier1", "store", "barrier2"])) +
+                  f"  | total {sum(d[:5])/nt:7.0f}  (112 MFMAs = 3584 pipe cycles per wave-tile)", flush=True)
         if a.phases and s == 1:
             dbg = torch.zeros(6, dtype=torch.int64, device=dev)
             nat.lib().lnn_debug_set_phase_buffer(dbg.data_ptr())
