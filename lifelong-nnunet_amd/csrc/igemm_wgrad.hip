@@ -900,6 +900,257 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v4_kernel(const WgradPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stride-1 weight gradient, v5 = v4 + a z-ring of input planes.  With the issue stalls gone v4 moves 3.4-3.8 TB/s through
+// the fabric on the level-0 layers (the 6x10x10 halo of a 4x8x8 tile is 2.34x its voxels and L2 keeps none of it: PMC 2.5x
+// the algorithmic bytes), i.e. it is bandwidth-bound again.  A block walks a column of tiles in z, so 2 of the 6 input
+// planes of the next tile are already in LDS: the input tile lives in a ring of 12 plane slots (10x10 positions x 64 B,
+// padded to 7 wave-wide DMA rows = 7 KB), only the 4 NEW planes are fetched per tile (6 when the next tile starts a new
+// column: the ring has room for them next to the 6 planes in use), the dy tile stays double-buffered.  Bytes per tile
+// 54.4 -> 41.6 KB.  Out-of-volume planes use a zero-length descriptor, out-of-volume rows / columns / channels an
+// out-of-range lane offset: both make the DMA write zeros (= the conv's zero padding).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4v wg_rsrc_n(const void* base, unsigned num_records) {
+    const unsigned long long a = (unsigned long long)base;
+    uint4v r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, num_records, 0x00020000u};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]);
+    r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]);
+    return r;
+}
+
+template <int STEP>
+__global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradParams p) {
+    constexpr int TZ = 4, TY = 8, TX = 8, PY = 10, PX = 10, PP = PY * PX, TPW = 7, NT = 512;
+    constexpr int SLOTB = 7 * 1024, NSLOT = 12, QB = NSLOT * SLOTB, PB = 2 * NT * 16;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), tg = wave & 3, hf = wave >> 2;
+    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
+    const half_t* const qsrc = c0 >= p.csplit ? p.q2 : p.q;
+    const int cq = c0 >= p.csplit ? c0 - p.csplit : c0;
+    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
+    const int chb = (cb + 4 * sq) * 2;
+    const int p_lane = QB + (8 * hk + sj) * 64 + chb + hf * 8 * 1024;      // + (dy tile image) * PB + chunk * 1024
+
+    // this wave's operand rows: k = 0, 1 -> (dz, dy) rows 2 tg, 2 tg + 1 with their three dx taps; k = 2 -> tap (2, 2, dx = tg)
+    // (a dropped duplicate for tg = 3)
+    int rowlane[3], rowdz[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int r = k < 2 ? 2 * tg + k : 8, dx0 = k < 2 ? 0 : min(tg, 2);
+        rowdz[k] = r / 3;
+        rowlane[k] = (hk * PX + sj) * 64 + chb + ((r % 3) * PX + dx0) * 64;
+    }
+    auto tap_of = [&](int ti) { return ti < 6 ? (2 * tg + ti / 3) * 3 + ti % 3 : (tg < 3 ? 24 + tg : 27); };
+
+    floatx16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
+    if (t_begin >= t_end) return;
+
+    // DMA lane constants.  Input plane: waves 0..6 cover its 400 16-byte pieces (piece = 64 wave + lane).
+    const int qpos = (wave * 64 + lane) >> 2, qc8 = lane & 3;
+    const int qpy = qpos / PX, qpx = qpos % PX;
+    const bool qst = qpos < PP;
+    const int qrel = qst ? ((qpy * p.Qw + qpx) * p.ld_q + qc8 * 8) * 2 : OOB;
+    const long qplane = (long)p.Qh * p.Qw * p.ld_q;            // elements per input plane
+    int prel[2], pco[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = j * NT + tid, vox = idx >> 2, c8 = idx & 3;
+        const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
+        prel[j] = (((z * p.Lh + y) * p.Lw + x) * p.ld_p + c8 * 8) * 2;
+        pco[j] = z | (y << 8) | (x << 16) | (c8 << 24);
+    }
+
+    struct Tile {
+        const half_t* qorg;    // input position (lz0 - 1, ly0 - 1, lx0 - 1) of sample n, channel cq
+        const half_t* porg;    // dy position (lz0, ly0, lx0), channel m0
+        int lz0, tz, qv, pxy[2], pv[2];
+    };
+    const long pplane = (long)p.Lh * p.Lw * p.ld_p;
+    auto set_pv = [&](Tile& t) {                               // z extent of the dy tile (the y / x / channel part is per column)
+        const bool zin = t.lz0 + TZ <= p.Ld;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) t.pv[j] = (zin || t.lz0 + (pco[j] & 255) < p.Ld) ? t.pxy[j] : OOB;
+    };
+    auto prep = [&](int tile) {                                // full decode: first tile of the block / of a column
+        Tile t;
+        int r = tile;
+        t.tz = r % p.tiles_z; r /= p.tiles_z;
+        const int tx = r % p.tiles_x; r /= p.tiles_x;
+        const int ty = r % p.tiles_y; r /= p.tiles_y;
+        const int n = r;
+        const int lz0 = t.tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+        t.lz0 = lz0;
+        t.qorg = qsrc + ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + cq;
+        t.porg = p.p + ((((long)n * p.Ld + lz0) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
+        const bool inner = ly0 >= 1 && lx0 >= 1 && ly0 + TY + 1 <= p.Qh && lx0 + TX + 1 <= p.Qw && c0 + 32 <= p.C;
+        if (inner) {
+            t.qv = qrel;
+        } else {
+            const int iy = ly0 - 1 + qpy, ix = lx0 - 1 + qpx;
+            const bool ok = qst && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw && c0 + qc8 * 8 < p.C;
+            t.qv = ok ? qrel : OOB;
+        }
+        const bool pin = ly0 + TY <= p.Lh && lx0 + TX <= p.Lw && m0 + 32 <= p.M;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = pin || (ly0 + ((pco[j] >> 8) & 255) < p.Lh && lx0 + ((pco[j] >> 16) & 255) < p.Lw && m0 + (pco[j] >> 24) * 8 < p.M);
+            t.pxy[j] = ok ? prel[j] : OOB;
+        }
+        set_pv(t);
+        return t;
+    };
+    auto advance = [&](const Tile& c, int tile_next) {         // next tile: same column -> a few adds (no divisions)
+        if (c.tz + 1 < p.tiles_z) {
+            Tile t = c;
+            t.tz = c.tz + 1;
+            t.lz0 = c.lz0 + TZ;
+            t.qorg = c.qorg + TZ * qplane;
+            t.porg = c.porg + TZ * pplane;
+            set_pv(t);
+            return t;
+        }
+        return prep(tile_next);
+    };
+    auto dma_q = [&](const Tile& t, int rel, int slot) {       // input plane `rel` (0..5) of tile t -> ring slot
+        const int iz = t.lz0 - 1 + rel;
+        const uint4v rs = wg_rsrc_n(t.qorg + rel * qplane, (unsigned)iz < (unsigned)p.Qd ? 0x7fffffffu : 0u);
+        if (wave < 7) wg_dma16(rs, lds0 + slot * SLOTB + wave * 1024, t.qv);
+    };
+    auto dma_p = [&](const Tile& t, int j, int img) {
+        wg_dma16(wg_rsrc_n(t.porg, 0x7fffffffu), lds0 + QB + img * PB + j * (NT * 16) + wave * 1024, t.pv[j]);
+    };
+    auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
+
+    Tile cur = prep(t_begin);
+    int base = 0, img = 0;
+#pragma unroll
+    for (int rel = 0; rel < 6; ++rel) dma_q(cur, rel, rel);
+    dma_p(cur, 0, 0);
+    dma_p(cur, 1, 0);
+    wg_wait_all();
+    __syncthreads();
+
+    // operand addresses of a tile: (row k, plane zq of this wave's tile half) -> ring slot; dy tile image
+    int qaddr[3][2], pa;
+    auto addr_for = [&](int b, int im, int (&qa)[3][2], int& pav) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int zq = 0; zq < 2; ++zq) qa[k][zq] = rowlane[k] + wrap(wrap(b + 2 * hf + zq + rowdz[k])) * SLOTB;
+        pav = p_lane + im * PB;
+    };
+    addr_for(0, 0, qaddr, pa);
+
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    const bool timed = (p.debug & 4) && p.dbgbuf;
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool more = tile + 1 < t_end;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (timed) t0 = __builtin_readcyclecounter();
+        Tile nxt = cur;
+        if (more) nxt = advance(cur, tile + 1);
+        const bool same_col = nxt.tz != 0;                  // z runs fastest: the next tile continues this column
+        const int nin = more ? (same_col ? 4 : 6) : 0, rel0 = same_col ? 2 : 0;
+        const int nbase = wrap(base + (same_col ? 4 : 6));
+        int qaddr_n[3][2], pa_n;
+
+        if (timed) t1 = __builtin_readcyclecounter();
+        constexpr int NCH = 8;
+        half4 al[2], ah[2];
+        auto rdA = [&](int ch) {
+            al[ch & 1] = lds_tr16(smem + pa + ch * 1024);
+            ah[ch & 1] = lds_tr16(smem + pa + ch * 1024 + 256);
+        };
+        uint2v g0[3], g1[3], g2[3];
+        auto rdG = [&](int g) {
+            const int ch = g / 3, k = g % 3, sl = g % 3;
+            const char* qa = smem + qaddr[k][ch / 4] + ((2 * ch) % TY) * PX * 64;
+            g0[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa));
+            g1[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 256));
+            if (k < 2) g2[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 512));
+        };
+        rdA(0);
+        rdG(0);
+        rdG(1);
+#pragma unroll
+        for (int g = 0; g < 3 * NCH; ++g) {
+            const int ch = g / 3, k = g % 3, sl = g % 3;
+            if (g + 2 < 3 * NCH) rdG(g + 2);
+            if (k == 1 && ch + 1 < NCH) rdA(ch + 1);
+            if (g == 12) addr_for(nbase, img ^ 1, qaddr_n, pa_n);     // next tile's addresses, off the critical path
+            if (g % STEP == STEP - 1 && g / STEP < 8) {     // 8 DMA issue points, every STEP-th group
+                const int i = g / STEP;
+                if (i < 6) {
+                    if (i < nin) dma_q(nxt, rel0 + i, wrap(wrap(base + 6 + i)));
+                } else if (more) {
+                    dma_p(nxt, i - 6, img ^ 1);
+                }
+            }
+            const half8 a = {al[ch & 1][0], al[ch & 1][1], al[ch & 1][2], al[ch & 1][3],
+                             ah[ch & 1][0], ah[ch & 1][1], ah[ch & 1][2], ah[ch & 1][3]};
+            const uint2v d01 = g0[sl], d23 = g1[sl], d45 = g2[sl];
+            const uint4v w0 = {d01[0], d01[1], d23[0], d23[1]};
+            if (k < 2) {
+                const uint4v w1 = {__builtin_amdgcn_alignbit(d01[1], d01[0], 16), __builtin_amdgcn_alignbit(d23[0], d01[1], 16),
+                                   __builtin_amdgcn_alignbit(d23[1], d23[0], 16), __builtin_amdgcn_alignbit(d45[0], d23[1], 16)};
+                const uint4v w2 = {d01[1], d23[0], d23[1], d45[0]};
+                acc[3 * k + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[3 * k + 0], 0, 0, 0);
+                acc[3 * k + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w1), acc[3 * k + 1], 0, 0, 0);
+                acc[3 * k + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w2), acc[3 * k + 2], 0, 0, 0);
+            } else {
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[6], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (timed) t2 = __builtin_readcyclecounter();
+        wg_wait_all();                   // the next tile's planes / dy tile are complete ...
+        if (timed) t3 = __builtin_readcyclecounter();
+        __syncthreads();                 // ... and every wave is done reading this tile
+        if (timed) {
+            const unsigned long long t4 = __builtin_readcyclecounter();
+            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+        }
+        base = nbase;
+        img ^= 1;
+        cur = nxt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int zq = 0; zq < 2; ++zq) qaddr[k][zq] = qaddr_n[k][zq];
+        pa = pa_n;
+    }
+    if (timed && lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(p.dbgbuf + i, ph[i]);
+        atomicAdd(p.dbgbuf + 5, (unsigned long long)(t_end - t_begin));
+    }
+    const int c = c0 + (lane & 31);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = tap_of(ti);
+        if (tap < 27) {
+            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
+                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
+            }
+        }
+    }
+}
+
 int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
     constexpr int TZ = 4, TY = 8, TX = 8;
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
@@ -914,6 +1165,13 @@ int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    static int dbg4 = -1;
+    static unsigned long long* dbgbuf4 = nullptr;
+    if (dbg4 < 0) {
+        const char* e = getenv("LNN_WGRAD_DEBUG"); dbg4 = e ? atoi(e) : 0;
+        const char* b = getenv("LNN_WGRAD_PHASEBUF"); if ((dbg4 & 4) && b) dbgbuf4 = (unsigned long long*)strtoull(b, nullptr, 0);
+    }
+    p.debug = dbg4; p.dbgbuf = dbgbuf4;
     static int step = 0;
     if (!step) { const char* e = getenv("LNN_WGRAD_V4_STEP"); step = e ? atoi(e) : 2; if (step < 1 || step > 3) step = 2; }
     // one block per CU: spread tiles x panels over ~num_cu blocks, >= 1 tile per block
@@ -923,6 +1181,19 @@ int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
     p.tiles_per_block = tpb;
     const size_t lds = (size_t)2 * (5 + 2) * 512 * 16;
     dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    static int ring = -1;
+    if (ring < 0) {
+        const char* e = getenv("LNN_WGRAD_RING");
+        ring = (e && e[0] == '0') ? 0 : 1;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (ring) {
+        if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<1>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
+        else hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<2>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
+        LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v5)");
+        return LNN_OK;
+    }
     if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<1>), grid, dim3(512), lds, s, p);
     else if (step == 2) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<2>), grid, dim3(512), lds, s, p);
     else hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<3>), grid, dim3(512), lds, s, p);

@@ -1,9 +1,4 @@
-export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/dn; mkdir -p $OUT
-for c in FETCH_SIZE WRITE_SIZE; do
-  d=/tmp/pmc_$c; rm -rf $d
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $d -o r -- python $OLDPWD/tools/kbench.py --layers enc1.0s2,up4 --which fwd,dgrad --iters 3 > $OUT/$c.log 2>&1)
-  db=$(find $d -name "*.db" | head -1)
-  python tools/rocpd_pmc.py $db > $OUT/$c.txt 2>&1
-  grep -A1 "down2\|up2" $OUT/$c.txt
-done
+export LNN_WGRAD_RING=0
+bash tools/gpu_r2_pmc.sh wg4 dec4.0,enc0.1,dec3.0 wgrad > /dev/null 2>&1
+for f in sq1 sq2; do echo "## $f"; grep -h -A11 "wgrad_s1_v4" gpurun_out/wg4/pmc_$f.txt | head -14; done
+grep -h -A2 "wgrad_s1_v4" gpurun_out/wg4/pmc_fetch.txt | head -4

@@ -104,7 +104,7 @@ def main():
         if wdbg is not None and s == 1 and "wgrad" in a.which:
             wdbg.zero_(); fns["wgrad"](); torch.cuda.synchronize()
             d = wdbg.cpu().tolist(); nt = max(d[5], 1)
-            print("   wgrad phases (cycles per wave-tile): " + ", ".join(f"{n} {d[i]/nt:7.0f}" for i, n in enumerate(["issue", "mfma", "barrier1", "store", "barrier2"])) +
+            print("   wgrad phases (cycles per wave-tile): " + ", ".join(f"{n} {d[i]/nt:7.0f}" for i, n in enumerate(["prep(v5)|issue(v2)", "mfma", "vmwait(v5)|barrier1", "barrier(v5)|store", "barrier2"])) +
                   f"  | total {sum(d[:5])/nt:7.0f}  (112 MFMAs = 3584 pipe cycles per wave-tile)", flush=True)
         if a.phases and s == 1:
             dbg = torch.zeros(6, dtype=torch.int64, device=dev)
