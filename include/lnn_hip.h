@@ -132,6 +132,8 @@ int lnn_unpack_wgrad_batched(lnn_stream_t s, const float* panel_base, float* dst
  *   fwd   : z = lrelu(gamma*(y-mean)*rstd + beta)  written with ld_z (may target a concat buffer)
  *   bwd   : g = dz * lrelu'(.) ; dy = gamma*rstd*(g - mean_v(g) - xhat*mean_v(g*xhat)) written IN PLACE
  *           over y; dgamma/dbeta/dbias (+)= (fp32; dbias is the conv bias gradient = sum_v dy).
+ *           dbias may be NULL: the sum is analytically zero (InstanceNorm removes the mean) -- what it accumulates is the
+ *           fp16 rounding of dy -- and without it pass 2 is a pure stream (no block reductions, no finalize launch).
  *           grad_unscale multiplies the parameter gradients (1/loss_scale).
  * ---------------------------------------------------------------------------------------------- */
 int lnn_instnorm_stats(lnn_stream_t s, const void* y_h, int N, long V, int C, float eps, float* mean,

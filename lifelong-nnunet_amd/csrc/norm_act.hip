@@ -231,16 +231,24 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
 }
 
 // ws[(n*C + c)*3 + {0,1}] = s1, s2 (fp64 totals of the partials)
-__global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, double* ws) {
+// also adds the affine-parameter gradients (dbeta = sum g, dgamma = sum g * xhat): they do not depend on pass 2
+__global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, int C, double* ws, float* dgamma, float* dbeta,
+                                         float unscale) {
     __shared__ double red[256];
     const int i = blockIdx.x * 16 + (threadIdx.x & 15);
     const double s0 = sum_partials(pws, 0, nblk, NC, red), s1 = sum_partials(pws, 1, nblk, NC, red);
     if (i >= NC || (threadIdx.x >> 4) != 0) return;
     ws[(long)i * 3 + 0] = s0;
     ws[(long)i * 3 + 1] = s1;
+    // atomics: N samples (and, with sample lanes, two HIP streams) add into the same channel
+    if (dgamma) atomicAdd(dgamma + i % C, (float)(s1 * unscale));
+    if (dbeta) atomicAdd(dbeta + i % C, (float)(s0 * unscale));
 }
 
-// pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V), in place over y; db partial = sum dy
+// pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V), in place over y; DBIAS: db partial = sum dy (the conv-bias gradient; it is
+// analytically ZERO -- InstanceNorm removes the mean, so sum_v dy = 0 -- and what this sums is the fp16 rounding of dy; the
+// training engine does not ask for it and the pass is then a pure stream without block reductions)
+template <bool DBIAS>
 __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restrict__ y, const half_t* __restrict__ dz, int ld_dz,
                                                                 long V, int C, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
                 const float g = (float)d[e] * (pre > 0.f ? 1.f : slope);
                 const half_t r = (half_t)(ga[e] * rs[e] * (g - m1[e] - xh * m2[e]));
                 o[e] = r;
-                part[0][e] += (float)r;
+                if (DBIAS) part[0][e] += (float)r;
             }
             return o;
         };
@@ -295,9 +303,10 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
         for (; v < end; v += step)
             *reinterpret_cast<half8*>(yp + v * C) = grad(*reinterpret_cast<const half8*>(yp + v * C), *reinterpret_cast<const half8*>(dp + v * ld_dz));
     }
-    block_channel_reduce<1>(rm, C, part, red, [&](int, int c, float s) {
-        pws[((long)blockIdx.x * gridDim.y + n) * C + c] = s;
-    });
+    if (DBIAS)
+        block_channel_reduce<1>(rm, C, part, red, [&](int, int c, float s) {
+            pws[((long)blockIdx.x * gridDim.y + n) * C + c] = s;
+        });
 }
 
 __global__ void in_lrelu_bwd_finalize_kernel(const double* ws, const float* pws, int nblk, int N, int C, float* dgamma,
@@ -308,8 +317,7 @@ __global__ void in_lrelu_bwd_finalize_kernel(const double* ws, const float* pws,
     if (i >= N * C || (threadIdx.x >> 4) != 0) return;
     const int c = i % C;
     // atomics: N samples (and, with sample lanes, two HIP streams) add into the same channel
-    if (dgamma) atomicAdd(dgamma + c, (float)(ws[(long)i * 3 + 1] * unscale));
-    if (dbeta) atomicAdd(dbeta + c, (float)(ws[(long)i * 3 + 0] * unscale));
+    (void)ws; (void)dgamma; (void)dbeta;        // the affine gradients are added by the sums kernel
     if (dbias) atomicAdd(dbias + c, (float)(db * unscale));
 }
 
@@ -380,13 +388,20 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
     hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, grid, dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
                        mean, rstd, gamma, beta, slope, pws);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(reduce)");
-    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, ws);
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
+                       grad_unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(sums)");
-    hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
-                       rstd, gamma, beta, slope, ws, pws);
-    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
-    hipLaunchKernelGGL(in_lrelu_bwd_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, ws, pws, nblk, N, C, dgamma,
-                       dbeta, dbias, grad_unscale);
-    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(finalize)");
+    if (dbias) {
+        hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<true>), grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
+                           rstd, gamma, beta, slope, ws, pws);
+        LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
+        hipLaunchKernelGGL(in_lrelu_bwd_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, ws, pws, nblk, N, C, dgamma,
+                           dbeta, dbias, grad_unscale);
+        LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(finalize)");
+    } else {
+        hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<false>), grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
+                           rstd, gamma, beta, slope, ws, pws);
+        LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
+    }
     return LNN_OK;
 }

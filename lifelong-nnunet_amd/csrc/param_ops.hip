@@ -101,6 +101,52 @@ __global__ __launch_bounds__(NT) void pack_weights_batched_kernel(const float* _
     }
 }
 
+// Tiled variant (round 2): the blocked panel was designed so that one (32-row block, 16-channel chunk) is a contiguous
+// ntaps x 1 KB run, but the element-wise kernel above gathers it with eight 4-byte loads 108 B apart per thread (64
+// cache lines per wave-wide load: 0.38 ms per step at 0.66 TB/s).  Here a block owns one such unit: it reads the
+// 32 x 16 x ntaps source elements in SOURCE order (runs of 16 x 27 or 32 x 27 consecutive floats), transposes through
+// LDS and writes the run with 16-byte stores.
+__global__ __launch_bounds__(NT) void pack_weights_tiled_kernel(const float* __restrict__ src, half_t* __restrict__ dst,
+                                                                const long* __restrict__ desc, int n) {
+    constexpr int TS = 520;                        // tap pitch in LDS (halves): 512 + 8 keeps consecutive taps on different banks
+    __shared__ long ufirst[DESC_MAX + 1];
+    __shared__ __attribute__((aligned(16))) half_t tile[27 * TS];
+    if (threadIdx.x == 0) {
+        long acc = 0;
+        for (int j = 0; j < n; ++j) {
+            ufirst[j] = acc;
+            const long M = desc[j * DESC_W + 6], KC = desc[j * DESC_W + 7];
+            acc += ((M + 31) >> 5) * ((KC + 15) >> 4);
+        }
+        ufirst[n] = acc;
+    }
+    __syncthreads();
+    const long units = ufirst[n];
+    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+        const long* d = desc + find_desc(ufirst, n, u) * DESC_W;
+        const int ntaps = (int)d[5], M = (int)d[6], KC = (int)d[7];
+        const int nck = (KC + 15) >> 4;
+        const long lu = u - ufirst[find_desc(ufirst, n, u)];
+        const int mb = (int)(lu / nck), ck = (int)(lu % nck);
+        const long sm = d[2], skc = d[3], st = d[4];
+        const bool kc_inner = skc < sm;            // forward orientation: (kc, t) runs inside a row; dgrad: (m, t) runs
+        const int E = 512 * ntaps;
+        const float* sp = src + d[0];
+        for (int e = threadIdx.x; e < E; e += NT) {
+            const int t = e % ntaps, r = e / ntaps;
+            const int kcl = kc_inner ? r % 16 : r / 32, ml = kc_inner ? r / 16 : r % 32;
+            const int m = mb * 32 + ml, kc = ck * 16 + kcl;
+            const float v = (m < M && kc < KC) ? sp[m * sm + kc * skc + t * st] : 0.f;
+            tile[t * TS + ml * 16 + kcl] = (half_t)v;
+        }
+        __syncthreads();
+        half_t* out = dst + d[1] + ((long)mb * nck + ck) * ntaps * 512;
+        for (int i = threadIdx.x * 8; i < E; i += NT * 8)
+            *reinterpret_cast<half8*>(out + i) = *reinterpret_cast<const half8*>(tile + (i >> 9) * TS + (i & 511));
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(NT) void unpack_wgrad_batched_kernel(const float* __restrict__ dwp, float* __restrict__ dst,
                                                                   const long* __restrict__ desc, int n, long total, float scale,
                                                                   int accumulate) {
@@ -357,8 +403,11 @@ extern "C" int lnn_pack_weights_batched(lnn_stream_t s_, const float* src_base, 
     LNN_REQUIRE(src_base && dst_base && desc_dev && lnn_aligned16(dst_base), "lnn_pack_weights_batched: null/misaligned pointer");
     LNN_REQUIRE(n > 0 && n <= DESC_MAX && total > 0, "lnn_pack_weights_batched: 1..%d descriptors, total > 0", DESC_MAX);
     LNN_REQUIRE(total % 8 == 0, "lnn_pack_weights_batched: total %ld is not a sum of padded panel sizes", total);
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(flat_blocks(total / 8, 2)), dim3(NT), 0, s, src_base, (half_t*)dst_base,
-                       desc_dev, n, total);
+    static int tiled = -1;          // LNN_PACK_ELEMENTWISE=1: the round-1 gather kernel (A/B measurements)
+    if (tiled < 0) { const char* e = getenv("LNN_PACK_ELEMENTWISE"); tiled = (e && e[0] == '1') ? 0 : 1; }
+    if (tiled) hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3(2048), dim3(NT), 0, s, src_base, (half_t*)dst_base, desc_dev, n);
+    else hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(flat_blocks(total / 8, 2)), dim3(NT), 0, s, src_base, (half_t*)dst_base,
+                            desc_dev, n, total);
     LNN_CHECK_LAUNCH("lnn_pack_weights_batched");
     return LNN_OK;
 }

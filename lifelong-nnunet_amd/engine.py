@@ -344,6 +344,10 @@ class UNetEngine:
         self._side = None
         self._lstreams, self._lws = [], []
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
+        # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
+        # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
+        # (weight decay, momentum) exactly as torch does with a ~0 gradient.
+        self.numeric_conv_bias_grad = os.environ.get("LNN_NUMERIC_CONV_BIAS_GRAD", "0") == "1"
         self.fuse_in_stats = os.environ.get("LNN_NO_FUSED_IN_STATS", "0") != "1"     # A/B switch (measurements only)
         # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
         # little room), kept because it is the natural hook for per-sample pipelining across GPUs / larger batches
@@ -560,7 +564,7 @@ class UNetEngine:
                     nat.call("lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
                              item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
                              self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
-                             self.pview(item.b, self.grad), 1.0, ws)
+                             self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws)
                     D, H, W = item.in_dims
                     xin = at(self.image, n0) if item.x is None else at(item.x, n0)
                     ldx = 1 if item.x is None else item.x.ld

@@ -1,5 +1,5 @@
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_training_gpu.py -x -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_training_gpu.py -x -q 2>&1 | tail -3
 for i in 1 2; do
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('v5', d['ms_per_step'], d['value'])"
-LNN_WGRAD_RING=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('v4', d['ms_per_step'], d['value'])"
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('new', d['ms_per_step'], d['value'])"
+LNN_PACK_ELEMENTWISE=1 LNN_NUMERIC_CONV_BIAS_GRAD=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('old', d['ms_per_step'], d['value'])"
 done
