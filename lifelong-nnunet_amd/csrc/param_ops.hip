@@ -412,13 +412,69 @@ extern "C" int lnn_pack_weights_batched(lnn_stream_t s_, const float* src_base, 
     return LNN_OK;
 }
 
+
+namespace {
+// Tiled unpack: the element-wise kernel reads the fp32 panel [tap][Mpad][KCpad] with a stride of Mpad*KCpad between the taps
+// of a destination run.  A block owns 8 rows x 32 channels x all taps: panel reads in 128-byte segments, LDS transpose,
+// destination writes in DESTINATION order (runs of 32 x ntaps or 8 x ntaps consecutive floats).
+__global__ __launch_bounds__(NT) void unpack_wgrad_tiled_kernel(const float* __restrict__ dwp, float* __restrict__ dst,
+                                                                const long* __restrict__ desc, int n, float scale, int accumulate) {
+    __shared__ long ufirst[DESC_MAX + 1];
+    __shared__ float tile[8 * 32 * 27];
+    if (threadIdx.x == 0) {
+        long acc = 0;
+        for (int j = 0; j < n; ++j) {
+            ufirst[j] = acc;
+            const long M = desc[j * DESC_W + 6], KC = desc[j * DESC_W + 7];
+            acc += ((M + 7) >> 3) * ((KC + 31) >> 5);
+        }
+        ufirst[n] = acc;
+    }
+    __syncthreads();
+    const long units = ufirst[n];
+    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+        const int j = find_desc(ufirst, n, u);
+        const long* d = desc + j * DESC_W;
+        const int ntaps = (int)d[5], M = (int)d[6], KC = (int)d[7];
+        const int Mpad = (M + 31) & ~31, KCpad = (KC + 31) & ~31, nck = (KC + 31) >> 5;
+        const long lu = u - ufirst[j];
+        const int m0 = (int)(lu / nck) * 8, kc0 = (int)(lu % nck) * 32;
+        const int E = 8 * 32 * ntaps;
+        const float* pp = dwp + d[0];
+        for (int e = threadIdx.x; e < E; e += NT) {
+            const int kcl = e & 31, ml = (e >> 5) & 7, t = e >> 8;
+            const int m = m0 + ml, kc = kc0 + kcl;
+            tile[(ml * 32 + kcl) * ntaps + t] = (m < M && kc < KC) ? pp[((long)t * Mpad + m) * KCpad + kc] : 0.f;
+        }
+        __syncthreads();
+        const long sm = d[2], skc = d[3], st = d[4];
+        const bool kc_inner = skc < sm;
+        float* op = dst + d[1];
+        for (int e = threadIdx.x; e < E; e += NT) {
+            const int t = e % ntaps, r = e / ntaps;
+            const int kcl = kc_inner ? r % 32 : r / 8, ml = kc_inner ? r / 32 : r % 8;
+            const int m = m0 + ml, kc = kc0 + kcl;
+            if (m < M && kc < KC) {
+                float* o = op + m * sm + kc * skc + t * st;
+                const float v = scale * tile[(ml * 32 + kcl) * ntaps + t];
+                *o = accumulate ? *o + v : v;
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
 extern "C" int lnn_unpack_wgrad_batched(lnn_stream_t s_, const float* panel_base, float* dst_base, const long* desc_dev, int n,
                                         long total, float scale, int accumulate) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(panel_base && dst_base && desc_dev, "lnn_unpack_wgrad_batched: null pointer");
     LNN_REQUIRE(n > 0 && n <= DESC_MAX && total > 0, "lnn_unpack_wgrad_batched: 1..%d descriptors, total > 0", DESC_MAX);
-    hipLaunchKernelGGL(unpack_wgrad_batched_kernel, dim3(flat_blocks(total, 4)), dim3(NT), 0, s, panel_base, dst_base, desc_dev,
-                       n, total, scale, accumulate);
+    static int tiled = -1;          // LNN_PACK_ELEMENTWISE=1: the round-1 gather kernel (A/B measurements)
+    if (tiled < 0) { const char* e = getenv("LNN_PACK_ELEMENTWISE"); tiled = (e && e[0] == '1') ? 0 : 1; }
+    if (tiled) hipLaunchKernelGGL(unpack_wgrad_tiled_kernel, dim3(2048), dim3(NT), 0, s, panel_base, dst_base, desc_dev, n, scale, accumulate);
+    else hipLaunchKernelGGL(unpack_wgrad_batched_kernel, dim3(flat_blocks(total, 4)), dim3(NT), 0, s, panel_base, dst_base, desc_dev,
+                            n, total, scale, accumulate);
     LNN_CHECK_LAUNCH("lnn_unpack_wgrad_batched");
     return LNN_OK;
 }

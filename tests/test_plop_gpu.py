@@ -198,7 +198,8 @@ def test_pod_trainer_flow_matches_reference(ref, fp16):
     # the fix behind the flag: the third task's POD term is alive
     tr2, out2 = _run_flow("pod", f, tarr, fp16, reference_hook_aliasing=False)
     assert any(p > 0 for p in out2["taskC"][1])
-    np.testing.assert_allclose(out2["taskB"][0], out["taskB"][0], rtol=1e-6)
+    # task B is unaffected by the flag; two fp16 runs differ by the order of the weight-gradient atomics, two fp32 runs do not
+    np.testing.assert_allclose(out2["taskB"][0], out["taskB"][0], rtol=1e-4 if fp16 else 1e-6)
 
 
 @pytest.mark.parametrize("fp16", [True, False])
