@@ -141,6 +141,12 @@ int lnn_instnorm_stats(lnn_stream_t s, const void* y_h, int N, long V, int C, fl
 int lnn_instnorm_lrelu_fwd(lnn_stream_t s, const void* y_h, void* z_h, int ld_z, int N, long V, int C,
                            const float* mean, const float* rstd, const float* gamma, const float* beta,
                            float slope);
+/* lnn_instnorm_lrelu_fwd + lnn_seg1x1_fwd of the same activation in one pass (decoder blocks that feed a seg_outputs head,
+ * generic_ViT_UNet.py:263-264): logits (N,K,V) fp32 = seg_w (K,C) . z, computed from the fp16-rounded z the kernel writes.
+ * K <= 8, C/8 a power of two <= 64; other shapes: call the two functions. */
+int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s, const void* y, void* z, int ld_z, int N, long V, int C, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, float slope, const float* seg_w,
+                               float* logits, int K);
 int lnn_instnorm_lrelu_bwd(lnn_stream_t s, void* y_inout_h, const void* dz_h, int ld_dz, int N, long V, int C,
                            const float* mean, const float* rstd, const float* gamma, const float* beta,
                            float slope, float* dgamma, float* dbeta, float* dbias, float grad_unscale,

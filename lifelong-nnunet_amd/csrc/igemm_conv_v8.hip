@@ -20,7 +20,21 @@ constexpr int XCHUNKS = P * 2;              // 16-byte chunks per halo tile
 constexpr int NT = 512;
 constexpr int XN = (XCHUNKS + NT - 1) / NT; // 4 loads per thread per step
 constexpr int MB = 64, MT = 2, VT = 2;
-constexpr int WBYTES = 27 * MB * ROWB, WCHUNKS = 27 * MB * 2, WN = (WCHUNKS + NT - 1) / NT;  // 27648 B, 4 loads
+constexpr int WCHUNKS = 27 * MB * 2, WN = (WCHUNKS + NT - 1) / NT;     // 55296 B = 3456 16-byte pieces, 7 per thread
+constexpr int WSLOT = WN * NT * 16;         // slot pitch: a whole number of wave-wide DMA rows (57344 B)
+
+typedef unsigned v8_uint4 __attribute__((ext_vector_type(4)));
+// LDS-DMA through inline asm (see igemm_wgrad.hip: hipcc serialises builtin LDS-DMA against later LDS reads it cannot analyse)
+__device__ __forceinline__ void v8_dma16(v8_uint4 rs, unsigned lds_addr, int voffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rs) : "memory");
+}
+__device__ __forceinline__ v8_uint4 v8_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    v8_uint4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]);
+    r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    return r;
+}
 
 __device__ __forceinline__ int xaddr(int pz, int py, int px, int c2) {
     return ((pz * PY + py) * PX + px) * ROWB + ((c2 ^ (py & 1)) << 4);
@@ -43,11 +57,18 @@ struct Step {   // (work unit, 16-channel chunk)
     bool valid, first_chunk, last_chunk, interior;
 };
 
+// WDMA (round 2): the weight chunk of the next step (7 of the 11 loads a thread issued per step) arrives by LDS-DMA, one
+// instruction at a time between the MFMA groups -- no staging registers, no LDS store phase for it, and the wave no longer
+// blocks at issue while the CU's L1 absorbs the 55 KB (what the phase timers of the weight-gradient kernel showed for this
+// prefetch pattern).  The halo tile keeps its register prefetch: LDS has no room for a second 31 KB tile buffer.
+template <bool WDMA>
 __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParams p, int units_total, int tiles_total,
                                                                  int units_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xb = smem;                   // halo tile (single buffer)
     char* const wb = smem + XBYTES;          // 2 weight slots
+    const unsigned lds_w = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)wb;
+    const int uwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = lane & 31, hk = lane >> 5;
@@ -103,6 +124,14 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParam
         wlds[i] = row * ROWB + ((c2 ^ ((r >> 3) & 1)) << 4);
     }
 
+    // WDMA: LDS piece L = i*NT + tid of a slot is (row = L >> 1, stored half = L & 1) and holds the global half (L & 1) ^ key(row)
+    int wdv[WN];
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+        const int L = i * NT + tid, row = L >> 1, r = row % MB, tl = row / MB;
+        const int c2 = (L & 1) ^ ((r >> 3) & 1);
+        wdv[i] = L < WCHUNKS ? (((r >> 5) * nck16 * 27 + (flip ? 26 - tl : tl)) * 512 + (r & 31) * 16 + c2 * 8) * 2 : (int)0x80000000;
+    }
     // Prefetch registers.  The global loads are UNCONDITIONAL (out-of-range lanes read element 0 of the tensor and
     // are zeroed when the value is written to LDS): a predicated load makes hipcc wrap each one in an exec-mask
     // branch with s_waitcnt vmcnt(0) in front, which serialises the whole prefetch.
@@ -152,6 +181,13 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParam
             wr[i] = *reinterpret_cast<const half8*>(bp + wrel[i] - (r >> 5) * second);
         }
     };
+    // second row block past the panel (Mpad = 32 * odd): its lanes re-read the first block, as load_w does
+    auto dma_w = [&](int m0, int c0, int slot, int i) {
+        const half_t* bp = p.wp + lnn_panel_off(0, m0, c0, 27, p.KCpad);
+        const int second = m0 + 32 < p.Mpad ? 0 : nck16 * 27 * 512 * 2;
+        const int L = i * NT + tid, r = (L >> 1) % MB;
+        v8_dma16(v8_rsrc(bp), lds_w + slot * WSLOT + i * (NT * 16) + uwave * 1024, L < WCHUNKS ? wdv[i] - (r >> 5) * second : wdv[i]);
+    };
     auto store_w = [&](char* buf) {
 #pragma unroll
         for (int i = 0; i < WN; ++i) {
@@ -184,8 +220,14 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParam
     store_x(xb);
     {
         const int s0 = by_chunk ? cur.ch : 0;
-        load_w(cur.m0, cur.c0);
-        store_w(wb + s0 * WBYTES);
+        if (WDMA) {
+#pragma unroll
+            for (int i = 0; i < WN; ++i) dma_w(cur.m0, cur.c0, s0, i);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            load_w(cur.m0, cur.c0);
+            store_w(wb + s0 * WSLOT);
+        }
         if (s0) wtag[1] = cur.m0 * 4096 + cur.c0; else wtag[0] = cur.m0 * 4096 + cur.c0;
     }
     __syncthreads();
@@ -197,7 +239,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParam
         const int ntag = nxt.m0 * 4096 + nxt.c0;
         const bool new_w = nxt.valid && (nslot ? wtag[1] : wtag[0]) != ntag;
         const char* xl = xb;
-        const char* wl = wb + wslot * WBYTES;
+        const char* wl = wb + wslot * WSLOT;
         if (cur.first_chunk) {
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -208,7 +250,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParam
         }
         // ---- issue the next step's global loads (in flight during the 108 MFMAs below) ----
         if (nxt.valid) load_x(nxt);
-        if (new_w) load_w(nxt.m0, nxt.c0);
+        if (new_w && !WDMA) load_w(nxt.m0, nxt.c0);
         half8 fa[3][MT], fb[3][VT];
         auto frag = [&](int tl, half8 (&a)[MT], half8 (&b)[VT]) {     // tl compile-time after unrolling
             const int dz = tl / 9, dy = (tl / 3) % 3, dx = tl % 3;
@@ -225,6 +267,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParam
 #pragma unroll
         for (int g = 0; g < 27; ++g) {
             if (g + 2 < 27) frag(g + 2, fa[(g + 2) % 3], fb[(g + 2) % 3]);
+            if (WDMA && g % 3 == 1 && g / 3 < WN) {
+                if (new_w) dma_w(nxt.m0, nxt.c0, nslot, g / 3);
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep the reads of g+2 above the MFMAs of g
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -235,7 +280,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v8_kernel(const ConvParam
         }
         // ---- weights of the next step go to the OTHER slot now; the single halo buffer after every wave is done ----
         if (new_w) {
-            store_w(wb + nslot * WBYTES);
+            if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else store_w(wb + nslot * WSLOT);
             if (nslot) wtag[1] = ntag; else wtag[0] = ntag;
         }
         __syncthreads();
@@ -290,13 +336,16 @@ int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name) {
     int upb = lnn_cdiv(units, num_cu);     // one resident 8-wave block per CU (139 KB of LDS)
     if (upb < 1) upb = 1;
     const int grid = lnn_cdiv(units, upb);
-    const size_t lds = XBYTES + 2 * WBYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        attr_set = true;
+    const size_t lds = XBYTES + 2 * WSLOT;
+    static int wdma = -1;           // LNN_V8_NO_WDMA=1: register-prefetched weights (round 1; A/B measurements)
+    if (wdma < 0) {
+        const char* e = getenv("LNN_V8_NO_WDMA");
+        wdma = (e && e[0] == '1') ? 0 : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     }
-    hipLaunchKernelGGL(igemm_conv_s1_v8_kernel, dim3(grid), dim3(NT), lds, s, p, (int)units, tiles, upb);
+    if (wdma) hipLaunchKernelGGL((igemm_conv_s1_v8_kernel<true>), dim3(grid), dim3(NT), lds, s, p, (int)units, tiles, upb);
+    else hipLaunchKernelGGL((igemm_conv_s1_v8_kernel<false>), dim3(grid), dim3(NT), lds, s, p, (int)units, tiles, upb);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }

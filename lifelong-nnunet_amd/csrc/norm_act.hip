@@ -177,6 +177,61 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
     for (; v < end; v += step) *reinterpret_cast<half8*>(zp + v * ld_z) = apply(*reinterpret_cast<const half8*>(yp + v * C));
 }
 
+// InstanceNorm + LeakyReLU + the 1x1x1 segmentation head of the SAME activation (decoder blocks that feed a seg head): the head
+// reads the fp16-rounded z this kernel has in registers, so the separate seg pass over z (0.63 GB at the top level) disappears.
+// A voxel's C/8 threads are adjacent lanes (C/8 a power of two <= 64): butterfly over them, lane c8 == 0 writes the K logits.
+constexpr int SEG_KMAX = 8;
+__global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __restrict__ y, half_t* __restrict__ z, int ld_z,
+                                                              long V, int C, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float slope,
+                                                              const float* __restrict__ segw, float* __restrict__ logits, int K) {
+    const RowMap rm = row_map(C);
+    if (!rm.active) return;
+    const int n = blockIdx.y;
+    float sc[8], sh[8], w[SEG_KMAX][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = rm.c8 * 8 + e;
+        sc[e] = gamma[c] * rstd[n * C + c];
+        sh[e] = beta[c] - mean[n * C + c] * sc[e];
+#pragma unroll
+        for (int k = 0; k < SEG_KMAX; ++k) w[k][e] = k < K ? segw[k * C + c] : 0.f;
+    }
+    const half_t* yp = y + (long)n * V * C + rm.c8 * 8;
+    half_t* zp = z + (long)n * V * ld_z + rm.c8 * 8;
+    float* ln = logits + (long)n * K * V;
+    const long end = vrange_end(V, rm), step = rm.VPB;
+    // the block's range is a multiple of VPB, so all C8 lanes of a voxel are in or out together
+    for (long v = vrange_begin(V, rm) + rm.vl; v < end; v += step) {
+        const half8 x = *reinterpret_cast<const half8*>(yp + v * C);
+        half8 o;
+        float pk[SEG_KMAX];
+#pragma unroll
+        for (int k = 0; k < SEG_KMAX; ++k) pk[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = (float)x[e] * sc[e] + sh[e];
+            o[e] = (half_t)(t > 0.f ? t : t * slope);
+            const float zf = (float)o[e];
+#pragma unroll
+            for (int k = 0; k < SEG_KMAX; ++k)
+                if (k < K) pk[k] += zf * w[k][e];
+        }
+        *reinterpret_cast<half8*>(zp + v * ld_z) = o;
+        for (int m = 1; m < rm.C8; m <<= 1) {
+#pragma unroll
+            for (int k = 0; k < SEG_KMAX; ++k)
+                if (k < K) pk[k] += __shfl_xor(pk[k], m, 64);
+        }
+        if (rm.c8 == 0) {
+#pragma unroll
+            for (int k = 0; k < SEG_KMAX; ++k)
+                if (k < K) ln[(long)k * V + v] = pk[k];
+        }
+    }
+}
+
 // pass 1 of backward: s1 = sum g, s2 = sum g*xhat with g = dz * lrelu'(gamma*xhat+beta)
 __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* __restrict__ y, const half_t* __restrict__ dz,
                                                                  int ld_dz, long V, int C, const float* __restrict__ mean,
@@ -371,6 +426,23 @@ extern "C" int lnn_instnorm_lrelu_fwd(lnn_stream_t s_, const void* y, void* z, i
     hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z, ld_z,
                        V, C, mean, rstd, gamma, beta, slope);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_fwd");
+    return LNN_OK;
+}
+
+extern "C" int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s_, const void* y, void* z, int ld_z, int N, long V, int C, const float* mean,
+                                          const float* rstd, const float* gamma, const float* beta, float slope,
+                                          const float* seg_w, float* logits, int K) {
+    hipStream_t s = (hipStream_t)s_;
+    if (int e = check_common(y, N, V, C, "lnn_instnorm_lrelu_seg_fwd")) return e;
+    LNN_REQUIRE(z != nullptr && lnn_aligned16(z) && ld_z >= C && ld_z % 8 == 0, "lnn_instnorm_lrelu_seg_fwd: bad z / ld_z");
+    LNN_REQUIRE(mean && rstd && gamma && beta && seg_w && logits, "lnn_instnorm_lrelu_seg_fwd: null parameter");
+    const int C8 = C >> 3;
+    LNN_REQUIRE(K >= 1 && K <= SEG_KMAX && (C8 & (C8 - 1)) == 0 && C8 <= 64,
+                "lnn_instnorm_lrelu_seg_fwd: K=%d / C=%d unsupported (K <= %d, C/8 a power of two <= 64): use lnn_instnorm_lrelu_fwd + lnn_seg1x1_fwd",
+                K, C, SEG_KMAX);
+    hipLaunchKernelGGL(in_lrelu_seg_fwd_kernel, dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z, ld_z, V, C,
+                       mean, rstd, gamma, beta, slope, seg_w, logits, K);
+    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_fwd");
     return LNN_OK;
 }
 

@@ -113,6 +113,7 @@ class SegHead:
     gx: Act = None
     gx_has_prior: bool = False     # a transposed-conv dgrad already wrote gx -> accumulate
     w: ParamSlot = None
+    x_block: object = None         # the ConvBlock that produces x (its normalisation pass can compute the head as well)
 
 
 @dataclass
@@ -276,11 +277,14 @@ class UNetEngine:
                 b0.x2, b0.gx2 = Act(self.cat[u][1], 0, cs), Act(self.gcat[u][1], 0, cs)
             b1 = new_block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, 1, b0.z, b0.gz, False, None, None, dims[d])
             seg = SegHead(f"seg_outputs.{u}", cs, x=b1.z, gx=b1.gz, gx_has_prior=(u < num_pool - 1))
+            seg.x_block = b1
             seg.w = arena.by_name[f"seg_outputs.{u}.weight"]
             self.segs.append(seg)
             order.append(seg)
             x, gx, cdown = b1.z, b1.gz, cs
         self.order = order
+        # decoder blocks whose output feeds a seg head directly (the head follows its block in execution order)
+        self._seg_after = {id(seg.x_block): seg for seg in self.segs}
 
         self.theta, self.grad = arena.theta, arena.grad
 
@@ -347,6 +351,7 @@ class UNetEngine:
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
         # (weight decay, momentum) exactly as torch does with a ~0 gradient.
+        self.fuse_seg_fwd = os.environ.get("LNN_NO_FUSED_SEG", "0") != "1"           # A/B switch (measurements only)
         self.numeric_conv_bias_grad = os.environ.get("LNN_NUMERIC_CONV_BIAS_GRAD", "0") == "1"
         self.fuse_in_stats = os.environ.get("LNN_NO_FUSED_IN_STATS", "0") != "1"     # A/B switch (measurements only)
         # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
@@ -439,6 +444,7 @@ class UNetEngine:
 
         def lane(n0, nn, ws):
             u = 0
+            fused_segs = set()
             for item in self.order:
                 if isinstance(item, ConvBlock):
                     if not body:
@@ -462,8 +468,16 @@ class UNetEngine:
                             nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
                                      nn, D, H, W, item.cin, C, item.stride)
                         nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
-                    nat.call("lnn_instnorm_lrelu_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
-                             self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE)
+                    seg = self._seg_after.get(id(item))
+                    if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
+                        # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y
+                        nat.call("lnn_instnorm_lrelu_seg_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
+                                 self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, self.pview(seg.w),
+                                 logits[self.segs.index(seg)][n0:], self.K)
+                        fused_segs.add(id(seg))
+                    else:
+                        nat.call("lnn_instnorm_lrelu_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
+                                 self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE)
                 elif isinstance(item, UpBlock):
                     if not body:
                         continue
@@ -471,8 +485,9 @@ class UNetEngine:
                     nat.call("lnn_convT3d_k2s2_fwd", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
                              item.y.ld, nn, D, H, W, item.cin, item.cout)
                 else:
-                    w = self.pview(item.w) if sw is None else sw[u]
-                    nat.call("lnn_seg1x1_fwd", at(item.x, n0), item.x.ld, w, logits[u][n0:], nn, item.x.V, item.cin, self.K)
+                    if id(item) not in fused_segs:
+                        w = self.pview(item.w) if sw is None else sw[u]
+                        nat.call("lnn_seg1x1_fwd", at(item.x, n0), item.x.ld, w, logits[u][n0:], nn, item.x.V, item.cin, self.K)
                     u += 1
 
         self._fork(lane)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "lnn_wgrad_panel_elems": (_sz, [_i, _i, _i]),
     "lnn_instnorm_stats": (_i, [_p, _p, _i, _l, _i, _f, _p, _p, _p]),
     "lnn_instnorm_lrelu_fwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f]),
+    "lnn_instnorm_lrelu_seg_fwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _i]),
     "lnn_instnorm_lrelu_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _p, _f, _p]),
     "lnn_instnorm_ws_doubles": (_sz, [_i, _i]),
     "lnn_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),
