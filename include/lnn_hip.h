@@ -77,6 +77,13 @@ int lnn_conv3d_fwd(lnn_stream_t s, const void* x_h, int ld_x, const void* wp_fwd
                    void* y_h, int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride);
 int lnn_conv3d_dgrad(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp_dgrad_h, void* dx_h, int ld_dx,
                      int N, int Di, int Hi, int Wi, int C, int K, int stride, int accumulate);
+/* Split-K workspace (optional, both may be NULL / 0): small deep layers -- fewer (8x8x8 tile x 32 channel) units than resident
+ * blocks and 20..40 serial 16-channel chunk steps per unit -- are latency-bound; with splitk_ws (fp32 scratch, contents don't
+ * matter; k * N*Do*Ho*Wo*roundup32(out channels) elements allow a k-way split, k <= 8) the chunk loop of a unit is split over
+ * k blocks that write fp32 partial sums to their own slice, a finalize launch adds the slices in a fixed order (deterministic)
+ * and converts.  lnn_conv3d_fwd_in_stats takes the same pair.  Larger layers ignore it. */
+int lnn_conv3d_dgrad_ws(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int Di, int Hi, int Wi,
+                        int C, int K, int stride, int accumulate, float* splitk_ws, long splitk_elems);
 int lnn_conv3d_wgrad(lnn_stream_t s, const void* x_h, int ld_x, const void* dy_h, int ld_dy, float* dwp,
                      int N, int Di, int Hi, int Wi, int C, int K, int stride);
 /* The same three ops (stride 1) on the CHANNEL CONCATENATION of two tensors that is never materialised
@@ -96,7 +103,8 @@ int lnn_conv3d_fwd_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int
  * ws >= lnn_instnorm_ws_doubles(N, K). */
 int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
                             const float* bias, void* y, int N, int Di, int Hi, int Wi, int C, int K, int stride,
-                            float eps, float* mean, float* rstd, double* ws);
+                            float eps, float* mean, float* rstd, double* ws, float* splitk_ws,
+                            long splitk_elems);
 int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp_dgrad_h, void* dx_a_h, void* dx_b_h,
                          int ld_dx, int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate);
 int lnn_conv3d_wgrad_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int ld_x, int c_a, const void* dy_h, int ld_dy,

@@ -28,6 +28,8 @@ struct ConvParams {
     int accumulate;
     float* stats_pws = nullptr;   // v9 only: fused InstanceNorm statistics partials [2][stats_nblk][N][M] (see igemm_conv_v9.hip)
     int stats_nblk = 0;
+    int ksplit = 1;               // v7 only: the 16-channel chunk loop of a unit is split over ksplit blocks which write fp32 partial
+    float* scratch = nullptr;     //   sums to scratch[part][voxel][Mpad]; lnn_launch_splitk_finalize adds the slices and converts
     unsigned long long* dbg;   // optional phase-cycle accumulators (LNN_DEBUG_PHASES), null in production
     TapTable taps;
 };
@@ -50,6 +52,7 @@ int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name);
 bool lnn_conv_s1_v9_supported(const ConvParams& p);
 int lnn_conv_s1_v9_stats_slots(const ConvParams& p);
 // norm_act.hip: mean / rstd from per-slot partial sums pws[a][slot][n*C + c] (the finalize half of lnn_instnorm_stats)
+int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name);
 int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd);
 int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name);
 // single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,

@@ -402,6 +402,30 @@ bool use_v8(const ConvParams& p) {
     return units >= 512;
 }
 
+// Split-K for the small deep layers (v7 path): the 8x8x8-tile x 32-channel units do not fill the chip (level 5 of C2: 20 units
+// for 512 resident blocks) and each walks C/16 = 20..40 chunk steps serially -- 60..240 us of latency per launch, 14 launches
+// per step.  With a caller-provided fp32 workspace the chunk loop is split over up to 8 blocks per unit.
+int pick_ksplit(const ConvParams& p, const float* ws, long ws_elems) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("LNN_NO_SPLITK"); off = (e && e[0] == '1') ? 1 : 0; }
+    if (off || !ws) return 1;
+    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+    const long units = (long)p.N * lnn_cdiv(p.Ld, 8) * lnn_cdiv(p.Lh, 8) * lnn_cdiv(p.Lw, 8) * lnn_cdiv(p.M, 32);
+    const int nchunks = (p.C + 15) / 16;
+    int best = 1;
+    for (int ks = 2; ks <= 8; ks *= 2)
+        if (nchunks % ks == 0 && nchunks / ks >= 2 && units * ks <= 1024 && ws_elems >= (long)ks * nvox * p.Mpad) best = ks;
+    return units < 512 ? best : 1;
+}
+int launch_v7_maybe_splitk(hipStream_t s, ConvParams& p, float* ws, long ws_elems, const char* name) {
+    const int ks = pick_ksplit(p, ws, ws_elems);
+    if (ks == 1) return lnn_launch_conv_s1_v7(s, p, name);
+    p.ksplit = ks;
+    p.scratch = ws;
+    if (int e = lnn_launch_conv_s1_v7(s, p, name)) return e;
+    return lnn_launch_splitk_finalize(s, p, name);
+}
+
 int check_act(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -421,7 +445,7 @@ extern "C" int lnn_debug_force_conv_kernel(int which) {
 namespace {
 int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int ld_x, const void* wp, const float* bias, void* y,
                     int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride, float* stats_pws = nullptr,
-                    int* stats_slots = nullptr) {
+                    int* stats_slots = nullptr, float* splitk_ws = nullptr, long splitk_elems = 0) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_fwd: stride %d unsupported", stride);
     LNN_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0, "lnn_conv3d_fwd: bad dims");
@@ -463,7 +487,7 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         }
         if (use_v2() && use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9)");
         if (use_v2() && use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_fwd(s1,v8)");
-        if (use_v2() && use_v7(p.C)) return lnn_launch_conv_s1_v7(s, p, "lnn_conv3d_fwd(s1,v7)");
+        if (use_v2() && use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,v7)");
         if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
@@ -503,7 +527,7 @@ extern "C" int lnn_conv3d_fwd_cat(lnn_stream_t s, const void* x_a, const void* x
 
 extern "C" int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
                                        const float* bias, void* y, int N, int Di, int Hi, int Wi, int C, int K, int stride,
-                                       float eps, float* mean, float* rstd, double* ws) {
+                                       float eps, float* mean, float* rstd, double* ws, float* splitk_ws, long splitk_elems) {
     LNN_REQUIRE(mean && rstd && ws, "lnn_conv3d_fwd_in_stats: null output/workspace");
     if (x_b) {
         if (int e = check_cat(x_b, c_a, C, stride, "lnn_conv3d_fwd_in_stats")) return e;
@@ -512,14 +536,16 @@ extern "C" int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const vo
     const long V = (long)((Di - 1) / stride + 1) * ((Hi - 1) / stride + 1) * ((Wi - 1) / stride + 1);
     float* pws = reinterpret_cast<float*>(ws + (size_t)N * K * 3);          // same region lnn_instnorm_stats uses
     int slots = 0;
-    if (int e = conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, K, N, Di, Hi, Wi, C, K, stride, pws, &slots)) return e;
+    if (int e = conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, K, N, Di, Hi, Wi, C, K, stride, pws, &slots, splitk_ws, splitk_elems))
+        return e;
     if (slots > 0) return lnn_launch_in_stats_finalize((hipStream_t)s, pws, slots, N, K, V, eps, mean, rstd);
     return lnn_instnorm_stats(s, y, N, V, K, eps, mean, rstd, ws);          // kernel without the fused epilogue: separate pass
 }
 
 namespace {
 int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, void* dx2, int c_a, int ld_dx, int N,
-                      int Di, int Hi, int Wi, int C, int K, int stride, int accumulate) {
+                      int Di, int Hi, int Wi, int C, int K, int stride, int accumulate, float* splitk_ws = nullptr,
+                      long splitk_elems = 0) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_dgrad: stride %d unsupported", stride);
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_conv3d_dgrad: weight panel null/misaligned");
@@ -546,7 +572,7 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
         p.dbg = g_dbg;
         if (use_v2() && use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad(s1,v9)");
         if (use_v2() && use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_dgrad(s1,v8)");
-        if (use_v2() && use_v7(p.C)) return lnn_launch_conv_s1_v7(s, p, "lnn_conv3d_dgrad(s1,v7)");
+        if (use_v2() && use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_dgrad(s1,v7)");
         if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
     }
@@ -582,6 +608,11 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
 extern "C" int lnn_conv3d_dgrad(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N,
                                 int Di, int Hi, int Wi, int C, int K, int stride, int accumulate) {
     return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, stride, accumulate);
+}
+
+extern "C" int lnn_conv3d_dgrad_ws(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int Di, int Hi,
+                                   int Wi, int C, int K, int stride, int accumulate, float* splitk_ws, long splitk_elems) {
+    return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, stride, accumulate, splitk_ws, splitk_elems);
 }
 
 extern "C" int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx_a, void* dx_b, int ld_dx,

@@ -38,7 +38,7 @@ __device__ __forceinline__ void lane_voxel(int v, int& r, int& x) {
 }
 
 struct Step {   // (work unit, 16-channel chunk)
-    int n, lz0, ly0, lx0, m0, c0, ch;
+    int n, lz0, ly0, lx0, m0, c0, ch, part;
     bool valid, first_chunk, last_chunk, interior;
 };
 
@@ -55,19 +55,26 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
     if (u_begin >= u_end) return;
     const int nchunks = (p.C + CK - 1) / CK;
     const bool flip = p.taps.slot[0] != 0;   // dgrad: tap offset d' uses weight slot 26 - d'
-    const int nq = (u_end - u_begin) * nchunks;
+    // split-K (small layers: fewer units than resident blocks, a long serial chunk loop per unit): unit index u' = u * ksplit +
+    // part, part owns nsteps = nchunks / ksplit consecutive chunks and writes its partial sums into ITS slice of the fp32
+    // scratch tensor [ksplit][voxel][Mpad] (plain 16-byte stores: float atomics from 8 XCDs onto one tensor measured slower
+    // than no split at all); lnn_launch_splitk_finalize adds the slices in a fixed order
+    const int ks = p.ksplit, nsteps = nchunks / ks;
+    const int nq = (u_end - u_begin) * nsteps;
 
     // units are ordered output-channel-block major, tile minor: a block's consecutive units share their weights
     auto decode = [&](int q) {
         Step r;
         r.valid = q < nq;
-        const int u = u_begin + q / nchunks;
-        r.ch = q % nchunks;
+        const int up = u_begin + q / nsteps, st = q % nsteps;
+        const int u = up / ks;
+        r.part = up % ks;
+        r.ch = r.part * nsteps + st;
         int t = u % tiles_total;
         r.m0 = (u / tiles_total) * MB;
         r.c0 = r.ch * CK;
-        r.first_chunk = r.ch == 0;
-        r.last_chunk = r.ch == nchunks - 1;
+        r.first_chunk = st == 0;
+        r.last_chunk = st == nsteps - 1;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int tz = t % p.tiles_z; t /= p.tiles_z;
@@ -211,7 +218,19 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
             for (int vt = 0; vt < VT; ++vt) {
                 const int lz = cur.lz0 + wave, ly = cur.ly0 + vt * 4 + vr, lx = cur.lx0 + vx;
                 if (lz >= p.Ld || ly >= p.Lh || lx >= p.Lw) continue;
-                const long yoff = ((((long)cur.n * p.Do + lz) * p.Ho + ly) * p.Wo + lx) * p.ld_y;
+                const long vox = (((long)cur.n * p.Do + lz) * p.Ho + ly) * p.Wo + lx;
+                if (ks > 1) {
+                    float* srow = p.scratch + ((long)cur.part * ((long)p.N * p.Do * p.Ho * p.Wo) + vox) * p.Mpad;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int m = cur.m0 + qq * 8 + hk * 4;
+                        if (m >= p.Mpad) continue;
+                        const floatx4 w4 = {acc[vt][qq * 4 + 0], acc[vt][qq * 4 + 1], acc[vt][qq * 4 + 2], acc[vt][qq * 4 + 3]};
+                        *reinterpret_cast<floatx4*>(srow + m) = w4;
+                    }
+                    continue;
+                }
+                const long yoff = vox * p.ld_y;
                 half_t* yrow = p.y + yoff;
                 half_t* yrow2 = p.y2 + yoff - p.msplit;      // output channels >= msplit go to the second tensor
 #pragma unroll
@@ -236,13 +255,47 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
     }
 }
 
+// scratch (fp32, [ksplit][voxel][Mpad]) -> y (fp16, slices added in order, + bias, + old value when accumulating)
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvParams p, long nvox) {
+    const int q4 = p.Mpad >> 2;
+    const long total = nvox * q4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long vox = i / q4;
+        const int m = (int)(i % q4) * 4;
+        if (m >= p.M) continue;
+        floatx4 r = *reinterpret_cast<const floatx4*>(p.scratch + vox * p.Mpad + m);
+        for (int k = 1; k < p.ksplit; ++k) r += *reinterpret_cast<const floatx4*>(p.scratch + ((long)k * nvox + vox) * p.Mpad + m);
+        if (p.bias) {
+            const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + m);
+            r += bv;
+        }
+        half_t* yrow = (m < p.msplit ? p.y : p.y2 - p.msplit) + vox * p.ld_y;
+        half4* dst = reinterpret_cast<half4*>(yrow + m);
+        if (p.accumulate) {
+            const half4 old = *dst;
+            r[0] += (float)old[0]; r[1] += (float)old[1]; r[2] += (float)old[2]; r[3] += (float)old[3];
+        }
+        const half4 o = {(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
+        *dst = o;
+    }
+}
+
 }  // namespace
+
+int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name) {
+    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+    const long total = nvox * (p.Mpad >> 2);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, s, p, nvox);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
 
 int lnn_launch_conv_s1_v7(hipStream_t s, ConvParams& p, const char* name) {
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
     const int mblocks = lnn_cdiv(p.M, MB);
     const int tiles = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
-    const long units = (long)tiles * mblocks;
+    const long units = (long)tiles * mblocks * p.ksplit;
     static int num_cu = 0;
     if (!num_cu) {
         int dev = 0;

@@ -343,6 +343,19 @@ class UNetEngine:
         cmax = max(2 * f for f in feats)
         ws_doubles = max(nat.query("lnn_instnorm_ws_doubles", N, cmax), (nat.query("lnn_seg1x1_bwd_ws_floats", N, cmax) + 1) // 2, 64)
         self.ws = torch.zeros(ws_doubles, dtype=torch.float64, device=dev)
+        # fp32 split-K scratch of the small deep layers (see lnn_conv3d_dgrad_ws): 8 slices of the largest
+        # [N][voxels][roundup32(channels)] among the stride-1 layers with fewer than 512 (8x8x8 x 32-channel) units
+        need = 1
+        for blk in self.blocks:
+            if blk.stride != 1 or blk.cin == 1:
+                continue
+            od = blk.in_dims
+            vox = N * od[0] * od[1] * od[2]
+            tiles = N * -(-od[0] // 8) * -(-od[1] // 8) * -(-od[2] // 8)
+            for ch in (blk.cout, blk.cin):
+                if tiles * -(-ch // 32) < 512:
+                    need = max(need, 8 * vox * (-(-ch // 32) * 32))
+        self.splitk_ws = torch.zeros(need, dtype=torch.float32, device=dev)
         self.packed_version = -1
         self.unused_heads: List[str] = []
         self._side = None
@@ -459,7 +472,8 @@ class UNetEngine:
                         # conv + InstanceNorm statistics in one call (the z-streaming kernel sums in its epilogue)
                         nat.call("lnn_conv3d_fwd_in_stats", xin, None if item.x2 is None else at(item.x2, n0), ldx,
                                  item.x.C if item.x2 is not None else 0, self._wp(item.wp_fwd), self.pview(item.b),
-                                 at(item.y, n0), nn, D, H, W, item.cin, C, item.stride, IN_EPS, mean, rstd, ws)
+                                 at(item.y, n0), nn, D, H, W, item.cin, C, item.stride, IN_EPS, mean, rstd, ws,
+                                 self.splitk_ws, self.splitk_ws.numel())
                     else:
                         if item.x2 is not None:
                             nat.call("lnn_conv3d_fwd_cat", xin, at(item.x2, n0), ldx, item.x.C, self._wp(item.wp_fwd),
@@ -598,8 +612,9 @@ class UNetEngine:
                         nat.call("lnn_conv3d_dgrad_cat", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0),
                                  at(item.gx2, n0), item.gx.ld, item.gx.C, nn, D, H, W, C, K, 1 if item.gx_accumulate else 0)
                     elif C != 1 and item.gx is not None:
-                        nat.call("lnn_conv3d_dgrad", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
-                                 nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0)
+                        nat.call("lnn_conv3d_dgrad_ws", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
+                                 nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0, self.splitk_ws,
+                                 self.splitk_ws.numel())
                 else:  # UpBlock
                     D, H, W = item.x.dims
                     C, K = item.cin, item.cout

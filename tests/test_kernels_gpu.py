@@ -419,9 +419,9 @@ def test_conv3d_fwd_in_stats(N, C, K, D, H, W, cat):
     nat.call("lnn_instnorm_stats", y1, N, V, K, 1e-5, m1, r1, ws)
     if cat:
         xa = xb[..., :C // 2].contiguous(); xc = xb[..., C // 2:].contiguous()
-        nat.call("lnn_conv3d_fwd_in_stats", xa, xc, C // 2, C // 2, wp, b, y2, N, D, H, W, C, K, 1, 1e-5, m2, r2, ws)
+        nat.call("lnn_conv3d_fwd_in_stats", xa, xc, C // 2, C // 2, wp, b, y2, N, D, H, W, C, K, 1, 1e-5, m2, r2, ws, None, 0)
     else:
-        nat.call("lnn_conv3d_fwd_in_stats", xb, None, C, 0, wp, b, y2, N, D, H, W, C, K, 1, 1e-5, m2, r2, ws)
+        nat.call("lnn_conv3d_fwd_in_stats", xb, None, C, 0, wp, b, y2, N, D, H, W, C, K, 1, 1e-5, m2, r2, ws, None, 0)
     assert torch.equal(y1, y2)
     yf = y1.float().reshape(N, V, K)
     mean = yf.mean(1).reshape(-1); var = yf.var(1, unbiased=False).reshape(-1)
@@ -493,3 +493,44 @@ def test_conv3d_cat_ops_match_concatenated_tensor(N, Ca, Cb, K, D, H, W):
     nat.call("lnn_conv3d_wgrad", xb, C, dyb, K, p1, N, D, H, W, C, K, 1)
     nat.call("lnn_conv3d_wgrad_cat", xa, xc, ld, Ca, dyb, K, p2, N, D, H, W, C, K)
     assert float((p1 - p2).abs().max()) <= 1e-5 * float(p1.abs().max())      # fp32 atomics: order differs between launches
+
+
+@pytest.mark.parametrize("C,K,D,H,W", [(256, 256, 8, 12, 8), (320, 320, 5, 6, 5), (640, 320, 5, 6, 5), (128, 256, 16, 8, 8)])
+def test_conv_splitk_small_layers(C, K, D, H, W):
+    """Split-K path of the small deep layers (lnn_conv3d_fwd_in_stats / lnn_conv3d_dgrad_ws with an fp32 workspace): same
+    result as the plain launch up to the fp32 summation order (one fp16 ulp), scratch contents irrelevant, accumulate honoured,
+    and the split result is bit-reproducible (slices are added in a fixed order)."""
+    torch.manual_seed(C + K + D)
+    N = 2
+    x = (torch.randn(N, D, H, W, C, device=DEV) * 0.5).half()
+    w = torch.randn(K, C, 3, 3, 3, device=DEV) * (2.0 / (27 * C)) ** 0.5
+    b = torch.randn(K, device=DEV) * 0.1
+    wp = torch.empty(nat.query("lnn_packed_weight_elems", 27, K, C), dtype=torch.float16, device=DEV)
+    nat.call("lnn_pack_weights", w, wp, 27, K, C, C * 27, 27, 1)
+    wd = torch.empty(nat.query("lnn_packed_weight_elems", 27, C, K), dtype=torch.float16, device=DEV)
+    nat.call("lnn_pack_weights", w, wd, 27, C, K, 27, C * 27, 1)
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    sk = torch.full((8 * N * D * H * W * max((C + 31) // 32, (K + 31) // 32) * 32,), float('nan'), device=DEV)   # contents must not matter
+    y0, y1 = torch.empty(N, D, H, W, K, dtype=torch.float16, device=DEV), torch.empty(N, D, H, W, K, dtype=torch.float16, device=DEV)
+    m0, r0, m1, r1 = (torch.empty(N * K, device=DEV) for _ in range(4))
+    nat.call("lnn_conv3d_fwd_in_stats", x, None, C, 0, wp, b, y0, N, D, H, W, C, K, 1, 1e-5, m0, r0, ws, None, 0)
+    nat.call("lnn_conv3d_fwd_in_stats", x, None, C, 0, wp, b, y1, N, D, H, W, C, K, 1, 1e-5, m1, r1, ws, sk, sk.numel())
+    torch.cuda.synchronize()
+    scale = float(y0.float().abs().max())
+    assert float((y0.float() - y1.float()).abs().max()) <= 2e-3 * scale
+    assert torch.allclose(m0, m1, atol=1e-3 * scale) and torch.allclose(r0, r1, rtol=2e-3)
+    y2 = torch.empty_like(y1)
+    nat.call("lnn_conv3d_fwd_in_stats", x, None, C, 0, wp, b, y2, N, D, H, W, C, K, 1, 1e-5, m1, r1, ws, sk, sk.numel())
+    assert torch.equal(y1, y2)
+    # against the CPU reference of the op
+    ref = torch.nn.functional.conv3d(x.float().cpu().permute(0, 4, 1, 2, 3), w.half().float().cpu(), b.cpu(), padding=1).permute(0, 2, 3, 4, 1)
+    assert float((y1.float().cpu() - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+    # data gradient with accumulation into an existing tensor
+    dy = (torch.randn(N, D, H, W, K, device=DEV) * 0.5).half()
+    base = (torch.randn(N, D, H, W, C, device=DEV) * 0.5).half()
+    g0, g1 = base.clone(), base.clone()
+    nat.call("lnn_conv3d_dgrad", dy, K, wd, g0, C, N, D, H, W, C, K, 1, 1)
+    nat.call("lnn_conv3d_dgrad_ws", dy, K, wd, g1, C, N, D, H, W, C, K, 1, 1, sk, sk.numel())
+    torch.cuda.synchronize()
+    gs = float(g0.float().abs().max())
+    assert float((g0.float() - g1.float()).abs().max()) <= 2e-3 * gs
