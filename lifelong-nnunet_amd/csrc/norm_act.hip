@@ -203,8 +203,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __re
     float* ln = logits + (long)n * K * V;
     const long end = vrange_end(V, rm), step = rm.VPB;
     // the block's range is a multiple of VPB, so all C8 lanes of a voxel are in or out together
-    for (long v = vrange_begin(V, rm) + rm.vl; v < end; v += step) {
-        const half8 x = *reinterpret_cast<const half8*>(yp + v * C);
+    auto one = [&](const half8& x, long v) {
         half8 o;
         float pk[SEG_KMAX];
 #pragma unroll
@@ -229,7 +228,16 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __re
             for (int k = 0; k < SEG_KMAX; ++k)
                 if (k < K) ln[(long)k * V + v] = pk[k];
         }
+    };
+    long v = vrange_begin(V, rm) + rm.vl;
+    for (; v + (UNR - 1) * step < end; v += UNR * step) {      // UNR loads in flight per thread, as the plain forward pass
+        half8 x[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) one(x[u], v + u * step);
     }
+    for (; v < end; v += step) one(*reinterpret_cast<const half8*>(yp + v * C), v);
 }
 
 // pass 1 of backward: s1 = sum g, s2 = sum g*xhat with g = dz * lrelu'(gamma*xhat+beta)
