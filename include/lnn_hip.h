@@ -124,6 +124,18 @@ int lnn_convT3d_k2s2_dgrad(lnn_stream_t s, const void* dy_h, int ld_dy, const vo
 int lnn_convT3d_k2s2_wgrad(lnn_stream_t s, const void* x_h, int ld_x, const void* dy_h, int ld_dy, float* dwp,
                            int N, int D, int H, int W, int C, int K);
 
+/* Deterministic weight gradients: the same kernels, but every writer of a block stores its partial sums into its own copy of
+ * the panel inside `parts` (fp32 scratch, contents irrelevant) and an ordered reduction adds the copies to dwp -- no atomics,
+ * bit-reproducible run to run (the default path finishes with coalesced fp32 atomics: order-dependent in the last bits).
+ * parts_elems >= blocks.x * writers * panel elements (<= 64 M floats for every layer of the BASELINE configs); a scratch that is
+ * too small is an error (LNN_ERR_BAD_ARG), not a silent fallback. */
+int lnn_conv3d_wgrad_det(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int Di, int Hi, int Wi,
+                         int C, int K, int stride, float* parts, long parts_elems);
+int lnn_conv3d_wgrad_cat_det(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* dy, int ld_dy, float* dwp,
+                             int N, int Di, int Hi, int Wi, int C, int K, float* parts, long parts_elems);
+int lnn_convT3d_k2s2_wgrad_det(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int D, int H,
+                               int W, int C, int K, float* parts, long parts_elems);
+
 /* dst[m*stride_m + kc*stride_kc + t*stride_t] (+)= scale * dwp[t][m][kc]  (panel rows padded to 32/32) */
 int lnn_unpack_wgrad(lnn_stream_t s, const float* dwp, float* dst, int ntaps, int M, int KC,
                      long stride_m, long stride_kc, long stride_t, float scale, int accumulate);

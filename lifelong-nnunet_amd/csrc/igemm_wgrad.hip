@@ -33,6 +33,11 @@ struct WgradParams {
     int M, C, Mpad, Cpad;
     int tiles_z, tiles_y, tiles_x, tiles_total, tiles_per_block;
     int pad_lo;
+    // deterministic mode (lnn_*_wgrad_det): every writer of a block stores its partial sums to its own copy of the panel,
+    // parts[(blockIdx.x * part_writers + writer) * part_stride + panel index]; wg_reduce_parts adds the copies in order
+    float* parts = nullptr;
+    long parts_elems = 0, part_stride = 0;
+    int part_writers = 1;
     int debug = 0;                    // LNN_WGRAD_DEBUG (measurements only): 1 = skip the epilogue atomics, 4 = phase timers
     unsigned long long* dbgbuf = nullptr;   // LNN_WGRAD_PHASEBUF: 6 x u64 {issue, mfma, barrier1, store, barrier2, tiles}
     WTapTable taps;
@@ -47,6 +52,22 @@ __device__ __forceinline__ half4 lds_tr16(const char* addr) {
     half4 o;
     __builtin_memcpy(&o, &r, 8);
     return o;
+}
+
+// panel accumulation: coalesced fp32 atomics (default) or, in deterministic mode, a plain store into this writer's panel copy
+__device__ __forceinline__ void wg_out(const WgradParams& p, int writer, long idx, float v) {
+    if (p.parts) p.parts[((long)blockIdx.x * p.part_writers + writer) * p.part_stride + idx] = v;
+    else atomicAdd(p.dwp + idx, v);
+}
+
+__global__ __launch_bounds__(256) void wg_reduce_parts_kernel(const float* __restrict__ parts, int nslots, long slot_elems,
+                                                              float* __restrict__ panel) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < slot_elems; i += (long)gridDim.x * 256 * 4) {
+        floatx4 a = *reinterpret_cast<const floatx4*>(parts + i);
+        for (int k = 1; k < nslots; ++k) a += *reinterpret_cast<const floatx4*>(parts + (long)k * slot_elems + i);
+        floatx4* o = reinterpret_cast<floatx4*>(panel + i);
+        *o = *o + a;
+    }
 }
 
 template <int IS, int EXT, int TZ, int TY, int TPW>
@@ -415,11 +436,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
     for (int ti = 0; ti < TPW; ++ti) {
         const int tap = tap_of(ti);
         if (tap < 27) {
-            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
+            const long pbase_ = (long)tap * p.Mpad * p.Cpad;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
+                wg_out(p, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
             }
         }
     }
@@ -585,14 +606,14 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_s2_v2_kernel(const WgradPa
     for (int ti = 0; ti < TPW; ++ti) {
         const int tap = wave + 8 * ti;
         if (tap < NTAP) {
-            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
+            const long pbase_ = (long)tap * p.Mpad * p.Cpad;
 #pragma unroll
             for (int mp = 0; mp < MP; ++mp) {
                 if (m0 + mp * 32 >= p.Mpad) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + mp * 32 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                    atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][mp][r]);
+                    wg_out(p, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][mp][r]);
                 }
             }
         }
@@ -682,13 +703,31 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
         }
     }
-    if (tapn < 27) {
+    if (tapn < 27 || p.parts) {           // deterministic mode: the 5 pad columns of every panel copy are written too (zeros)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-            atomicAdd(p.dwp + (long)m * 32 + tapn, acc[r]);
+            wg_out(p, wave, (long)m * 32 + tapn, tapn < 27 ? acc[r] : 0.f);
         }
     }
+}
+
+// deterministic mode: size check + the ordered reduction of the panel copies into the panel
+int wg_prepare_parts(WgradParams& p, unsigned gridx, int writers, long slot_elems, const char* name) {
+    if (!p.parts) return LNN_OK;
+    LNN_REQUIRE((long)gridx * writers * slot_elems <= p.parts_elems,
+                "%s: deterministic scratch too small (%ld floats needed, %ld given)", name, (long)gridx * writers * slot_elems, p.parts_elems);
+    p.part_stride = slot_elems;
+    p.part_writers = writers;
+    return LNN_OK;
+}
+int wg_reduce_parts(hipStream_t s, const WgradParams& p, unsigned gridx, long slot_elems, const char* name) {
+    if (!p.parts) return LNN_OK;
+    const long v4 = slot_elems / 4;
+    const int blocks = (int)((v4 + 255) / 256 < 2048 ? (v4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wg_reduce_parts_kernel, dim3(blocks), dim3(256), 0, s, p.parts, (int)(gridx * p.part_writers), slot_elems, p.dwp);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
 }
 
 template <int IS, int EXT, int TZ, int TY, int TPW>
@@ -711,6 +750,7 @@ int launch_wgrad(hipStream_t s, WgradParams& p, const char* name) {
         attr_set = true;
     }
     dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    LNN_REQUIRE(!p.parts, "%s: the generic first-version kernel has no deterministic mode", name);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
@@ -910,11 +950,11 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v4_kernel(const WgradPa
     for (int ti = 0; ti < TPW; ++ti) {
         const int tap = tap_of(ti);
         if (tap < 27) {
-            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
+            const long pbase_ = (long)tap * p.Mpad * p.Cpad;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
+                wg_out(p, hf, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
             }
         }
     }
@@ -1161,11 +1201,11 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
     for (int ti = 0; ti < TPW; ++ti) {
         const int tap = tap_of(ti);
         if (tap < 27) {
-            float* panel = p.dwp + (long)tap * p.Mpad * p.Cpad;
+            const long pbase_ = (long)tap * p.Mpad * p.Cpad;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
+                wg_out(p, hf, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
             }
         }
     }
@@ -1208,17 +1248,19 @@ int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    const long slot_elems = 27L * p.Mpad * p.Cpad;
+    if (int e = wg_prepare_parts(p, grid.x, 2, slot_elems, "lnn_conv3d_wgrad(s1)")) return e;       // writers: the two tile halves
     if (ring) {
         if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<1>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
         else hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<2>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
         LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v5)");
-        return LNN_OK;
+        return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(s1,v5,reduce)");
     }
     if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<1>), grid, dim3(512), lds, s, p);
     else if (step == 2) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<2>), grid, dim3(512), lds, s, p);
     else hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<3>), grid, dim3(512), lds, s, p);
     LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v4)");
-    return LNN_OK;
+    return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(s1,v4,reduce)");
 }
 
 int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
@@ -1249,10 +1291,12 @@ int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
     dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
     // operand sharing pays where the launch is LDS-bound (deeper layers: +5..10 %); the two level-0 shapes with 1-2 panels are
     // bound by the halo traffic (PMC: 2.5x algorithmic at 3.3 TB/s) and lose 4-8 % to the extra VALU work
+    const long slot_elems = 27L * p.Mpad * p.Cpad;
+    if (int e = wg_prepare_parts(p, grid.x, 1, slot_elems, "lnn_conv3d_wgrad(s1,v2)")) return e;
     if (share && panels >= 4) hipLaunchKernelGGL((igemm_wgrad_s1_v2_kernel<true>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((igemm_wgrad_s1_v2_kernel<false>), grid, dim3(256), lds, s, p);
     LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v2)");
-    return LNN_OK;
+    return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(s1,v2,reduce)");
 }
 
 template <int EXT>
@@ -1275,9 +1319,11 @@ int launch_wgrad_s2_v2(hipStream_t s, WgradParams& p, const char* name) {
         attr_set = true;
     }
     dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    const long slot_elems = (long)(EXT * EXT * EXT) * p.Mpad * p.Cpad;
+    if (int e = wg_prepare_parts(p, grid.x, 1, slot_elems, name)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
     LNN_CHECK_LAUNCH(name);
-    return LNN_OK;
+    return wg_reduce_parts(s, p, grid.x, slot_elems, name);
 }
 
 // LNN_WGRAD_S2_V1=1 selects the generic kernel for the stride-2 / transposed-conv weight gradients (A/B measurements)
@@ -1323,13 +1369,14 @@ extern "C" size_t lnn_wgrad_panel_elems(int ntaps, int M, int KC) {
 
 namespace {
 int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int ld_x, const void* dy, int ld_dy, float* dwp, int N,
-                      int Di, int Hi, int Wi, int C, int K, int stride) {
+                      int Di, int Hi, int Wi, int C, int K, int stride, float* parts = nullptr, long parts_elems = 0) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_wgrad: stride %d unsupported", stride);
     LNN_REQUIRE(dwp != nullptr, "lnn_conv3d_wgrad: null panel");
     if (int e = check_act_w(dy, ld_dy, K, "lnn_conv3d_wgrad(dy)")) return e;
     WgradParams p{};
     p.p = (const half_t*)dy; p.q = (const half_t*)x; p.dwp = dwp; p.ld_p = ld_dy; p.ld_q = ld_x;
+    p.parts = parts; p.parts_elems = parts_elems;
     if (x2) { p.q2 = (const half_t*)x2; p.csplit = c_a; }
     p.N = N; p.Qd = Di; p.Qh = Hi; p.Qw = Wi;
     p.Ld = (Di - 1) / stride + 1; p.Lh = (Hi - 1) / stride + 1; p.Lw = (Wi - 1) / stride + 1;
@@ -1344,9 +1391,11 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
         if (tpb < 1) tpb = 1;
         p.tiles_per_block = tpb;
         dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)(p.Mpad / 32));
+        const long slot_elems = (long)p.Mpad * 32;
+        if (int e = wg_prepare_parts(p, grid.x, 4, slot_elems, "lnn_conv3d_wgrad(C=1)")) return e;            // writers: the 4 waves
         hipLaunchKernelGGL((wgrad_c1_kernel<TZ, TY>), grid, dim3(256), 0, s, p);
         LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(C=1)");
-        return LNN_OK;
+        return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(C=1,reduce)");
     }
     if (int e = check_act_w(x, ld_x, x2 ? c_a : C, "lnn_conv3d_wgrad(x)")) return e;
     p.taps.ntaps = 27;
@@ -1390,8 +1439,39 @@ extern "C" int lnn_conv3d_wgrad_cat(lnn_stream_t s, const void* x_a, const void*
     return conv3d_wgrad_impl(s, x_a, x_b, c_a, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, 1);
 }
 
-extern "C" int lnn_convT3d_k2s2_wgrad(lnn_stream_t s_, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp,
+namespace {
+int convT3d_k2s2_wgrad_impl(lnn_stream_t s_, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int D, int H, int W,
+                            int C, int K, float* parts, long parts_elems);
+}
+extern "C" int lnn_convT3d_k2s2_wgrad(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp,
                                       int N, int D, int H, int W, int C, int K) {
+    return convT3d_k2s2_wgrad_impl(s, x, ld_x, dy, ld_dy, dwp, N, D, H, W, C, K, nullptr, 0);
+}
+// Deterministic variants (VERDICT r1 / SURVEY 7: "deterministic split-K reduce"): the same kernels, but every writer of a
+// block stores its partial sums into its own copy of the panel inside `parts` (fp32 scratch, contents irrelevant) and an
+// ordered reduction adds the copies to dwp -- no atomics, bit-reproducible run to run.  parts_elems >= blocks.x * writers *
+// panel elements (<= 64 M floats for every layer of the BASELINE configs); too small a scratch is an error, not a fallback.
+extern "C" int lnn_conv3d_wgrad_det(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int Di, int Hi,
+                                    int Wi, int C, int K, int stride, float* parts, long parts_elems) {
+    LNN_REQUIRE(parts != nullptr && lnn_aligned16(parts), "lnn_conv3d_wgrad_det: scratch null/misaligned");
+    return conv3d_wgrad_impl(s, x, nullptr, 0, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, stride, parts, parts_elems);
+}
+extern "C" int lnn_conv3d_wgrad_cat_det(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* dy, int ld_dy,
+                                        float* dwp, int N, int Di, int Hi, int Wi, int C, int K, float* parts, long parts_elems) {
+    LNN_REQUIRE(parts != nullptr && lnn_aligned16(parts), "lnn_conv3d_wgrad_cat_det: scratch null/misaligned");
+    LNN_REQUIRE(x_b != nullptr && lnn_aligned16(x_b), "lnn_conv3d_wgrad_cat_det: second tensor null/misaligned");
+    LNN_REQUIRE(c_a > 0 && c_a < C && c_a % 32 == 0 && (C - c_a) % 8 == 0, "lnn_conv3d_wgrad_cat_det: split %d of %d channels must be a multiple of 32", c_a, C);
+    LNN_REQUIRE(ld_x >= c_a && ld_x >= C - c_a, "lnn_conv3d_wgrad_cat_det: ld_x %d smaller than a part (%d / %d)", ld_x, c_a, C - c_a);
+    return conv3d_wgrad_impl(s, x_a, x_b, c_a, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, 1, parts, parts_elems);
+}
+extern "C" int lnn_convT3d_k2s2_wgrad_det(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int D,
+                                          int H, int W, int C, int K, float* parts, long parts_elems) {
+    LNN_REQUIRE(parts != nullptr && lnn_aligned16(parts), "lnn_convT3d_k2s2_wgrad_det: scratch null/misaligned");
+    return convT3d_k2s2_wgrad_impl(s, x, ld_x, dy, ld_dy, dwp, N, D, H, W, C, K, parts, parts_elems);
+}
+namespace {
+int convT3d_k2s2_wgrad_impl(lnn_stream_t s_, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int D, int H, int W,
+                            int C, int K, float* parts, long parts_elems) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(dwp != nullptr, "lnn_convT3d_k2s2_wgrad: null panel");
     if (int e = check_act_w(x, ld_x, C, "lnn_convT3d_k2s2_wgrad(x)")) return e;
@@ -1399,6 +1479,7 @@ extern "C" int lnn_convT3d_k2s2_wgrad(lnn_stream_t s_, const void* x, int ld_x, 
     WgradParams p{};
     // dW[c,k,d] = sum_l x[l,c] dy[2l+d,k]:  P = x (rows c), Q = dy gathered with stride 2 (cols k)
     p.p = (const half_t*)x; p.q = (const half_t*)dy; p.dwp = dwp; p.ld_p = ld_x; p.ld_q = ld_dy;
+    p.parts = parts; p.parts_elems = parts_elems;
     p.N = N; p.Ld = D; p.Lh = H; p.Lw = W; p.Qd = 2 * D; p.Qh = 2 * H; p.Qw = 2 * W;
     p.M = C; p.C = K; p.Mpad = lnn_round_up(C, 32); p.Cpad = lnn_round_up(K, 32); p.pad_lo = 0;
     if (use_wgrad_s2_v2()) return launch_wgrad_s2_v2<2>(s, p, "lnn_convT3d_k2s2_wgrad(v2)");
@@ -1410,3 +1491,4 @@ extern "C" int lnn_convT3d_k2s2_wgrad(lnn_stream_t s_, const void* x, int ld_x, 
     }
     return launch_wgrad<2, 2, 2, 4, 2>(s, p, "lnn_convT3d_k2s2_wgrad");
 }
+}  // namespace

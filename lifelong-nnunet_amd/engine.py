@@ -364,6 +364,8 @@ class UNetEngine:
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
         # (weight decay, momentum) exactly as torch does with a ~0 gradient.
+        self.deterministic_wgrad = os.environ.get("LNN_DETERMINISTIC_WGRAD", "0") == "1"
+        self._det_buf = None
         self.fuse_seg_fwd = os.environ.get("LNN_NO_FUSED_SEG", "0") != "1"           # A/B switch (measurements only)
         self.numeric_conv_bias_grad = os.environ.get("LNN_NUMERIC_CONV_BIAS_GRAD", "0") == "1"
         self.fuse_in_stats = os.environ.get("LNN_NO_FUSED_IN_STATS", "0") != "1"     # A/B switch (measurements only)
@@ -524,6 +526,17 @@ class UNetEngine:
                 u += 1
         return out
 
+    def _det_scratch(self):
+        """fp32 scratch of the deterministic weight gradients (``deterministic_wgrad`` / LNN_DETERMINISTIC_WGRAD=1): every writer
+        of a weight-gradient block stores into its own panel copy, an ordered reduction replaces the fp32 atomics -> two
+        identical steps give bit-identical parameters.  64 M floats cover every layer of the BASELINE configs (the library
+        reports an error, not a fallback, if a layer needs more).  All weight gradients run on ONE stream, so one scratch."""
+        if not self.deterministic_wgrad:
+            return None
+        if self._det_buf is None:
+            self._det_buf = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)
+        return self._det_buf
+
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dlogits: List[Optional[torch.Tensor]], skip_body: bool = False, progress=None):
         """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.
@@ -599,9 +612,16 @@ class UNetEngine:
                     ldx = 1 if item.x is None else item.x.ld
 
                     def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
-                        if item.x2 is not None:
+                        det = self._det_scratch()
+                        if item.x2 is not None and det is not None:
+                            nat.call("lnn_conv3d_wgrad_cat_det", xin, at(item.x2, n0), ldx, item.x.C, at(item.y, n0), K,
+                                     self._pn(item.panel), nn, D, H, W, C, K, det, det.numel())
+                        elif item.x2 is not None:
                             nat.call("lnn_conv3d_wgrad_cat", xin, at(item.x2, n0), ldx, item.x.C, at(item.y, n0), K,
                                      self._pn(item.panel), nn, D, H, W, C, K)
+                        elif det is not None:
+                            nat.call("lnn_conv3d_wgrad_det", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
+                                     item.stride, det, det.numel())
                         else:
                             nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
                                      item.stride)
@@ -620,8 +640,13 @@ class UNetEngine:
                     C, K = item.cin, item.cout
 
                     def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
-                        nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
-                                 self._pn(item.panel), nn, D, H, W, C, K)
+                        det = self._det_scratch()
+                        if det is not None:
+                            nat.call("lnn_convT3d_k2s2_wgrad_det", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
+                                     self._pn(item.panel), nn, D, H, W, C, K, det, det.numel())
+                        else:
+                            nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
+                                     self._pn(item.panel), nn, D, H, W, C, K)
                         if per_layer_unpack:
                             unpack(item)
                     on_side(up_wgrad)

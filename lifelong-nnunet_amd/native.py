@@ -37,6 +37,9 @@ SIGNATURES = {
     "lnn_convT3d_k2s2_fwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "lnn_convT3d_k2s2_dgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
     "lnn_convT3d_k2s2_wgrad": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
+    "lnn_conv3d_wgrad_det": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _l]),
+    "lnn_conv3d_wgrad_cat_det": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _l]),
+    "lnn_convT3d_k2s2_wgrad_det": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _l]),
     "lnn_unpack_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _f, _i]),
     "lnn_pack_weights_batched": (_i, [_p, _p, _p, _p, _i, _l]),
     "lnn_unpack_wgrad_batched": (_i, [_p, _p, _p, _p, _i, _l, _f, _i]),

@@ -167,6 +167,8 @@ class Generic_UNet(nn.Module):
             cls = UNetEngineF32 if self.storage == "fp32" else UNetEngine
             eng = cls(self.arena, self.input_channels, self.base_num_features, self.num_classes, self.num_pool,
                       tuple(x.shape[2:]), x.shape[0], self.device_, self.MAX_NUM_FILTERS_3D)
+            if getattr(self, "deterministic_wgrad", False) and hasattr(eng, "deterministic_wgrad"):
+                eng.deterministic_wgrad = True        # ordered reduction instead of fp32 atomics in every weight gradient
             self._engines[key] = eng
         return eng
 

@@ -52,7 +52,7 @@ class nnUNetTrainerMultiHead:
                  vit_type='base', version=1, split_gpu=False, transfer_heads=False, ViT_task_specific_ln=False,
                  do_LSA=False, do_SPT=False, network=None, use_param_split=False,
                  plans: Optional[dict] = None, data_provider: Optional[Callable] = None, device="cuda",
-                 process_group=None):
+                 process_group=None, deterministic_wgrad=False):
         assert not use_vit, "Generic_ViT_UNet variants are out of scope (SURVEY.md section 2 row 8)"
         # the positional constructor arguments the reference stores next to every checkpoint (MH.py:181-185)
         self.init_args = (split, task, plans_file, fold, output_folder, dataset_directory, batch_dice, stage, unpack_data,
@@ -69,6 +69,9 @@ class nnUNetTrainerMultiHead:
         self.device = torch.device(device)
         self.data_provider = data_provider or default_data_provider
         self.process_group = process_group
+        # bit-reproducible fp16 steps: ordered reductions instead of fp32 atomics in the weight-gradient kernels (what
+        # torch.backends.cudnn.deterministic, which upstream's ``deterministic`` flag sets, stands for); off by default
+        self.deterministic_wgrad = deterministic_wgrad
         self.already_trained_on = already_trained_on or OrderedDict()
         self.tasks_list_with_char = tasks_list_with_char
         # upstream nnUNetTrainerV2 constants
@@ -120,6 +123,7 @@ class nnUNetTrainerMultiHead:
                                            p["base_num_features"], p["num_classes"], p["num_pool"],
                                            device=self.device)
         self.network = self.mh_network.model
+        self.network.deterministic_wgrad = bool(self.deterministic_wgrad)
         self.network.inference_apply_nonlin = lambda x: torch.softmax(x, 1)
 
     def initialize_optimizer_and_scheduler(self):

@@ -534,3 +534,48 @@ def test_conv_splitk_small_layers(C, K, D, H, W):
     torch.cuda.synchronize()
     gs = float(g0.float().abs().max())
     assert float((g0.float() - g1.float()).abs().max()) <= 2e-3 * gs
+
+
+@pytest.mark.parametrize("case", ["c1", "s1_small", "s1_panels", "s1_cat", "s2", "convT"])
+def test_wgrad_deterministic_variants(case):
+    """lnn_*_wgrad_det (per-writer panel copies + ordered reduction): equal to the atomics path up to the fp32 summation order,
+    and BIT-identical between two runs on a scratch full of NaNs."""
+    torch.manual_seed(7)
+    N = 2
+    scratch = torch.full((64 * 1024 * 1024,), float("nan"), device=DEV)
+    if case == "convT":
+        C, K, D, H, W = 64, 32, 6, 9, 10
+        x = (torch.randn(N, D, H, W, C, device=DEV) * 0.5).half()
+        dy = (torch.randn(N, 2 * D, 2 * H, 2 * W, K, device=DEV) * 0.5).half()
+        elems = nat.query("lnn_wgrad_panel_elems", 8, C, K)
+        plain = lambda pn: nat.call("lnn_convT3d_k2s2_wgrad", x, C, dy, K, pn, N, D, H, W, C, K)
+        det = lambda pn: nat.call("lnn_convT3d_k2s2_wgrad_det", x, C, dy, K, pn, N, D, H, W, C, K, scratch, scratch.numel())
+    else:
+        C, K, D, H, W, stride = {"c1": (1, 32, 9, 13, 17, 1), "s1_small": (32, 32, 9, 13, 17, 1), "s1_panels": (128, 64, 8, 9, 10, 1),
+                                 "s1_cat": (64, 32, 9, 13, 17, 1), "s2": (32, 64, 10, 14, 18, 2)}[case]
+        Do, Ho, Wo = [(v - 1) // stride + 1 for v in (D, H, W)]
+        x = (torch.randn(N, D, H, W, C, device=DEV) * 0.5).half() if C > 1 else (torch.randn(N, D, H, W, device=DEV) * 0.5).half()
+        dy = (torch.randn(N, Do, Ho, Wo, K, device=DEV) * 0.5).half()
+        elems = nat.query("lnn_wgrad_panel_elems", 27, K, C) if C > 1 else nat.query("lnn_wgrad_panel_elems", 1, K, 27)
+        ld = C if C > 1 else 1
+        if case == "s1_cat":
+            xa, xb = x[..., :32].contiguous(), x[..., 32:].contiguous()
+            plain = lambda pn: nat.call("lnn_conv3d_wgrad_cat", xa, xb, 32, 32, dy, K, pn, N, D, H, W, C, K)
+            det = lambda pn: nat.call("lnn_conv3d_wgrad_cat_det", xa, xb, 32, 32, dy, K, pn, N, D, H, W, C, K, scratch, scratch.numel())
+        else:
+            plain = lambda pn: nat.call("lnn_conv3d_wgrad", x, ld, dy, K, pn, N, D, H, W, C, K, stride)
+            det = lambda pn: nat.call("lnn_conv3d_wgrad_det", x, ld, dy, K, pn, N, D, H, W, C, K, stride, scratch, scratch.numel())
+    p0, p1, p2 = (torch.full((elems,), 0.25, device=DEV) for _ in range(3))     # the panels accumulate: a non-zero start
+    plain(p0); det(p1); det(p2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(p1).all()
+    assert torch.equal(p1, p2)
+    assert float((p0 - p1).norm() / p0.norm()) < 1e-5
+    # an insufficient scratch is reported, never silently ignored
+    with pytest.raises(RuntimeError):
+        if case == "convT":
+            nat.call("lnn_convT3d_k2s2_wgrad_det", x, C, dy, K, p1, N, D, H, W, C, K, scratch, 1024)
+        elif case == "s1_cat":
+            nat.call("lnn_conv3d_wgrad_cat_det", xa, xb, 32, 32, dy, K, p1, N, D, H, W, C, K, scratch, 1024)
+        else:
+            nat.call("lnn_conv3d_wgrad_det", x, ld, dy, K, p1, N, D, H, W, C, K, stride, scratch, 1024)

@@ -158,3 +158,30 @@ def test_sliding_window_kernels_exact_properties():
         assert (seg == ref.argmax(0)).mean() > 0.9999
     seg, prob = predict_3D(net, vol[:, :5], do_mirroring=False, mirror_axes=(), step_size=0.5, patch_size=(8, 16, 8))
     assert prob.shape == (3, 5, 30, 17) and np.allclose(prob, ref[:, :5], atol=2e-6)
+
+
+def test_fp16_step_is_bit_reproducible_with_deterministic_wgrad():
+    """``deterministic_wgrad``: the fp32 atomics of the weight-gradient kernels are the only order-dependent arithmetic of the
+    fp16 step; with the ordered reduction two runs from the same weights on the same batches end on bit-identical parameters
+    (and agree with the default path to the rounding of the summation order)."""
+    torch.manual_seed(3)
+    batches = [make_patch_batch(2, (16, 32, 16), 3, seed=900 + i) for i in range(3)]
+    ref = Generic_UNet(1, 8, 3, 3, device=DEV)
+    init = {k: v.clone() for k, v in ref.state_dict().items()}
+
+    def run(det):
+        net = Generic_UNet(1, 8, 3, 3, device=DEV)
+        net.load_state_dict(init)
+        net.deterministic_wgrad = det
+        opt = FusedSGD(net, 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+        scaler = GradScaler()
+        loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), ds_loss_weights(3))
+        losses = [_hip_step(net, opt, scaler, loss_fn, d, t)[0] for d, t in batches]
+        return net.arena.theta.clone(), losses
+
+    t1, l1 = run(True)
+    t2, l2 = run(True)
+    t0, l0 = run(False)
+    assert torch.equal(t1, t2) and l1 == l2
+    assert float((t1 - t0).norm() / t0.norm()) < 1e-5
+    assert np.allclose(l1, l0, rtol=1e-5)
