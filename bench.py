@@ -339,7 +339,7 @@ def main():
         "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: nnUNetTrainerSequential.run_iteration, "
+        "config": {"workload": f"{wl_desc}, "
                                f"{'x'.join(map(str, plans['patch_size']))} patches, batch {B}/GPU, num_pool {plans['num_pool']}, "
                                f"base {plans['base_num_features']}, {plans['num_classes']} logits",
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss),
