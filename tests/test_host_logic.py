@@ -29,6 +29,36 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.lnn_version() >= 100
 
 
+def test_ctypes_signatures_match_the_header():
+    """Every declaration of include/lnn_hip.h against the ctypes table: same number of parameters, and per parameter the same
+    class (pointer / int / long / float / size_t) -- a wrong table entry would corrupt a call silently."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "lnn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    decls = re.findall(r"\b([a-zA-Z_][a-zA-Z0-9_ \*]*?)\s*\b(lnn_[a-zA-Z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(decls) >= 30
+
+    def klass(param):
+        param = " ".join(param.split())
+        if "*" in param or param.startswith("lnn_stream_t"):
+            return C.c_void_p
+        base = param.rsplit(" ", 1)[0] if " " in param else param
+        return {"int": C.c_int, "long": C.c_long, "float": C.c_float, "size_t": C.c_size_t, "unsigned": C.c_uint}[base.replace("const ", "")]
+
+    same = {C.c_char_p: C.c_void_p}
+    for ret, name, params in decls:
+        res, argtypes = nat.SIGNATURES[name]
+        plist = [q for q in (x.strip() for x in params.split(",")) if q and q != "void"]
+        assert len(plist) == len(argtypes), f"{name}: header has {len(plist)} parameters, ctypes table {len(argtypes)}"
+        for i, (q, a) in enumerate(zip(plist, argtypes)):
+            want = klass(q)
+            got = same.get(a, a)
+            if hasattr(got, "_type_") and not isinstance(got._type_, str):       # POINTER(c_int) and friends
+                got = C.c_void_p
+            assert got is want, f"{name}: parameter {i} ({q!r}) is {want.__name__} in the header, {a} in the ctypes table"
+
+
 def test_bad_arguments_are_reported_not_thrown():
     lib = nat.lib()
     rc = lib.lnn_pack_weights(None, None, None, 27, 32, 32, 1, 1, 1)
