@@ -247,3 +247,27 @@ def test_lwf_trainer_matches_reference_flow(ref):
     g1 = _Counting(ref_batches(7000, 12))
     tr.run_iteration(g1, True)
     assert g1.n == 1
+
+
+@pytest.mark.parametrize("transfer", [False, True])
+def test_mib_trainer_matches_reference_flow(golden_dir, ref, transfer):
+    """nnUNetTrainerMiB on the HIP path vs the reference's own MiB trainer (oracle/make_goldens_mib.py: task A 2 plain iterations,
+    task B 3 iterations of CE + unbiased KD against the snapshot of the task-A model), with and without ``transfer_heads``."""
+    meta, arr = ref
+    mmeta = json.load(open(golden_dir + "/mib_flow_reference.json"))
+    marr = np.load(golden_dir + "/mib_flow_reference.npz")
+    f = mmeta["mib_flow_" + ("transfer" if transfer else "init")]
+    tr = _trainer("mib", f["seeds"], 4, arr, 2, transfer_heads=transfer, mib_alpha=f["alpha"], mib_lkd=f["lkd"])
+    losses = []
+    orig = tr.run_iteration
+    tr.run_iteration = lambda *a, **k: (lambda v: (losses.append(float(v)), v)[1])(orig(*a, **k))
+    tr.run_training("taskA")
+    _close_losses(losses, f["lossesA"])
+    del losses[:]
+    tr.num_batches_per_epoch = 3
+    tr.run_training("taskB")
+    print(f"MiB task B vs reference ({'transfer' if transfer else 'init'} head): {losses} ref {f['lossesB']}")
+    _close_losses(losses, f["lossesB"], rtol_first=5e-4, rtol_later=1e-3)
+    rt = _rel(marr, "mib_" + ("transfer" if transfer else "init") + "::final_theta", dict(tr.network.named_parameters()), f["names"])
+    print(f"MiB final theta rel-L2: {rt:.2e}")
+    assert rt < 3e-3
