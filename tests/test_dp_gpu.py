@@ -73,9 +73,9 @@ def test_forced_dp_step_equals_plain_step(nccl_world1):
     for b in bs:
         lp = plain.run_iteration(iter([b]), True)
         ld = dp.run_iteration(iter([b]), True)
-        assert abs(float(lp) - float(ld)) <= 1e-6 * abs(float(lp))
+        assert abs(float(lp) - float(ld)) <= 1e-5 * abs(float(lp))       # two fp16 runs: the order of the weight-gradient atomics
     tp, td = plain.network.arena.theta, dp.network.arena.theta
-    assert float((tp - td).norm() / tp.norm()) < 1e-6          # fp32 atomics of the weight-gradient kernels: order only
+    assert float((tp - td).norm() / tp.norm()) < 1e-5          # fp32 atomics of the weight-gradient kernels: order only
     wms = [e[1] for e in log if e[0] == "wm"]
     ars = [(e[1], e[2]) for e in log if e[0] == "ar"]
     per_step = len(dp.dp.buckets)
@@ -102,7 +102,7 @@ def test_batch_dice_and_accumulated_fisher_through_forced_dp(nccl_world1):
         tr.data_provider = lambda task, split, plans: iter(data)
         tr.reinitialize("taskA")
         tr.run_training("taskA")
-    assert np.allclose(a.all_tr_losses, b.all_tr_losses, rtol=1e-6)
+    assert np.allclose(a.all_tr_losses, b.all_tr_losses, rtol=1e-5)      # two fp16 runs: the order of the weight-gradient atomics
     names = list(a.fisher["taskA"].keys())
     fa = torch.cat([a.fisher["taskA"][n].reshape(-1) for n in names if a.fisher["taskA"][n].numel() > 1])
     fb = torch.cat([b.fisher["taskA"][n].reshape(-1) for n in names if b.fisher["taskA"][n].numel() > 1])
