@@ -188,31 +188,71 @@ def regulariser_rooflines(trainer, plans):
     return {"P": P, "logits_elems": B * K * V, "kernels": res}
 
 
-def cpu_baseline(plans, flops_full):
-    """The oracle (pure PyTorch CPU fp32 restatement of the reference's step) on the GPU box's host cores, on a
-    bounded sample: the SAME 5-level network on a 128x128x128 sub-patch (43 % of the voxels), B=1, one warm-up and
-    one timed iteration; converted to full-size patches/s by the voxel ratio."""
+def cpu_baseline_and_parity(tr, plans, flops_full, batch, sample="full"):
+    """The oracle (pure PyTorch CPU fp32 restatement of the reference's step, oracle/) on the GPU box's host cores, timed on
+    ONE full-size patch (B=1; `sample="small"`: a 128^3 sub-patch scaled by the voxel ratio), with the weights the benchmarked
+    trainer holds after its timed steps -- and the SAME patch through the HIP path: the Dice half of BASELINE.json's metric
+    (`mean Dice vs ref`) and the loss gate the reference prints with every timing (MH.py:1017-1019).
+    Returns (cpu_baseline, parity)."""
     import torch
     from oracle import losses as olosses, train as otrain
     from oracle.unet import OracleGenericUNet
     from lifelong_nnunet_amd.synthetic import make_patch_batch
     cores = min(os.cpu_count() or 1, 32)     # oneDNN conv3d stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(cores)
-    q = 2 ** plans["num_pool"]
-    sub = tuple(max(2 * q, min(128, p // q * q)) for p in plans["patch_size"])      # divisible by 2^num_pool, ~10 s of CPU work
-    torch.manual_seed(0)
-    net = OracleGenericUNet(1, plans["base_num_features"], plans["num_classes"], plans["num_pool"])
-    opt = otrain.make_optimizer(net)
-    w = olosses.ds_loss_weights(plans["num_pool"])
-    data, tgts = make_patch_batch(1, sub, plans["num_pool"], seed=1)
-    small = make_patch_batch(1, tuple(2 ** (plans["num_pool"] + 1) for _ in sub), plans["num_pool"], seed=2)
-    otrain.run_iteration(net, opt, small[0], small[1], w)        # warm-up (thread pools, oneDNN primitives)
-    t0 = time.time()
-    otrain.run_iteration(net, opt, data, tgts, w)
-    dt = time.time() - t0
+    K, npool = plans["num_classes"], plans["num_pool"]
+    data = batch["data"][:1].float().cpu()
+    tgts = [t[:1].float().cpu() for t in batch["target"]]
     ratio = 1.0
-    for a, b in zip(sub, plans["patch_size"]):
-        ratio *= a / b
+    if sample != "full":
+        q = 2 ** npool
+        sub = tuple(max(2 * q, min(128, p // q * q)) for p in plans["patch_size"])
+        data = data[:, :, :sub[0], :sub[1], :sub[2]].contiguous()
+        tgts = [t[:, :, :sub[0] >> i, :sub[1] >> i, :sub[2] >> i].contiguous() for i, t in enumerate(tgts)]
+        for a_, b_ in zip(sub, plans["patch_size"]):
+            ratio *= a_ / b_
+    shape = tuple(data.shape[2:])
+    net = OracleGenericUNet(1, plans["base_num_features"], K, npool)
+    net.load_state_dict({k: v.detach().float().cpu() for k, v in tr.network.state_dict().items()})
+    w = olosses.ds_loss_weights(npool)
+    # HIP path on the same patch (no-grad forward, B = 1 engine), BEFORE the oracle's optimiser step changes its weights
+    from lifelong_nnunet_amd.losses import DC_and_CE_loss, MultipleOutputLoss2, ds_loss_weights
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), ds_loss_weights(npool))
+    dev = tr.network.device_
+    with torch.no_grad():
+        tr.network.eval()
+        out_g = tr.network(data.to(dev))
+        loss_g = float(loss_fn(out_g, [t.to(dev) for t in tgts]))
+        seg_g = out_g[0].argmax(1).cpu()
+        tr.network.train()
+    del out_g
+    opt = otrain.make_optimizer(net)
+    small = make_patch_batch(1, tuple(2 ** (npool + 1) for _ in shape), npool, seed=2)
+    warm = OracleGenericUNet(1, plans["base_num_features"], K, npool)
+    otrain.run_iteration(warm, otrain.make_optimizer(warm), small[0], small[1], w)   # warm-up (thread pools, oneDNN primitives)
+    del warm
+    t0 = time.time()
+    loss_o, out_o = otrain.run_iteration(net, opt, data, tgts, w)
+    dt = time.time() - t0
+    seg_o = out_o[0].detach().argmax(1)
+    lab = tgts[0][:, 0].long()
+
+    def dice(a_, b_):
+        ds = []
+        for c in range(1, K):
+            x, y = a_ == c, b_ == c
+            den = int(x.sum()) + int(y.sum())
+            if den:
+                ds.append(2.0 * int((x & y).sum()) / den)
+        return sum(ds) / len(ds) if ds else float("nan")
+
+    d_go, d_gl, d_ol = dice(seg_g, seg_o), dice(seg_g, lab), dice(seg_o, lab)
+    parity = {"patch": "x".join(map(str, shape)) + ", B=1, the trainer's weights after the timed steps",
+              "loss_hip": loss_g, "loss_oracle": loss_o, "loss_rel_err": abs(loss_g - loss_o) / max(abs(loss_o), 1e-12),
+              "dice_hip_vs_oracle_seg": d_go, "mean_dice_hip": d_gl, "mean_dice_oracle": d_ol, "abs_delta_dice": abs(d_gl - d_ol),
+              "voxel_agreement": float((seg_g == seg_o).float().mean()),
+              "gates": {"loss_rel_err<=1e-4": abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), "abs_delta_dice<=1e-3": abs(d_gl - d_ol) <= 1e-3,
+                        "dice_hip_vs_oracle_seg>=0.9": d_go >= 0.9}}
     cpu_name = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -221,48 +261,18 @@ def cpu_baseline(plans, flops_full):
                 break
     except OSError:
         pass
-    return {"value": ratio / dt, "unit": "patches/s", "cores": cores, "kind": "port", "extrapolated": True, "cpu": cpu_name,
-            "sample": f"oracle.train.run_iteration, same {plans['num_pool']}-level U-Net, ONE {sub[0]}x{sub[1]}x{sub[2]} "
-                      f"patch (B=1, {ratio:.4f} of the voxels of a {'x'.join(map(str, plans['patch_size']))} patch) in "
-                      f"{dt:.1f} s, scaled by the voxel ratio",
+    base = {"value": ratio / dt, "unit": "patches/s", "cores": cores, "kind": "port", "extrapolated": sample != "full", "cpu": cpu_name,
+            "sample": f"oracle.train.run_iteration (forward, Dice+CE, backward, clip, SGD), same {npool}-level U-Net, ONE "
+                      f"{'x'.join(map(str, shape))} patch (B=1) in {dt:.1f} s" + ("" if sample == "full" else f", scaled by the voxel ratio {ratio:.4f}"),
             "gflops": flops_full * ratio / dt / 1e9}
+    return base, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-
+def build_trainer(workload, device, rank):
+    """Trainer of one BASELINE.json configuration in the state its timed iteration needs (second task for the CL methods)."""
     import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("LNN_FORCE_DP", "0") == "1"
-    # stdout must carry exactly ONE line (the JSON): libraries that print to the C-level stdout (RCCL writes a version
-    # banner there at communicator creation) are sent to stderr; the JSON goes to the saved descriptor at the end
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        # NO device_id: with it the RCCL communicator is created eagerly, BEFORE the engine allocates its buffers, and every
-        # step then runs 6-7 % slower on this stack (ROCm 7.0 / RCCL 2.26.6; tools/dp_ab.py: 27.6 vs 25.9 ms, plain 25.9).
-        # Created lazily by the first collective (the first warm-up step's gradient all-reduce) it costs nothing.
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-
-    from lifelong_nnunet_amd import get_trainer_class, native as nat
-    plans, ext, wl_desc = WORKLOADS[args.workload]
+    from lifelong_nnunet_amd import get_trainer_class
+    plans, ext, wl_desc = WORKLOADS[workload]
     plans = dict(plans)
     Trainer = get_trainer_class(ext)
 
@@ -301,6 +311,83 @@ def main():
         tr.network.train()
         tr.freeze_run, tr.loss, tr.batch_idx = False, tr.LwFloss, 0
         extra_cfg["teacher_store_MB"] = sum(t.numel() * t.element_size() for v in tr.target_logits.values() for t in v) / 1e6
+    return tr, plans, ext, wl_desc, extra_cfg
+
+
+def heaviest_block(eng):
+    from lifelong_nnunet_amd.engine import ConvBlock
+    return max((b for b in eng.order if isinstance(b, ConvBlock) and b.cin > 1), key=lambda b: b.z.V * b.cin * b.cout)
+
+
+def other_workload(workload, args, device, rank):
+    """One of the continual-learning configurations as extra keys of the same line (N = 1): same loop, same clock."""
+    import torch
+    tr, plans, ext, wl_desc, extra_cfg = build_trainer(workload, device, rank)
+    for _ in range(args.warmup):
+        tr.run_iteration(tr.tr_gen, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.run_iteration(tr.tr_gen, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    B = plans["batch_size"]
+    res = {"workload": f"{wl_desc}, {'x'.join(map(str, plans['patch_size']))} patches, batch {B}", "value": B * args.steps / dt,
+           "unit": "patches/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "loss": float(loss)}
+    res.update(extra_cfg)
+    if ext == "lwf":          # the fix behind a flag: every head evaluated on the training batch (one batch, one body pass)
+        tr.same_batch_predictions = True
+        for _ in range(2):
+            tr.run_iteration(tr.tr_gen, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.run_iteration(tr.tr_gen, True)
+        torch.cuda.synchronize()
+        res["same_batch_predictions_patches_per_s"] = B * args.steps / (time.perf_counter() - t0)
+        res["note"] = "value = reference semantics (T+2 batches per iteration, one extra eval forward per head on its own batch)"
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
+                    help="CPU baseline / parity patch: one full-size patch (~15 s of CPU work) or a 128^3 sub-patch")
+    ap.add_argument("--other-workloads", default=None,
+                    help="comma list of further BASELINE configurations reported as extra keys (default: c3,c4,c5 with --workload c2 at N=1; 'none')")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    use_dist = world > 1 or os.environ.get("LNN_FORCE_DP", "0") == "1"
+    # stdout must carry exactly ONE line (the JSON): libraries that print to the C-level stdout (RCCL writes a version
+    # banner there at communicator creation) are sent to stderr; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        # NO device_id: with it the RCCL communicator is created eagerly, BEFORE the engine allocates its buffers, and every
+        # step then runs 6-7 % slower on this stack (ROCm 7.0 / RCCL 2.26.6; tools/dp_ab.py: 27.6 vs 25.9 ms, plain 25.9).
+        # Created lazily by the first collective (the first warm-up step's gradient all-reduce) it costs nothing.
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from lifelong_nnunet_amd import native as nat
+    tr, plans, ext, wl_desc, extra_cfg = build_trainer(args.workload, device, rank)
 
     def step():
         return tr.run_iteration(tr.tr_gen, True)
@@ -315,6 +402,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    eng = list(tr.network._engines.values())[0]
+    probe = None
+    if rank == 0 and not args.no_roofline:
+        # the three MFMA families on their heaviest layer, bracketed with HIP events on the streams they launch on,
+        # INSIDE the timed steps (two event records per call: no synchronisation, no extra launches)
+        probe = {"layer": heaviest_block(eng).prefix}
+        eng.probe = probe
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -325,17 +419,17 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    eng.probe = None
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
 
-    eng = list(tr.network._engines.values())[0]
     flops_patch, mac_fwd = eng.flops_per_patch()
     B = plans["batch_size"]
     patches_per_s = world * B * args.steps / dt
     out = {
-        "metric": "3D patches/sec (whole node), 5-level 3D Generic_UNet training step", "value": patches_per_s,
+        "metric": "3D patches/sec (whole node) + mean Dice vs ref, 5-level 3D Generic_UNet training step", "value": patches_per_s,
         "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
@@ -372,32 +466,66 @@ def main():
                                                   "how": "pinned host buffers, copy of batch i+1 on a side stream during step i"}
         except Exception as e:
             out["config"]["h2d_inclusive"] = {"error": repr(e)}
-    if rank == 0 and not args.no_roofline:
-        kr = kernel_rooflines(tr)
-        dom = min(kr["kernels"].items(), key=lambda kv: kv[1]["tflops"])     # the slowest family bounds the stack
-        fwd = kr["kernels"]["igemm_conv_fwd"]
+    if probe is not None:
+        kr = kernel_rooflines(tr)                    # the same three launches back to back on an otherwise idle chip
+        fam = {"fwd": "igemm_conv_fwd", "dgrad": "igemm_conv_dgrad", "wgrad": "igemm_wgrad"}
+        names = {"igemm_conv_fwd": "igemm_conv_s1_v9_kernel (stride-1 3x3x3 conv forward, z-streaming, InstanceNorm-statistics epilogue)",
+                 "igemm_conv_dgrad": "igemm_conv_s1_v9_kernel (data gradient)",
+                 "igemm_wgrad": "igemm_wgrad_s1_v5_kernel (stride-1 weight gradient; the rocprof top row of the step)"}
+        fams = {}
+        for kind, key in fam.items():
+            evs = probe.get(kind, [])
+            iso = kr["kernels"][key]
+            ms_in = sum(a_.elapsed_time(b_) for a_, b_ in evs) / len(evs) if evs else None
+            fams[key] = {"kernel": names[key], "launch_ms_in_step": ms_in, "launch_ms_isolated": iso["ms"],
+                         "achieved_in_step": iso["gflop"] / ms_in if ms_in else None, "achieved_isolated": iso["tflops"],
+                         "frac_in_step": iso["gflop"] / ms_in / PEAK_MFMA_F16_TFLOPS if ms_in else None,
+                         "frac_isolated": iso["tflops"] / PEAK_MFMA_F16_TFLOPS, "launches_timed": len(evs)}
+        # the headline is the family that bounds the stack: the slowest of the three IN the step
+        dom_key = min(fams, key=lambda k: fams[k]["achieved_in_step"] or fams[k]["achieved_isolated"])
+        dom = fams[dom_key]
         traffic, traffic_note = None, None
-        try:      # HBM bytes per launch of the same kernel/launch from the committed PMC passes (separate rocprofv3 runs)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            traffic, traffic_note = tj["hbm_bytes_per_launch_corrected"], "profiles/r02_pmc_traffic.json: " + tj["note"]
+        try:      # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 runs)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            traffic, traffic_note = tj["kernels"][dom_key]["hbm_bytes_per_launch_corrected"], "profiles/r03_pmc_traffic.json: " + tj["note"]
         except Exception:
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_conv_s1_v9_kernel<4,1,2> (stride-1 3x3x3 conv fwd, z-streaming) on " + kr["layer"], "achieved": fwd["tflops"],
-                           "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": fwd["tflops"] / PEAK_MFMA_F16_TFLOPS,
+        ach = dom["achieved_in_step"] or dom["achieved_isolated"]
+        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"] + " on " + kr["layer"], "achieved": ach,
+                           "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
                            "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_note,
-                           "launch_ms": fwd["ms"], "algorithmic_gflop_per_launch": fwd["gflop"],
-                           "other_kernels": {k: {"achieved": v["tflops"], "frac": v["tflops"] / PEAK_MFMA_F16_TFLOPS,
-                                                 "launch_ms": v["ms"]} for k, v in kr["kernels"].items()},
-                           "slowest_family": dom[0]}
+                           "launch_ms": dom["launch_ms_in_step"] or dom["launch_ms_isolated"],
+                           "how": "HIP events around the C-ABI call on the stream it launches on, inside the timed steps "
+                                  "(the forward call includes its 2 tiny statistics launches); *_isolated = the same launch "
+                                  "repeated back to back on an idle chip",
+                           "algorithmic_gflop_per_launch": kr["kernels"][dom_key]["gflop"],
+                           "families": fams, "slowest_family": dom_key}
         try:
             out["regulariser_kernels"] = regulariser_rooflines(tr, plans)
         except Exception as e:
             out["regulariser_kernels"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(plans, flops_patch)
+            batch = tr.tr_gen.items[0] if isinstance(tr.tr_gen, ResidentBatches) else next(tr.tr_gen)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(tr, plans, flops_patch, batch, args.cpu_sample)
         except Exception as e:      # the GPU numbers above must still be reported
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    others = args.other_workloads
+    if others is None:
+        others = "c3,c4,c5" if (args.workload == "c2" and world == 1 and not args.no_roofline) else "none"
+    if rank == 0 and world == 1 and others != "none":
+        del tr, eng
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["other_workloads"] = {}
+        for wname in others.split(","):
+            try:
+                out["other_workloads"][wname] = other_workload(wname, args, device, rank)
+            except Exception as e:
+                out["other_workloads"][wname] = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
     if rank == 0:
         info = nat.device_info()
         out["device"] = info

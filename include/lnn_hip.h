@@ -98,8 +98,9 @@ int lnn_conv3d_fwd_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int
 /* Conv3d (3x3x3, padding 1) -> dense output y (ld_y == K) AND the InstanceNorm statistics of that output in one call
  * (ConvDropoutNormNonlin = instnorm(conv(x)), test_MultiHead_Module.py:287-291; statistics as lnn_instnorm_stats: biased
  * variance over D*H*W per (n, c) of the fp16-stored values).  x_b may be NULL (single input tensor; c_a ignored).  Where the
- * stride-1 z-streaming kernel applies (C = 32 / 64) the sums are taken in its epilogue from the values it stores -- the
- * separate 2 B/element statistics pass disappears; otherwise the call runs the convolution followed by lnn_instnorm_stats.
+ * stride-1 z-streaming kernel applies (C = 32 / 64), and for the first layer (C == 1), the sums are taken in the conv's
+ * epilogue from the values it stores -- the separate 2 B/element statistics pass disappears; otherwise the call runs the
+ * convolution followed by lnn_instnorm_stats.
  * ws >= lnn_instnorm_ws_doubles(N, K). */
 int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
                             const float* bias, void* y, int N, int Di, int Hi, int Wi, int C, int K, int stride,
@@ -172,6 +173,17 @@ int lnn_instnorm_lrelu_bwd(lnn_stream_t s, void* y_inout_h, const void* dz_h, in
                            float slope, float* dgamma, float* dbeta, float* dbias, float grad_unscale,
                            double* ws);
 size_t lnn_instnorm_ws_doubles(int N, int C);
+/* lnn_seg1x1_bwd + lnn_instnorm_lrelu_bwd of a decoder block that feeds a seg_outputs head (generic_ViT_UNet.py:263-264 in
+ * backward), without dL/dz in memory: both passes rebuild dz = [dz_prior] + fp16(sum_k dlogits[k] w[k][c]) and the fp16
+ * activation z (for d seg_w) in registers from y and the K-channel dlogits.  dz_prior (may be NULL) is the part of dL/dz that
+ * is already in memory (the transposed conv of the next level wrote it), channel stride ld_dz.  dy replaces y in place;
+ * dgamma / dbeta / seg_dw (+)= grad_unscale * (...).  K <= 4; other shapes: call the two functions.
+ * ws: >= lnn_instnorm_lrelu_seg_bwd_ws_doubles(N, C) doubles. */
+int lnn_instnorm_lrelu_seg_bwd(lnn_stream_t s, void* y_inout_h, const void* dz_prior_h, int ld_dz, const float* seg_w,
+                               const float* dlogits, float* seg_dw, int K, int N, long V, int C, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, float slope, float* dgamma,
+                               float* dbeta, float grad_unscale, double* ws);
+size_t lnn_instnorm_lrelu_seg_bwd_ws_doubles(int N, int C);
 
 /* ------------------------------------------------------------------------------------------------
  * seg_outputs[u]: nn.Conv3d 1x1x1, no bias (test_MultiHead_Module.py:427-431).
@@ -196,6 +208,11 @@ size_t lnn_seg1x1_bwd_ws_floats(int N, int C);
  * ---------------------------------------------------------------------------------------------- */
 int lnn_dice_ce_fwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
                     int batch_dice, float smooth, float* out_loss, double* ws);
+/* One deep-supervision level of MultipleOutputLoss2 (weights recipe MH.py:1373-1383): as lnn_dice_ce_fwd, and
+ * total[0] = (accumulate ? total[0] : 0) + weight * out_loss[0] -- the weighted sum over the levels without a host-side
+ * multiply / add per level (stream-ordered read-modify-write of one float). */
+int lnn_dice_ce_fwd_ds(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V, int batch_dice,
+                       float smooth, float* out_loss, double* ws, float weight, float* total, int accumulate);
 int lnn_dice_ce_bwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
                     int batch_dice, float smooth, const double* ws, float gscale, const float* gscale_dev,
                     float dice_scale, float* dlogits);

@@ -204,39 +204,28 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvParams p) {
 //   y[n,p,m] = b[m] + sum_tap w[m][tap] x[n, p + tap - 1]
 // x tile: (TZ+2)(TY+2)(TX+2) halves.  Weight panel wp[0][Mpad][32].
 // ------------------------------------------------------------------------------------------------
-template <int TZ, int TY, int MT>
-__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const ConvParams p) {
-    constexpr int TX = 8, VT = TZ * TY * TX / 128, PZ = TZ + 2, PY = TY + 2, PX = TX + 2, P = PZ * PY * PX;
+// Persistent blocks: grid (nb, N, M / 32); a block walks the 4x8x8-voxel tiles t = blockIdx.x, + nb, ... of ONE sample, so the
+// per-(sample, channel) sums of the STATS epilogue (the InstanceNorm statistics of the next op, on the fp16-rounded values
+// it stores) stay in registers until the block ends: one partial row per block, p.stats_pws[a][blockIdx.x][n][c].
+// The next tile's input halves are fetched into registers before the current tile's MFMAs; the epilogue exchanges
+// accumulator quads between the two half-waves (v_permlane32_swap) so that a lane stores 8 consecutive channels (16 bytes).
+typedef unsigned c1_uint4 __attribute__((ext_vector_type(4)));
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void conv_c1_fwd_kernel(const ConvParams p, int tiles_per_sample) {
+    constexpr int TZ = 4, TY = 8, TX = 8, VT = TZ * TY * TX / 128, PZ = TZ + 2, PY = TY + 2, PX = TX + 2, P = PZ * PY * PX;
+    constexpr int NL = (P + 255) / 256;
     __shared__ half_t xl[P];
+    __shared__ float sred[STATS ? 4 * 2 * 32 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int t = blockIdx.x;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y; t /= p.tiles_y;
-    const int tz = t % p.tiles_z; t /= p.tiles_z;
-    const int n = t;
-    const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
-    const int m0 = blockIdx.y * 32 * MT;
+    const int n = blockIdx.y;
+    const int m0 = blockIdx.z * 32;
     const long xbase_n = (long)n * p.Di * p.Hi * p.Wi;
-    for (int pos = tid; pos < P; pos += 256) {
-        const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-        const int iz = lz0 + pz - 1, iy = ly0 + py - 1, ix = lx0 + px - 1;
-        half_t val = 0;
-        if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-            val = p.x[xbase_n + ((long)iz * p.Hi + iy) * p.Wi + ix];
-        xl[pos] = val;
-    }
     const int v = lane & 31, hk = lane >> 5;
     // weight fragments straight from global (tiny, L2 resident)
-    half8 a[MT][2];
+    half8 a[2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int k16 = 0; k16 < 2; ++k16) {
-            const int m = m0 + mt * 32 + v;
-            half8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (m < p.Mpad) val = *reinterpret_cast<const half8*>(p.wp + lnn_panel_off(0, m, k16 * 16 + hk * 8, 1, 32));
-            a[mt][k16] = val;
-        }
+    for (int k16 = 0; k16 < 2; ++k16) a[k16] = *reinterpret_cast<const half8*>(p.wp + lnn_panel_off(0, m0 + v, k16 * 16 + hk * 8, 1, 32));
     // tap offsets of this lane's 16 contraction slots
     int toff[2][8];
 #pragma unroll
@@ -246,41 +235,107 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const ConvParams p) {
             const int kc = k16 * 16 + hk * 8 + j;
             toff[k16][j] = kc < 27 ? ((kc / 9) * PY + (kc / 3) % 3) * PX + kc % 3 : 0;
         }
-    __syncthreads();
+    float bv[16];
 #pragma unroll
-    for (int vt = 0; vt < VT; ++vt) {
-        const int tile = wave * VT + vt;
-        const int z = tile / (TY / 4), y = (tile % (TY / 4)) * 4 + (v >> 3), x = v & 7;
-        const int base = (z * PY + y) * PX + x;
-        floatx16 acc[MT];
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r >> 2) * 8 + hk * 4 + (r & 3);
+        bv[r] = (p.bias && m < p.M) ? p.bias[m] : 0.f;
+    }
+    float ssum[16], ssq[16];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.f;
+
+    half_t pre[NL];
+    auto fetch = [&](int t) {
+        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tz = t / (p.tiles_x * p.tiles_y);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-#pragma unroll
-        for (int k16 = 0; k16 < 2; ++k16) {
-            half8 b;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = xl[base + toff[k16][j]];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][k16], b, acc[mt], 0, 0, 0);
+        for (int i = 0; i < NL; ++i) {
+            const int pos = tid + i * 256;
+            const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
+            const int iz = tz * TZ + pz - 1, iy = ty * TY + py - 1, ix = tx * TX + px - 1;
+            half_t val = 0;
+            if (pos < P && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                val = p.x[xbase_n + ((long)iz * p.Hi + iy) * p.Wi + ix];
+            pre[i] = val;
         }
-        const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
-        if (lz >= p.Do || ly >= p.Ho || lx >= p.Wo) continue;
-        half_t* yrow = p.y + ((((long)n * p.Do + lz) * p.Ho + ly) * p.Wo + lx) * p.ld_y;
+    };
+    int t = blockIdx.x;
+    if (t < tiles_per_sample) fetch(t);
+    for (; t < tiles_per_sample; t += gridDim.x) {
+        __syncthreads();                      // every wave is done reading the previous tile
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int i = 0; i < NL; ++i)
+            if (tid + i * 256 < P) xl[tid + i * 256] = pre[i];
+        __syncthreads();
+        if (t + (int)gridDim.x < tiles_per_sample) fetch(t + gridDim.x);
+        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tz = t / (p.tiles_x * p.tiles_y);
+        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
+#pragma unroll 1
+        for (int vt = 0; vt < VT; ++vt) {      // not unrolled: keeps the STATS variant at three blocks per CU
+            const int tile = wave * VT + vt;
+            const int z = tile / (TY / 4), y = (tile % (TY / 4)) * 4 + (v >> 3), x = v & 7;
+            const int base = (z * PY + y) * PX + x;
+            floatx16 acc;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + mt * 32 + q * 8 + hk * 4;
-                if (m >= p.M) continue;
-                floatx4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *reinterpret_cast<const floatx4*>(p.bias + m);
-                half4 o = {(half_t)(acc[mt][q * 4 + 0] + bv[0]), (half_t)(acc[mt][q * 4 + 1] + bv[1]),
-                           (half_t)(acc[mt][q * 4 + 2] + bv[2]), (half_t)(acc[mt][q * 4 + 3] + bv[3])};
-                *reinterpret_cast<half4*>(yrow + m) = o;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int k16 = 0; k16 < 2; ++k16) {
+                half8 b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = xl[base + toff[k16][j]];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k16], b, acc, 0, 0, 0);
             }
+            const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
+            const bool ok = lz < p.Do && ly < p.Ho && lx < p.Wo;
+            half_t* yrow = p.y + ((((long)n * p.Do + (ok ? lz : 0)) * p.Ho + (ok ? ly : 0)) * p.Wo + (ok ? lx : 0)) * p.ld_y;
+            half_t r[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = (half_t)(acc[i] + bv[i]);
+            if constexpr (STATS) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float f = ok ? (float)r[i] : 0.f;
+                    ssum[i] += f;
+                    ssq[i] = __builtin_fmaf(f, f, ssq[i]);
+                }
+            }
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                // quads 2 qp (vdst) and 2 qp + 1 (src): lanes < 32 end with channels 8 (2 qp) .. +7, lanes >= 32 with 8 (2 qp + 1) .. +7
+                const int q0 = 2 * qp * 4, q1 = (2 * qp + 1) * 4;
+                const half2v a0 = {r[q0 + 0], r[q0 + 1]}, a1 = {r[q0 + 2], r[q0 + 3]};
+                const half2v b0 = {r[q1 + 0], r[q1 + 1]}, b1 = {r[q1 + 2], r[q1 + 3]};
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+                const c1_uint4 o = {s0[0], s1[0], s0[1], s1[1]};
+                const int m = m0 + (2 * qp + hk) * 8;
+                if (ok && m < p.M) *reinterpret_cast<c1_uint4*>(yrow + m) = o;
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // butterfly over the 32 voxel lanes of each half-wave, then over the 4 waves through LDS; threads 0..63 write the row
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { ssum[i] += __shfl_xor(ssum[i], o, 64); ssq[i] += __shfl_xor(ssq[i], o, 64); }
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = (i >> 2) * 8 + hk * 4 + (i & 3);
+                sred[(wave * 2 + 0) * 32 + c] = ssum[i];
+                sred[(wave * 2 + 1) * 32 + c] = ssq[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int aidx = tid >> 5, c = tid & 31;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += sred[(w * 2 + aidx) * 32 + c];
+            if (m0 + c < p.M)
+                p.stats_pws[(((long)aidx * gridDim.x + blockIdx.x) * gridDim.y + n) * p.M + m0 + c] = tot;
+        }
     }
 }
 
@@ -464,8 +519,19 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         LNN_REQUIRE(x != nullptr, "lnn_conv3d_fwd: null x");
         p.KCpad = 32;
         p.tiles_z = lnn_cdiv(p.Ld, 4); p.tiles_y = lnn_cdiv(p.Lh, 8); p.tiles_x = lnn_cdiv(p.Lw, 8);
-        dim3 grid((unsigned)((long)N * p.tiles_z * p.tiles_y * p.tiles_x), (unsigned)lnn_cdiv(K, 32));
-        hipLaunchKernelGGL((conv_c1_fwd_kernel<4, 8, 1>), grid, dim3(256), 0, s, p);
+        const int tps = p.tiles_z * p.tiles_y * p.tiles_x;
+        int nb = 768 / N;                                  // x N samples: three resident 4-wave blocks per CU on 256 CUs
+        if (nb < 1) nb = 1;
+        if (nb > tps) nb = tps;
+        dim3 grid((unsigned)nb, (unsigned)N, (unsigned)lnn_cdiv(K, 32));
+        if (stats_pws && ld_y == K) {
+            p.stats_pws = stats_pws;
+            p.stats_nblk = nb;
+            hipLaunchKernelGGL((conv_c1_fwd_kernel<true>), grid, dim3(256), 0, s, p, tps);
+            *stats_slots = nb;
+        } else {
+            hipLaunchKernelGGL((conv_c1_fwd_kernel<false>), grid, dim3(256), 0, s, p, tps);
+        }
         LNN_CHECK_LAUNCH("lnn_conv3d_fwd(C=1)");
         return LNN_OK;
     }

@@ -384,6 +384,256 @@ __global__ void in_lrelu_bwd_finalize_kernel(const double* ws, const float* pws,
     if (dbias) atomicAdd(dbias + c, (float)(db * unscale));
 }
 
+// ---- decoder blocks that feed a seg_outputs head: 1x1x1-head backward + InstanceNorm/LeakyReLU backward without dL/dz in HBM ----
+// The unfused plan runs lnn_seg1x1_bwd (reads z, writes dz), then the two passes above (each reads dz and y): at the top
+// level dz and z are 0.63 GB tensors while dlogits is 0.12 GB.  Here both passes rebuild what they need in registers:
+//   dz  = [prior dz, written by the transposed conv of the level above] + fp16( sum_k dlogits[k] w[k][c] )
+//   z   = fp16( lrelu(y * gamma*rstd + beta - mean*gamma*rstd) )   -- the forward pass's own expression, for d(seg w)
+// so pass 1 reads y (+ prior) + dlogits and pass 2 the same, writing dy over y.  Rounding points are those of the unfused
+// kernels (dz and z pass through fp16); lrelu' is taken at the forward expression t = y*sc + sh instead of gamma*xhat + beta
+// (equal up to fp32 rounding, i.e. except for |t| ~ 1e-7).  K <= 4 (compile-time K: the per-thread weight / partial arrays).
+template <int KT>
+__device__ __forceinline__ void seg_dz(const float (&d)[KT], const float (&wr)[KT][8], const half8* prior, half8& dzh) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float o = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) o += d[k] * wr[k][e];
+        if (prior) o += (float)(*prior)[e];
+        dzh[e] = (half_t)o;
+    }
+}
+
+// The K dlogits of a voxel.  QUAD (C % 32 == 0: the four lanes of a quad always hold octets of the SAME voxel): lane j of the
+// quad loads channel j, the others get it through a DPP quad broadcast -- one 4-byte load per voxel and thread instead of K.
+template <int KT, bool QUAD>
+struct DlFetch {
+    float raw[QUAD ? 1 : KT];
+    __device__ __forceinline__ void load(const float* __restrict__ dln, long V, long v) {
+        if constexpr (QUAD) {
+            const int kq = (int)(threadIdx.x & 3);
+            raw[0] = dln[(long)(kq < KT ? kq : KT - 1) * V + v];
+        } else {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) raw[k] = dln[(long)k * V + v];
+        }
+    }
+    __device__ __forceinline__ void get(float (&d)[KT]) const {
+        if constexpr (QUAD) {
+            const int r = __builtin_bit_cast(int, raw[0]);
+            d[0] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(r, 0x00, 0xf, 0xf, true));
+            if constexpr (KT > 1) d[1] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(r, 0x55, 0xf, 0xf, true));
+            if constexpr (KT > 2) d[2] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(r, 0xaa, 0xf, 0xf, true));
+            if constexpr (KT > 3) d[3] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(r, 0xff, 0xf, 0xf, true));
+        } else {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) d[k] = raw[k];
+        }
+    }
+};
+
+// pass 1: s1 = sum g, s2 = sum g * xhat (as in_lrelu_bwd_reduce_kernel) and the head's weight-gradient partials
+// pws layout: [2][nblk][N][C] (s1, s2) then [N][nblk][KT][C] (d seg_w)
+template <int KT, bool PRIOR, bool QUAD>
+__global__ __launch_bounds__(NT, (KT <= 3 && !PRIOR && QUAD) ? 3 : 2) void in_lrelu_seg_bwd_reduce_kernel(const half_t* __restrict__ y, const half_t* __restrict__ dzp,
+                                                                     int ld_dz, long V, int C, const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, float slope,
+                                                                     const float* __restrict__ segw, const float* __restrict__ dl,
+                                                                     float* pws) {
+    constexpr int NA = 2 + KT;
+    __shared__ float red[NT * 17];
+    const RowMap rm = row_map(C);
+    const int n = blockIdx.y;
+    float part[NA][8];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[a][e] = 0.f;
+    if (rm.active) {
+        float rs[8], nmr[8], sc[8], sh[8], wr[KT][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = rm.c8 * 8 + e;
+            rs[e] = rstd[n * C + c];
+            nmr[e] = -mean[n * C + c] * rs[e];
+            sc[e] = gamma[c] * rs[e];
+            sh[e] = beta[c] - mean[n * C + c] * sc[e];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) wr[k][e] = segw[k * C + c];
+        }
+        const half_t* yp = y + (long)n * V * C + rm.c8 * 8;
+        const half_t* dp = dzp + (long)n * V * ld_dz + rm.c8 * 8;
+        const float* dln = dl + (long)n * KT * V;
+        auto accum = [&](const half8& x, const half8& pr, const float (&d)[KT]) {
+            half8 dzh;
+            seg_dz<KT>(d, wr, PRIOR ? &pr : nullptr, dzh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xf = (float)x[e];
+                const float t = xf * sc[e] + sh[e];
+                const bool pos = t > 0.f;
+                const float zf = (float)(half_t)(pos ? t : t * slope);
+                const float xh = xf * rs[e] + nmr[e];
+                const float g = (float)dzh[e] * (pos ? 1.f : slope);
+                part[0][e] += g;
+                part[1][e] += g * xh;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) part[2 + k][e] += d[k] * zf;
+            }
+        };
+        const long end = vrange_end(V, rm), step = rm.VPB;
+        long v = vrange_begin(V, rm) + rm.vl;
+        // voxels in flight per thread: this pass keeps ~100 registers of sums / constants (3 waves per SIMD), so the bytes in
+        // flight have to come from the loop: 3 x 16 B of y (+ one 4-byte dlogit each) per thread; a 4th would cost the third wave
+        constexpr int U2 = (PRIOR || !QUAD) ? UNR / 2 : 3;
+        for (; v + (U2 - 1) * step < end; v += U2 * step) {
+            half8 x[U2], pr[U2];
+            DlFetch<KT, QUAD> df[U2];
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+                if (PRIOR) pr[u] = *reinterpret_cast<const half8*>(dp + (v + u * step) * ld_dz);
+                df[u].load(dln, V, v + u * step);
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                float d[KT];
+                df[u].get(d);
+                accum(x[u], pr[u], d);
+            }
+        }
+        for (; v < end; v += step) {
+            half8 pr;
+            float d[KT];
+            DlFetch<KT, QUAD> df;
+            if (PRIOR) pr = *reinterpret_cast<const half8*>(dp + v * ld_dz);
+            df.load(dln, V, v);
+            df.get(d);
+            accum(*reinterpret_cast<const half8*>(yp + v * C), pr, d);
+        }
+    }
+    float* const pseg = pws + 2l * gridDim.x * gridDim.y * C;
+    // the block reduction two accumulators at a time through the 17-float rows of `red` (LDS stays at 17 KB per block)
+#pragma unroll
+    for (int a0 = 0; a0 < NA; a0 += 2) {
+        float two[2][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            two[0][e] = part[a0][e];
+            two[1][e] = a0 + 1 < NA ? part[a0 + 1 < NA ? a0 + 1 : a0][e] : 0.f;
+        }
+        block_channel_reduce<2>(rm, C, two, red, [&](int a, int c, float s) {
+            const int aa = a0 + a;
+            if (aa < 2) pws[(((long)aa * gridDim.x + blockIdx.x) * gridDim.y + n) * C + c] = s;
+            else if (aa < NA) pseg[(((long)n * gridDim.x + blockIdx.x) * KT + (aa - 2)) * C + c] = s;
+        });
+    }
+}
+
+// blocks [0, nb_in): the (n, c) totals of pass 1 (= in_lrelu_bwd_sums_kernel); blocks [nb_in, ..): d seg_w[k][c] += unscale * total
+__global__ void in_lrelu_seg_bwd_sums_kernel(const float* pws, int nblk, int N, int C, int K, int nb_in, double* ws, float* dgamma,
+                                             float* dbeta, float* dsegw, float unscale) {
+    __shared__ double red[256];
+    const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    if ((int)blockIdx.x < nb_in) {
+        const int NC = N * C;
+        const int i = blockIdx.x * 16 + ii;
+        const double s0 = sum_partials(pws, 0, nblk, NC, red), s1 = sum_partials(pws, 1, nblk, NC, red);
+        if (i >= NC || sl != 0) return;
+        ws[(long)i * 3 + 0] = s0;
+        ws[(long)i * 3 + 1] = s1;
+        if (dgamma) atomicAdd(dgamma + i % C, (float)(s1 * unscale));
+        if (dbeta) atomicAdd(dbeta + i % C, (float)(s0 * unscale));
+        return;
+    }
+    const float* pseg = pws + 2l * nblk * N * C;
+    const int i = (blockIdx.x - nb_in) * 16 + ii;          // entry k * C + c; partial b of it sits at pseg[b * K * C + i]
+    double s = 0;
+    if (i < K * C)
+        for (int b = sl; b < nblk * N; b += 16) s += (double)pseg[(long)b * K * C + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && i < K * C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + ii];
+        dsegw[i] += (float)(s * unscale);
+    }
+}
+
+// pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V) over y, dz rebuilt as in pass 1
+template <int KT, bool PRIOR, bool QUAD>
+__global__ __launch_bounds__(NT) void in_lrelu_seg_bwd_apply_kernel(half_t* __restrict__ y, const half_t* __restrict__ dzp, int ld_dz,
+                                                                    long V, int C, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float slope,
+                                                                    const float* __restrict__ segw, const float* __restrict__ dl,
+                                                                    const double* ws) {
+    const RowMap rm = row_map(C);
+    if (!rm.active) return;
+    const int n = blockIdx.y;
+    // dy = sc * (g - m1 - xhat * m2) with xhat = y * rs - mean * rs, regrouped per channel as  sc * g + (ca + y * cb):
+    // four constants per channel instead of six (this pass sits at the 128-register / 4-waves-per-SIMD boundary)
+    float sc[8], sh[8], ca[8], cb[8], wr[KT][8];
+    const float invV = 1.0f / (float)V;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = rm.c8 * 8 + e;
+        const float rs = rstd[n * C + c], nmr = -mean[n * C + c] * rs;
+        const float m1 = (float)(ws[((long)n * C + c) * 3 + 0] * (double)invV);
+        const float m2 = (float)(ws[((long)n * C + c) * 3 + 1] * (double)invV);
+        sc[e] = gamma[c] * rs;
+        sh[e] = beta[c] - mean[n * C + c] * sc[e];
+        ca[e] = -sc[e] * (m1 + nmr * m2);
+        cb[e] = -sc[e] * rs * m2;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) wr[k][e] = segw[k * C + c];
+    }
+    half_t* yp = y + (long)n * V * C + rm.c8 * 8;
+    const half_t* dp = dzp + (long)n * V * ld_dz + rm.c8 * 8;
+    const float* dln = dl + (long)n * KT * V;
+    auto grad = [&](const half8& x, const half8& pr, const float (&d)[KT]) {
+        half8 dzh, o;
+        seg_dz<KT>(d, wr, PRIOR ? &pr : nullptr, dzh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xf = (float)x[e];
+            const float t = xf * sc[e] + sh[e];
+            const float g = (float)dzh[e] * (t > 0.f ? 1.f : slope);
+            o[e] = (half_t)(sc[e] * g + (xf * cb[e] + ca[e]));
+        }
+        return o;
+    };
+    const long end = vrange_end(V, rm), step = rm.VPB;
+    long v = vrange_begin(V, rm) + rm.vl;
+    constexpr int U2 = UNR / 2;
+    for (; v + (U2 - 1) * step < end; v += U2 * step) {
+        half8 x[U2], pr[U2];
+        DlFetch<KT, QUAD> df[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+            if (PRIOR) pr[u] = *reinterpret_cast<const half8*>(dp + (v + u * step) * ld_dz);
+            df[u].load(dln, V, v + u * step);
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            float d[KT];
+            df[u].get(d);
+            *reinterpret_cast<half8*>(yp + (v + u * step) * C) = grad(x[u], pr[u], d);
+        }
+    }
+    for (; v < end; v += step) {
+        half8 pr;
+        float d[KT];
+        DlFetch<KT, QUAD> df;
+        if (PRIOR) pr = *reinterpret_cast<const half8*>(dp + v * ld_dz);
+        df.load(dln, V, v);
+        df.get(d);
+        *reinterpret_cast<half8*>(yp + v * C) = grad(*reinterpret_cast<const half8*>(yp + v * C), pr, d);
+    }
+}
+
 int blocks_for(long V, int C) {
     const int vpb = NT / (C / 8);
     long b = (V + (long)vpb * 8 - 1) / ((long)vpb * 8);  // ~8 passes per block
@@ -483,5 +733,46 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
                            rstd, gamma, beta, slope, ws, pws);
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
     }
+    return LNN_OK;
+}
+
+// [N*C*3 doubles: s1, s2, (unused)] [fp32 per-block partials: 2 * MAX_BLOCKS * N * C (s1, s2) + MAX_BLOCKS * N * 4 * C (d seg_w)]
+extern "C" size_t lnn_instnorm_lrelu_seg_bwd_ws_doubles(int N, int C) { return (size_t)N * C * 3 + (size_t)MAX_BLOCKS * N * C * 3; }
+
+extern "C" int lnn_instnorm_lrelu_seg_bwd(lnn_stream_t s_, void* y, const void* dz_prior, int ld_dz, const float* seg_w,
+                                          const float* dlogits, float* seg_dw, int K, int N, long V, int C, const float* mean,
+                                          const float* rstd, const float* gamma, const float* beta, float slope, float* dgamma,
+                                          float* dbeta, float grad_unscale, double* ws) {
+    hipStream_t s = (hipStream_t)s_;
+    if (int e = check_common(y, N, V, C, "lnn_instnorm_lrelu_seg_bwd")) return e;
+    LNN_REQUIRE(dz_prior == nullptr || (lnn_aligned16(dz_prior) && ld_dz >= C && ld_dz % 8 == 0),
+                "lnn_instnorm_lrelu_seg_bwd: bad dz_prior / ld_dz");
+    LNN_REQUIRE(mean && rstd && gamma && beta && ws && seg_w && dlogits && seg_dw, "lnn_instnorm_lrelu_seg_bwd: null parameter");
+    LNN_REQUIRE(K >= 1 && K <= 4, "lnn_instnorm_lrelu_seg_bwd: K=%d unsupported (1..4): use lnn_seg1x1_bwd + lnn_instnorm_lrelu_bwd", K);
+    float* pws = reinterpret_cast<float*>(ws + (size_t)N * C * 3);
+    const int nblk = blocks_for(V, C);
+    const dim3 grid(nblk, N);
+    const half_t* pr = (const half_t*)dz_prior;
+    const int nb_in = lnn_cdiv(N * C, 16);
+#define LNN_SB(KT, PRIOR) do { if (C % 32 == 0) LNN_SBQ(KT, PRIOR, true); else LNN_SBQ(KT, PRIOR, false); } while (0)
+#define LNN_SBQ(KT, PRIOR, QUAD)                                                                                                     \
+    do {                                                                                                                             \
+        hipLaunchKernelGGL((in_lrelu_seg_bwd_reduce_kernel<KT, PRIOR, QUAD>), grid, dim3(NT), 0, s, (const half_t*)y, pr, ld_dz, V, C, \
+                           mean, rstd, gamma, beta, slope, seg_w, dlogits, pws);                                                     \
+        LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_bwd(reduce)");                                                                      \
+        hipLaunchKernelGGL(in_lrelu_seg_bwd_sums_kernel, dim3(nb_in + lnn_cdiv(K * C, 16)), dim3(256), 0, s, pws, nblk, N, C, K,     \
+                           nb_in, ws, dgamma, dbeta, seg_dw, grad_unscale);                                                          \
+        LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_bwd(sums)");                                                                        \
+        hipLaunchKernelGGL((in_lrelu_seg_bwd_apply_kernel<KT, PRIOR, QUAD>), grid, dim3(NT), 0, s, (half_t*)y, pr, ld_dz, V, C, mean, \
+                           rstd, gamma, beta, slope, seg_w, dlogits, ws);                                                            \
+        LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_bwd(apply)");                                                                       \
+    } while (0)
+    if (pr) {
+        if (K == 1) LNN_SB(1, true); else if (K == 2) LNN_SB(2, true); else if (K == 3) LNN_SB(3, true); else LNN_SB(4, true);
+    } else {
+        if (K == 1) LNN_SB(1, false); else if (K == 2) LNN_SB(2, false); else if (K == 3) LNN_SB(3, false); else LNN_SB(4, false);
+    }
+#undef LNN_SB
+#undef LNN_SBQ
     return LNN_OK;
 }

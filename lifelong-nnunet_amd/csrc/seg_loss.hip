@@ -266,7 +266,7 @@ __device__ void dice_ce_loss_from_totals(const double* ws, int N, int K, long V,
 
 // one 256-thread block: totals of the per-block partials (fp64), then the loss
 __global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nblk, int N, int K, long V, int batch_dice,
-                                                              float smooth, float* out) {
+                                                              float smooth, float* out, float weight, float* total, int accumulate) {
     __shared__ double red[NT];
     constexpr int W = 3 * KMAX + 1;
     const float* pws = reinterpret_cast<const float*>(ws + (long)N * K * 3 + 2);
@@ -291,6 +291,8 @@ __global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nb
     if (threadIdx.x != 0) return;
     ws[(long)N * K * 3] = ce_sum;
     dice_ce_loss_from_totals(ws, N, K, V, batch_dice, smooth, out);
+    // deep supervision: total (+)= weight * loss of this level (launches of one stream are ordered: plain read-modify-write)
+    if (total) total[0] = (accumulate ? total[0] : 0.f) + weight * out[0];
 }
 
 // the loss again after the caller changed the totals (data-parallel batch Dice: tp/fp/fn summed over the ranks)
@@ -608,8 +610,8 @@ extern "C" int lnn_seg1x1_bwd(lnn_stream_t s_, const void* z, int ld_z, const fl
 // totals [N*K*3 + 2] + fp32 per-block partials [N][<=1024 blocks][3*KMAX+1]
 extern "C" size_t lnn_dice_ce_ws_doubles(int N, int K) { return (size_t)N * K * 3 + 2 + ((size_t)N * 1024 * (3 * KMAX + 1) + 1) / 2; }
 
-extern "C" int lnn_dice_ce_fwd(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
-                               int batch_dice, float smooth, float* out_loss, double* ws) {
+static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* labels, int N, int K, long V,
+                            int batch_dice, float smooth, float* out_loss, double* ws, float weight, float* total, int accumulate) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(logits && labels && out_loss && ws, "lnn_dice_ce_fwd: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
@@ -620,9 +622,22 @@ extern "C" int lnn_dice_ce_fwd(lnn_stream_t s_, const float* logits, const float
     else { if (K == 3) LNN_DCE_FWD(3, 1); else if (K == 2) LNN_DCE_FWD(2, 1); else if (K == 4) LNN_DCE_FWD(4, 1); else LNN_DCE_FWD(0, 1); }
 #undef LNN_DCE_FWD
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd");
-    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(NT), 0, s, ws, nblk, N, K, V, batch_dice, smooth, out_loss);
+    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(NT), 0, s, ws, nblk, N, K, V, batch_dice, smooth, out_loss, weight,
+                       total, accumulate);
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd(finalize)");
     return LNN_OK;
+}
+
+extern "C" int lnn_dice_ce_fwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
+                               int batch_dice, float smooth, float* out_loss, double* ws) {
+    return dice_ce_fwd_impl(s, logits, labels, N, K, V, batch_dice, smooth, out_loss, ws, 0.f, nullptr, 0);
+}
+
+extern "C" int lnn_dice_ce_fwd_ds(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
+                                  int batch_dice, float smooth, float* out_loss, double* ws, float weight, float* total,
+                                  int accumulate) {
+    LNN_REQUIRE(total != nullptr, "lnn_dice_ce_fwd_ds: null total");
+    return dice_ce_fwd_impl(s, logits, labels, N, K, V, batch_dice, smooth, out_loss, ws, weight, total, accumulate);
 }
 
 extern "C" int lnn_dice_ce_loss_from_totals(lnn_stream_t s_, const double* ws, int N, int K, long V, int batch_dice, float smooth,

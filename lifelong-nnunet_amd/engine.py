@@ -341,7 +341,8 @@ class UNetEngine:
         self._unpack_desc = torch.tensor(up, dtype=torch.int64, device=dev)
         self._pack_total, self._unpack_total = pk_total, up_total
         cmax = max(2 * f for f in feats)
-        ws_doubles = max(nat.query("lnn_instnorm_ws_doubles", N, cmax), (nat.query("lnn_seg1x1_bwd_ws_floats", N, cmax) + 1) // 2, 64)
+        ws_doubles = max(nat.query("lnn_instnorm_ws_doubles", N, cmax), (nat.query("lnn_seg1x1_bwd_ws_floats", N, cmax) + 1) // 2,
+                         nat.query("lnn_instnorm_lrelu_seg_bwd_ws_doubles", N, max(seg.cin for seg in self.segs)), 64)
         self.ws = torch.zeros(ws_doubles, dtype=torch.float64, device=dev)
         # fp32 split-K scratch of the small deep layers (see lnn_conv3d_dgrad_ws): 8 slices of the largest
         # [N][voxels][roundup32(channels)] among the stride-1 layers with fewer than 512 (8x8x8 x 32-channel) units
@@ -359,7 +360,7 @@ class UNetEngine:
         self.packed_version = -1
         self.unused_heads: List[str] = []
         self._side = None
-        self._lstreams, self._lws = [], []
+        self._lstreams, self._lws, self._lsplitk = [], [], []
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
@@ -369,14 +370,30 @@ class UNetEngine:
         self.fuse_seg_fwd = os.environ.get("LNN_NO_FUSED_SEG", "0") != "1"           # A/B switch (measurements only)
         self.numeric_conv_bias_grad = os.environ.get("LNN_NUMERIC_CONV_BIAS_GRAD", "0") == "1"
         self.fuse_in_stats = os.environ.get("LNN_NO_FUSED_IN_STATS", "0") != "1"     # A/B switch (measurements only)
+        # seg head backward folded into the InstanceNorm backward of the block that feeds it (dL/dz never written): A/B switch
+        self.fuse_seg_bwd = os.environ.get("LNN_NO_FUSED_SEG_BWD", "0") != "1"
         # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
         # little room), kept because it is the natural hook for per-sample pipelining across GPUs / larger batches
         self.sample_lanes = os.environ.get("LNN_SAMPLE_LANES", "0") == "1"
+        # measurement hook (bench.py): {"layer": <block prefix>} -> the forward conv / data-gradient / weight-gradient calls of
+        # that block are bracketed with timing events ON THE STREAM THEY LAUNCH ON, appended to probe["fwd" | "dgrad" | "wgrad"]
+        self.probe = None
         # arena offset right after each item's parameter slots (= start of the next item's slots)
         self._watermark = {}
         for item in order:
             slots = [s for s in (getattr(item, a, None) for a in ("w", "b", "gamma", "beta")) if s is not None]
             self._watermark[id(item)] = max(s.offset + (s.numel + 3) // 4 * 4 for s in slots)
+
+    def _probed(self, kind, item, fn):
+        pr = self.probe
+        if pr is None or pr.get("layer") != item.prefix:
+            fn()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        pr.setdefault(kind, []).append((e0, e1))
 
     # ------------------------------------------------------------------------------------------ views
     def pview(self, slot: ParamSlot, arena=None):
@@ -415,6 +432,8 @@ class UNetEngine:
         while len(self._lstreams) < n:
             self._lstreams.append(torch.cuda.Stream(device=self.device))
             self._lws.append(torch.zeros_like(self.ws))
+            # every lane runs on its own stream: the split-K scratch of the small deep layers must not be shared either
+            self._lsplitk.append(self.splitk_ws if not self._lsplitk else torch.zeros_like(self.splitk_ws))
         return self._lstreams[:n]
 
     @staticmethod
@@ -425,19 +444,19 @@ class UNetEngine:
         return obj[n0:]
 
     def _fork(self, fn):
-        """Run fn(n0, nn, ws) for every lane; lanes beyond the first on their own stream, joined before returning."""
+        """Run fn(n0, nn, ws, splitk_ws) for every lane (workspaces are per lane); lanes beyond the first on their own stream, joined before returning."""
         lanes = self._lanes()
         if len(lanes) == 1:
-            fn(0, self.N, self.ws)
+            fn(0, self.N, self.ws, self.splitk_ws)
             return
         main = torch.cuda.current_stream()
         streams = self._lane_streams(len(lanes))
         ev = torch.cuda.Event()
         ev.record(main)
-        for (n0, nn), st, ws in zip(lanes, streams, self._lws):
+        for (n0, nn), st, ws, sk in zip(lanes, streams, self._lws, self._lsplitk):
             st.wait_event(ev)
             with torch.cuda.stream(st):
-                fn(n0, nn, ws)
+                fn(n0, nn, ws, sk)
         for st in streams:
             main.wait_stream(st)
 
@@ -457,7 +476,7 @@ class UNetEngine:
         sw = None if seg_weights is None else [w.contiguous() for w in seg_weights]
         at = self._at
 
-        def lane(n0, nn, ws):
+        def lane(n0, nn, ws, splitk_ws):
             u = 0
             fused_segs = set()
             for item in self.order:
@@ -470,12 +489,13 @@ class UNetEngine:
                     C = item.cout
                     V = item.z.V
                     mean, rstd = item.mean[n0 * C:], item.rstd[n0 * C:]
-                    if item.x is not None and self.fuse_in_stats:
+                    if self.fuse_in_stats:
                         # conv + InstanceNorm statistics in one call (the z-streaming kernel sums in its epilogue)
-                        nat.call("lnn_conv3d_fwd_in_stats", xin, None if item.x2 is None else at(item.x2, n0), ldx,
-                                 item.x.C if item.x2 is not None else 0, self._wp(item.wp_fwd), self.pview(item.b),
-                                 at(item.y, n0), nn, D, H, W, item.cin, C, item.stride, IN_EPS, mean, rstd, ws,
-                                 self.splitk_ws, self.splitk_ws.numel())
+                        self._probed("fwd", item, lambda: nat.call(
+                            "lnn_conv3d_fwd_in_stats", xin, None if item.x2 is None else at(item.x2, n0), ldx,
+                            item.x.C if item.x2 is not None else 0, self._wp(item.wp_fwd), self.pview(item.b),
+                            at(item.y, n0), nn, D, H, W, item.cin, C, item.stride, IN_EPS, mean, rstd, ws,
+                            splitk_ws, splitk_ws.numel()))
                     else:
                         if item.x2 is not None:
                             nat.call("lnn_conv3d_fwd_cat", xin, at(item.x2, n0), ldx, item.x.C, self._wp(item.wp_fwd),
@@ -546,6 +566,8 @@ class UNetEngine:
         dls = [None if dl is None else dl.contiguous() for dl in dlogits]
         at = self._at
         multi = len(self._lanes()) > 1
+        assert not (multi and self.deterministic_wgrad), \
+            "deterministic_wgrad keeps ONE ordered-reduction scratch: not available with LNN_SAMPLE_LANES=1 (two streams)"
         # Weight gradients are off the critical path of backward (they only have to be final before the optimiser /
         # the all-reduce).  Single lane: they go to a SIDE HIP stream right after the layer's dL/dy exists; two lanes:
         # each lane already overlaps the other, both accumulate into the same fp32 panels (atomics) and the panels
@@ -582,19 +604,27 @@ class UNetEngine:
                 C, K = item.cin, item.cout
                 nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), 8, C, K, K * 8, 8, 1, 1.0, 1)
 
-        def lane(n0, nn, ws):
+        fuse_seg = self.fuse_seg_bwd and not skip_body and not self.numeric_conv_bias_grad and self.K <= 4
+
+        def lane(n0, nn, ws, splitk_ws):
             seg_u = len(self.segs)
+            pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
             for item in reversed(self.order):
                 if progress is not None and not multi and item is not self.order[-1]:
                     # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
-                    # (weight gradients + their unpack) have run what is enqueued so far
-                    progress(self._watermark[id(item)], side)
+                    # (weight gradients + their unpack) have run what is enqueued so far; a head that was deferred into
+                    # this block's call is not final yet: only what lies behind the head is
+                    wm_item = pending[id(item)][0] if id(item) in pending else item
+                    progress(self._watermark[id(wm_item)], side)
                 if isinstance(item, SegHead):
                     seg_u -= 1
                     dl = dls[seg_u]
                     if dl is None:
                         if not item.gx_has_prior:
                             item.gx.buf[n0:n0 + nn].zero_()
+                        continue
+                    if fuse_seg:
+                        pending[id(item.x_block)] = (item, dl)
                         continue
                     gw = self.pview(item.w, self.grad).view(self.K, item.cin)
                     nat.call("lnn_seg1x1_bwd", at(item.x, n0), item.x.ld, self.pview(item.w), dl[n0:], at(item.gx, n0),
@@ -603,15 +633,27 @@ class UNetEngine:
                     continue
                 elif isinstance(item, ConvBlock):
                     V, K, C = item.z.V, item.cout, item.cin
-                    nat.call("lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                             item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
-                             self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
-                             self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws)
+                    if id(item) in pending:
+                        seg, dl = pending.pop(id(item))
+                        nat.call("lnn_instnorm_lrelu_seg_bwd", at(item.y, n0), at(item.gz, n0) if seg.gx_has_prior else None,
+                                 item.gz.ld, self.pview(seg.w), dl[n0:], self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
+                                 nn, V, K, item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta),
+                                 LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws)
+                    else:
+                        nat.call("lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
+                                 item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                                 self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
+                                 self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws)
                     D, H, W = item.in_dims
                     xin = at(self.image, n0) if item.x is None else at(item.x, n0)
                     ldx = 1 if item.x is None else item.x.ld
 
                     def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
+                        self._probed("wgrad", item, lambda: conv_wgrad_call(item, xin, ldx, K, C, D, H, W))
+                        if per_layer_unpack:
+                            unpack(item)
+
+                    def conv_wgrad_call(item, xin, ldx, K, C, D, H, W):
                         det = self._det_scratch()
                         if item.x2 is not None and det is not None:
                             nat.call("lnn_conv3d_wgrad_cat_det", xin, at(item.x2, n0), ldx, item.x.C, at(item.y, n0), K,
@@ -625,16 +667,16 @@ class UNetEngine:
                         else:
                             nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
                                      item.stride)
-                        if per_layer_unpack:
-                            unpack(item)
                     on_side(conv_wgrad)
                     if C != 1 and item.gx is not None and item.gx2 is not None:
-                        nat.call("lnn_conv3d_dgrad_cat", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0),
-                                 at(item.gx2, n0), item.gx.ld, item.gx.C, nn, D, H, W, C, K, 1 if item.gx_accumulate else 0)
+                        self._probed("dgrad", item, lambda: nat.call(
+                            "lnn_conv3d_dgrad_cat", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0),
+                            at(item.gx2, n0), item.gx.ld, item.gx.C, nn, D, H, W, C, K, 1 if item.gx_accumulate else 0))
                     elif C != 1 and item.gx is not None:
-                        nat.call("lnn_conv3d_dgrad_ws", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
-                                 nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0, self.splitk_ws,
-                                 self.splitk_ws.numel())
+                        self._probed("dgrad", item, lambda: nat.call(
+                            "lnn_conv3d_dgrad_ws", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
+                            nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0, splitk_ws,
+                            splitk_ws.numel()))
                 else:  # UpBlock
                     D, H, W = item.x.dims
                     C, K = item.cin, item.cout

@@ -85,6 +85,51 @@ class DC_and_CE_loss(nn.Module):
         return _DiceCEFunction.apply(net_output, target, self.batch_dice, self.smooth, self.process_group)
 
 
+class _DSDiceCEFunction(torch.autograd.Function):
+    """``MultipleOutputLoss2(DC_and_CE_loss)`` as ONE autograd node: sum_i w_i * (CE_i + Dice_i) over the levels with a
+    non-zero weight.  Same kernels as the per-level path; the weighted sum is formed by the levels' finalize launches
+    (``lnn_dice_ce_fwd_ds``) and backward hands every level its weight as the host scalar next to the upstream gradient on
+    the device -- no per-level multiply / add kernels (4 + 4 + 3 launches per step on a 5-level network)."""
+
+    @staticmethod
+    def forward(ctx, batch_dice, smooth, weights, *tensors):
+        L = len(weights)
+        logits, targets = tensors[:L], tensors[L:]
+        dev = logits[0].device
+        total = torch.empty(1, device=dev)
+        saved, cfgs, first = [], [], True
+        for i in range(L):
+            if weights[i] == 0:
+                continue
+            lg = logits[i].contiguous()
+            N, K = lg.shape[:2]
+            V = lg[0, 0].numel()
+            labels = targets[i].reshape(N, V).to(dev, torch.float32).contiguous()
+            ws = torch.empty(nat.query("lnn_dice_ce_ws_doubles", N, K), dtype=torch.float64, device=dev)
+            out = torch.empty(1, device=dev)
+            nat.call("lnn_dice_ce_fwd_ds", lg, labels, N, K, V, int(batch_dice), float(smooth), out, ws, float(weights[i]),
+                     total, 0 if first else 1)
+            first = False
+            saved += [lg, labels, ws]
+            cfgs.append((i, N, K, V))
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (cfgs, int(batch_dice), float(smooth), tuple(float(w) for w in weights), L)
+        return total[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        cfgs, bd, smooth, weights, L = ctx.cfg
+        saved = ctx.saved_tensors
+        gdev = g.reshape(1).float().contiguous()
+        grads = [None] * L
+        for j, (i, N, K, V) in enumerate(cfgs):
+            lg, labels, ws = saved[3 * j:3 * j + 3]
+            dl = torch.empty_like(lg)
+            nat.call("lnn_dice_ce_bwd", lg, labels, N, K, V, bd, smooth, ws, weights[i], gdev, 1.0, dl)
+            grads[i] = dl
+        return (None, None, None) + tuple(grads) + (None,) * L
+
+
 class MultipleOutputLoss2(nn.Module):
     def __init__(self, loss, weight_factors=None):
         super().__init__()
@@ -95,6 +140,11 @@ class MultipleOutputLoss2(nn.Module):
         assert isinstance(x, (tuple, list)), "x must be either tuple or list"
         assert isinstance(y, (tuple, list)), "y must be either tuple or list"
         weights = [1] * len(x) if self.weight_factors is None else self.weight_factors
+        if type(self.loss) is DC_and_CE_loss and weights[0] != 0 and \
+                not (self.loss.batch_dice and _world_size(self.loss.process_group) > 1):
+            # (with a data-parallel batch Dice every level needs its own exchange + recomputed loss: per-level path below)
+            return _DSDiceCEFunction.apply(self.loss.batch_dice, self.loss.smooth, tuple(float(w) for w in weights[:len(x)]),
+                                           *x, *y[:len(x)])
         l = weights[0] * self.loss(x[0], y[0])
         for i in range(1, len(x)):
             if weights[i] != 0:          # zero-weight levels are skipped, not multiplied

@@ -167,5 +167,28 @@ class MultiHead_Module(nn.Module):
             "assemble_model(task) + a full forward per head is required for deeper splits".format(task, [n for n, _ in named][:3])
         return [p for _, p in sorted(named, key=lambda kv: int(kv[0].split('.')[1]))]
 
+    def head_is_seg_only(self, task=None):
+        """True when the head holds nothing but the 1x1x1 segmentation layers (split ``seg_outputs``)."""
+        task = self.active_task if task is None else task
+        return all(n.startswith("seg_outputs.") for n, _ in self.heads[str(task)].named_parameters())
+
+    def head_logits(self, task, x):
+        """Full-resolution logits of head ``task`` on ``x`` (eval, identity nonlinearity, no autograd) -- what the reference
+        computes with ``assemble_model(task)`` + a complete forward per head (MHM.py:326-377, LWF.py:317-346, HF.py:239-258).
+        For the ``seg_outputs`` split that is the task's 1x1x1 weights on one body pass; for any other ``--split_at``
+        (run_training.py:103) the head holds body-side layers too, so the head is swapped in, the whole network runs, and
+        the previously active head (and the body's frozen state) are restored."""
+        if self.head_is_seg_only(task):
+            return self.model.forward_heads(x, [self.head_weights(task)])[0]
+        active, frozen = self.active_task, self.body_freezed
+        if str(task) != str(active):
+            self.assemble_model(task, freeze_body=frozen)
+        with torch.no_grad():
+            out = self.class_object.forward(self.model, x)
+        out = out[0] if isinstance(out, (tuple, list)) else out
+        if str(task) != str(active):
+            self.assemble_model(active, freeze_body=frozen)
+        return out.detach()
+
     def get_model_type(self):
         return self.model.__class__.__name__

@@ -49,10 +49,13 @@ SIGNATURES = {
     "lnn_instnorm_lrelu_seg_fwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _i]),
     "lnn_instnorm_lrelu_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _p, _f, _p]),
     "lnn_instnorm_ws_doubles": (_sz, [_i, _i]),
+    "lnn_instnorm_lrelu_seg_bwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _f, _p]),
+    "lnn_instnorm_lrelu_seg_bwd_ws_doubles": (_sz, [_i, _i]),
     "lnn_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),
     "lnn_seg1x1_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _l, _i, _i, _i, _f, _p]),
     "lnn_seg1x1_bwd_ws_floats": (_sz, [_i, _i]),
     "lnn_dice_ce_fwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _f, _p, _p]),
+    "lnn_dice_ce_fwd_ds": (_i, [_p, _p, _p, _i, _i, _l, _i, _f, _p, _p, _f, _p, _i]),
     "lnn_dice_ce_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _f, _p, _f, _p, _f, _p]),
     "lnn_dice_ce_loss_from_totals": (_i, [_p, _p, _i, _i, _l, _i, _f, _p]),
     "lnn_dice_ce_ws_doubles": (_sz, [_i, _i]),

@@ -51,6 +51,17 @@ class GradScaler:
     def scale(self, loss):
         return loss * self._scale if self.enabled else loss
 
+    def backward(self, loss):
+        """``self.scale(loss).backward()`` without the two multiply launches: the scale rides in as the seed gradient."""
+        if not self.enabled:
+            loss.backward()
+            return
+        t = getattr(self, "_seed", None)
+        if t is None or t.device != loss.device or self._seed_value != self._scale:
+            self._seed = t = torch.full((), self._scale, dtype=loss.dtype, device=loss.device)
+            self._seed_value = self._scale
+        loss.backward(gradient=t)
+
     def get_scale(self):
         return self._scale
 
@@ -96,6 +107,7 @@ class FusedSGD:
         self._ctrl_buf = torch.zeros(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=net.arena.theta.device)
         self.ctrl = self._ctrl_buf[:2]
         self._ctrl_valid = False
+        self._ever_stepped = set()       # names the optimiser has stepped at least once (torch creates their momentum_buffer then)
 
     def zero_grad(self, set_to_none=False):
         self.net.arena.grad.zero_()
@@ -123,7 +135,15 @@ class FusedSGD:
                      float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(inv_scale), float(max_norm),
                      self.ctrl)
         self._ctrl_valid = False
+        skip = set(getattr(self.net, "params_without_grad", ())) - set(getattr(self.net, "penalty_grad_names", ()))
+        self._ever_stepped.update(n for n, p in self.net._named if p.requires_grad and n not in skip)
         self.net.mark_params_changed()
+
+    def fetch_with_loss(self, loss):
+        """numpy [sum g^2, #non-finite, loss]: the loss is parked next to the control block (slot 2 is scratch of the norm
+        reduction, free once the step has been enqueued) so that ONE device-to-host copy carries all three."""
+        self._ctrl_buf[2:3].copy_(loss.detach().reshape(1))
+        return self._ctrl_buf[:3].cpu().numpy()
 
     def read_ctrl(self):
         """(total_norm, found_inf) -- ONE host sync; call after the loss has been fetched anyway."""
@@ -137,17 +157,17 @@ class FusedSGD:
     def state_dict(self):
         """``torch.optim.SGD.state_dict()`` layout, so checkpoints interoperate with the reference's trainers
         (upstream ``NetworkTrainer.save_checkpoint`` / ``load_checkpoint_ram``): ``state[i]['momentum_buffer']`` per
-        parameter index, one param group.  A parameter the optimiser never stepped (momentum still all zero AND listed in
-        ``params_without_grad``) has no state entry, as in torch."""
+        parameter index, one param group.  A parameter the optimiser never stepped (e.g. the zero-weight deep-supervision
+        head as long as no penalty term gave it a gradient) has no state entry, as in torch."""
         g = self.param_groups[0]
         named = self._trainable()
-        skip = getattr(self.net, "params_without_grad", ())
         state = {}
         for i, (n, p) in enumerate(named):
-            if n in skip:
-                continue
             s = p._lnn_slot
-            state[i] = {"momentum_buffer": self.net.arena.momentum[s.offset:s.offset + s.numel].view(s.shape).clone()}
+            mom = self.net.arena.momentum[s.offset:s.offset + s.numel]
+            if n not in self._ever_stepped and not bool(mom.any()):      # (a momentum loaded from a checkpoint counts as well)
+                continue
+            state[i] = {"momentum_buffer": mom.view(s.shape).clone()}
         group = {"lr": g["lr"], "momentum": g["momentum"], "dampening": 0, "weight_decay": g["weight_decay"],
                  "nesterov": True, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
                  "params": list(range(len(named)))}
@@ -164,10 +184,12 @@ class FusedSGD:
         for k in ("lr", "momentum", "weight_decay"):
             self.param_groups[0][k] = grp[k]
         self.net.arena.momentum.zero_()
+        self._ever_stepped = set()
         for pos, idx in enumerate(grp["params"]):
             st = d["state"].get(idx)
             if st is None or st.get("momentum_buffer") is None:
                 continue
+            self._ever_stepped.add(named[pos][0])
             s = named[pos][1]._lnn_slot
             self.net.arena.momentum[s.offset:s.offset + s.numel].copy_(
                 st["momentum_buffer"].to(self.net.arena.momentum.device, torch.float32).reshape(-1))

@@ -33,14 +33,12 @@ def calculate_target_logits(mh_network, gen, num_batches_per_epoch, fp16=True, g
     """HF.py:207-266: for each head IN TURN, ``num_batches_per_epoch`` consecutive batches of ``gen`` are
     pushed through body + that head (eval, identity nonlinearity) and the full-resolution logits are kept."""
     target_logits = dict()
-    net = mh_network.model
     for task in list(mh_network.heads.keys()):
-        hw = mh_network.head_weights(task)
         target_logits[task] = list()
         for _ in range(num_batches_per_epoch):
             data_dict = next(gen)
             x = torch.as_tensor(data_dict['data'])
-            target_logits[task].append(net.forward_heads(x, [hw])[0])
+            target_logits[task].append(mh_network.head_logits(task, x))     # any --split_at (full forward for deeper splits)
     return target_logits
 
 
@@ -115,8 +113,11 @@ class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
             for t in heads:
                 if t == str(self.mh_network.active_task):
                     all_pred_logits.append(output[0].detach())
-                else:
+                elif self.mh_network.head_is_seg_only(t):
                     all_pred_logits.append(eng.forward(data, seg_weights=self.mh_network.head_weights(t), body=False)[-1])
+                else:
+                    raise RuntimeError("same_batch_predictions re-uses the body pass of the training forward and needs "
+                                       "split_at='seg_outputs'; other splits run the reference order (one forward per head)")
         self.loss.update_logits(all_pred_logits, self._targets(heads))
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, *args, **kwargs):
@@ -131,9 +132,20 @@ class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
             with torch.no_grad():
                 for t in heads:
                     x = torch.as_tensor(next(data_generator)['data']).to(self.device, non_blocking=True)
-                    preds.append(self.network.forward_heads(x, [self.mh_network.head_weights(t)])[0])
+                    preds.append(self.mh_network.head_logits(t, x))
             self.loss.update_logits(preds, self._targets(heads))
             ret = super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
             next(data_generator)
         self.batch_idx += 1       # LWF.py:364
         return ret
+
+    def _perform_validation(self, *args, **kwargs):
+        """LWF.py ``on_epoch_end``: the reference sets ``do_val = True`` around the per-head validation so that its
+        iterations take the plain branch -- otherwise every validation iteration would consume T + 2 batches of the
+        per-task generator, advance ``batch_idx`` (teacher logits out of step with training) and pair subject names with
+        the wrong batch."""
+        keep, self.do_val = self.do_val, True
+        try:
+            return super()._perform_validation(*args, **kwargs)
+        finally:
+            self.do_val = keep

@@ -223,7 +223,7 @@ class nnUNetTrainerMultiHead:
             if self.dp is not None:
                 self.dp.begin()
                 self.network.on_grad_progress = self.dp.progress
-            self.amp_grad_scaler.scale(l).backward()
+            self.amp_grad_scaler.backward(l)           # = scale(l).backward(), the scale as the seed gradient
             world_avg = 1.0
             if self.dp is not None:
                 self.dp.finish()
@@ -241,10 +241,10 @@ class nnUNetTrainerMultiHead:
             return None
         if detach:
             if do_backprop:
-                vals = torch.cat([l.detach().double().reshape(1), self.optimizer.ctrl]).cpu().numpy()
-                self.last_grad_norm, self.last_found_inf = float(vals[1]) ** 0.5, bool(vals[2] > 0)
+                vals = self.optimizer.fetch_with_loss(l)          # {sum g^2, #non-finite, loss}: one copy launch + one D2H
+                self.last_grad_norm, self.last_found_inf = float(vals[0]) ** 0.5, bool(vals[1] > 0)
                 self.amp_grad_scaler.update(self.last_found_inf)
-                return np.float32(vals[0])
+                return np.float32(vals[2])
             return l.detach().cpu().numpy()
         return l
 
@@ -360,6 +360,71 @@ class nnUNetTrainerMultiHead:
         return predict_3D(self.network, data, do_mirroring=do_mirroring, mirror_axes=tuple(mirror_axes),
                           use_sliding_window=use_sliding_window, step_size=step_size, patch_size=tuple(self.plans["patch_size"]),
                           use_gaussian=use_gaussian, verbose=verbose)
+
+    def validate(self, do_mirroring=True, use_sliding_window=True, step_size=0.5, save_softmax=True, use_gaussian=True,
+                 overwrite=True, validation_folder_name='validation_raw', debug=False, all_in_gpu=False,
+                 segmentation_export_kwargs=None, run_postprocessing_on_folds=True, output_folder=None):
+        """MH.py:1052-1135 (-> upstream ``nnUNetTrainer.validate`` per task): for EVERY head the model holds, in head order,
+        that task's preprocessed dataset is loaded and split, the head is assembled, and every case of the VALIDATION split
+        is predicted as a whole volume by tiled inference (``predict_preprocessed_data_return_seg_and_softmax``: sliding
+        window, Gaussian importance, test-time mirroring); the per-subject summary is the reference evaluator's dictionary
+        (``evaluation.compute_scores_and_build_dict``, evaluator2.py:60-109: IoU / Dice per mask, ``None`` for a class absent
+        from both volumes).  The reference writes NIfTI predictions into ``<output_folder>/<validation_folder_name><task>``
+        and returns a list of ``None``; NIfTI export is out of scope, so with ``output_folder`` the
+        segmentation (and the softmax with ``save_softmax``) of every case goes there as ``<case>.npz`` next to a
+        ``summary.json``, and the returned list holds one ``{'task', 'cases', 'summary'}`` entry per head.  Needs a data
+        provider over preprocessed folders (``dataset_for`` / ``splits_file_for``, dataloading.PreprocessedDataProvider)."""
+        import json
+        import os
+        from ....dataloading import do_split
+        from ....evaluation import compute_scores_and_build_dict, summarize
+        trained_on = list(self.mh_network.heads.keys())
+        assert len(trained_on) != 0, "Before performing any validation, the model needs to be trained on at least one task."
+        prov = self.data_provider
+        assert hasattr(prov, "dataset_for") and hasattr(prov, "splits_file_for"), \
+            "validate() predicts whole preprocessed cases: the data provider must expose dataset_for(task) / splits_file_for(task)"
+        active = self.mh_network.active_task
+        ret_joined = list()
+        self.network.eval()
+        num_fg = self.plans["num_classes"] - 1            # evaluator2.py:61,92: plan['num_classes'] counts foreground classes
+        for task in trained_on:
+            dataset = prov.dataset_for(task)
+            _, dataset_val = do_split(dataset, self.fold, prov.splits_file_for(task))
+            self.network = self.mh_network.assemble_model(task)
+            self.network.eval()
+            folder = None
+            if output_folder is not None:
+                folder = os.path.join(output_folder, validation_folder_name + str(task))
+                os.makedirs(folder, exist_ok=True)
+            cases = OrderedDict()
+            for k, entry in dataset_val.items():
+                fname = None if folder is None else os.path.join(folder, k + ".npz")
+                if fname is not None and not overwrite and os.path.isfile(fname):
+                    seg = np.load(fname)["seg"]
+                else:
+                    npy = entry['data_file'][:-4] + ".npy"
+                    data = np.load(npy, 'r') if os.path.isfile(npy) else np.load(entry['data_file'])['data']
+                    seg, softmax = self.predict_preprocessed_data_return_seg_and_softmax(
+                        data[:-1], do_mirroring=do_mirroring, use_sliding_window=use_sliding_window, step_size=step_size,
+                        use_gaussian=use_gaussian, all_in_gpu=all_in_gpu, verbose=False, mixed_precision=self.fp16)
+                    if fname is not None:
+                        if save_softmax:
+                            np.savez_compressed(fname, seg=seg.astype(np.uint8), softmax=softmax.astype(np.float16))
+                        else:
+                            np.savez_compressed(fname, seg=seg.astype(np.uint8))
+                gt = np.load(entry['data_file'][:-4] + ".npy", 'r')[-1] if os.path.isfile(entry['data_file'][:-4] + ".npy") \
+                    else np.load(entry['data_file'])['data'][-1]
+                cases[k] = (seg, np.maximum(np.asarray(gt), 0))          # -1 marks voxels outside the non-zero mask: background
+            cases_dict = compute_scores_and_build_dict(cases, num_fg)
+            entry = {"task": task, "cases": cases_dict, "summary": summarize(cases_dict)}
+            if folder is not None:
+                with open(os.path.join(folder, "summary.json"), "w") as f:
+                    json.dump(entry, f, indent=1)
+            ret_joined.append(entry)
+        self.already_trained_on.setdefault(str(self.fold), {}).setdefault('finished_validation_on', []).append(trained_on[-1])
+        self.network = self.mh_network.assemble_model(active)
+        self.network.train()
+        return ret_joined
 
     def save_checkpoint(self, fname=None, save_optimizer=True):
         """MH.py:1164-1197 -> upstream ``NetworkTrainer.save_checkpoint`` / ``nnUNetTrainer.save_checkpoint``: the WHOLE

@@ -340,3 +340,34 @@ def test_preprocessed_data_loader(tmp_path):
     assert tuple(d["data"].shape) == (2, 1) + ps and [tuple(x.shape) for x in d["target"]] == [(2, 1, 16, 16, 16), (2, 1, 8, 8, 8), (2, 1, 4, 4, 4)]
     assert set(d["keys"]) <= set(tr) and float(d["target"][0].min()) >= 0
     assert set(next(prov("Task900_Toy", "val", plans))["keys"]) <= set(val)
+
+
+def test_evaluator_summary_matches_the_reference_arithmetic():
+    """lifelong-nnunet_amd/evaluation.py against the reference's own scikit-learn call (evaluator2.py:88-107, restated in
+    oracle/evaluation.py): random label volumes, a class absent from both volumes (-> None), a class only predicted."""
+    from oracle import evaluation as oev
+    from lifelong_nnunet_amd.evaluation import compute_scores_and_build_dict, summarize
+    rng = np.random.RandomState(0)
+    cases = {}
+    for i in range(4):
+        tgt = rng.randint(0, 3, (9, 11, 7))
+        out = np.where(rng.rand(9, 11, 7) < 0.8, tgt, rng.randint(0, 3, (9, 11, 7)))
+        cases[f"case_{i}"] = (out, tgt)
+    bg = np.zeros((5, 5, 5), int)
+    cases["all_background"] = (bg, bg)                                   # every mask None
+    only_pred = bg.copy(); only_pred[1, 1, 1] = 2
+    cases["false_positive_only"] = (only_pred, bg)                       # mask_2: IoU = Dice = 0, mask_1 None
+    got = compute_scores_and_build_dict(cases, 2)
+    assert list(got) == list(cases)
+    for k, (out, tgt) in cases.items():
+        exp = oev.case_scores(out, tgt, 2)
+        assert list(got[k]) == ["mask_1", "mask_2"]
+        for m in exp:
+            for metric in ("IoU", "Dice"):
+                a, b = got[k][m][metric], exp[m][metric]
+                assert (a is None and b is None) or abs(a - b) <= 1e-12, (k, m, metric, a, b)
+    assert got["all_background"]["mask_1"] == {"IoU": None, "Dice": None}
+    assert got["false_positive_only"]["mask_2"] == {"IoU": 0.0, "Dice": 0.0} and got["false_positive_only"]["mask_1"]["Dice"] is None
+    sm = summarize(got)
+    assert sm["mask_1"]["Dice"]["n"] == 4 and sm["mask_2"]["Dice"]["n"] == 5
+    assert abs(sm["mask_1"]["Dice"]["mean"] - np.mean([got[f"case_{i}"]["mask_1"]["Dice"] for i in range(4)])) < 1e-12

@@ -204,6 +204,53 @@ def test_seg1x1_fwd_bwd(N, C, K, V3):
     assert rel_err(dw.cpu(), 2.0 * w.grad.view(K, C)) < 1e-4
 
 
+@pytest.mark.parametrize("prior", [False, True])
+@pytest.mark.parametrize("N,C,K,V3", [(2, 32, 3, (8, 16, 8)), (1, 8, 2, (5, 9, 11)), (2, 320, 3, (3, 4, 3)), (1, 64, 4, (7, 8, 8))])
+def test_instnorm_lrelu_seg_bwd_fused(N, C, K, V3, prior):
+    """lnn_instnorm_lrelu_seg_bwd (dL/dz of a head-feeding decoder block never written to memory) against autograd through
+    conv1x1(leaky_relu(instance_norm(y))) + <prior, z>, and against the two unfused entries it replaces."""
+    y = (q16(_rand((N, C) + V3, 1) * 2 + 0.5)).requires_grad_(True)
+    g = torch.Generator().manual_seed(9)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    w = (torch.randn((K, C, 1, 1, 1), generator=g) * 0.2).requires_grad_(True)
+    V = V3[0] * V3[1] * V3[2]
+    yb, _ = to_cl_h(y.detach())
+    mean = torch.empty(N * C, device=DEV); rstd = torch.empty(N * C, device=DEV)
+    ws = torch.zeros(max(nat.query("lnn_instnorm_lrelu_seg_bwd_ws_doubles", N, C), nat.query("lnn_instnorm_ws_doubles", N, C)),
+                     dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", yb, N, V, C, 1e-5, mean, rstd, ws)
+    ga, be = gamma.detach().to(DEV), beta.detach().to(DEV)
+    zb = torch.zeros((N,) + V3 + (C,), dtype=torch.float16, device=DEV)
+    nat.call("lnn_instnorm_lrelu_fwd", yb, zb, C, N, V, C, mean, rstd, ga, be, 0.01)
+    # reference: the head reads the fp16-rounded z the forward kernel stored (straight-through for the rounding)
+    z = F.leaky_relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    zq = z + (from_cl_h(zb, C) - z).detach()
+    logits = F.conv3d(zq, w)
+    dl = torch.randn(logits.shape, generator=g)
+    pr = _rand(z.shape, 4) if prior else None
+    loss = (logits * dl).sum() + ((z * pr).sum() if prior else 0)
+    loss.backward()
+    wd = w.detach().view(K, C).contiguous().to(DEV)
+    prb = to_cl_h(pr, ld=C + 8)[0] if prior else None
+    # unfused pair
+    dzb = prb.clone() if prior else torch.zeros((N,) + V3 + (C + 8,), dtype=torch.float16, device=DEV)
+    yb_u = yb.clone()
+    dw_u = torch.zeros((K, C), device=DEV); dg_u = torch.zeros(C, device=DEV); db_u = torch.zeros(C, device=DEV)
+    nat.call("lnn_seg1x1_bwd", zb, C, wd, dl.to(DEV), dzb, C + 8, dw_u, N, V, C, K, 1 if prior else 0, 0.5, None)
+    nat.call("lnn_instnorm_lrelu_bwd", yb_u, dzb, C + 8, N, V, C, mean, rstd, ga, be, 0.01, dg_u, db_u, None, 0.5, ws)
+    # fused
+    dw = torch.zeros((K, C), device=DEV); dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
+    nat.call("lnn_instnorm_lrelu_seg_bwd", yb, prb, C + 8, wd, dl.to(DEV), dw, K, N, V, C, mean, rstd, ga, be, 0.01, dg, db, 0.5, ws)
+    assert rel_err(from_cl_h(yb, C), y.grad) < 3e-3
+    assert rel_err(dg.cpu(), 0.5 * gamma.grad) < 1e-3
+    assert rel_err(db.cpu(), 0.5 * beta.grad) < 1e-3
+    assert rel_err(dw.cpu(), 0.5 * w.grad.view(K, C)) < 1e-3
+    # same rounding points as the unfused pair: agreement to fp32 summation order (dy differs by at most an fp16 ulp where it does)
+    assert rel_err(from_cl_h(yb, C), from_cl_h(yb_u, C)) < 1e-3
+    assert rel_err(dw.cpu(), dw_u.cpu()) < 1e-4 and rel_err(dg.cpu(), dg_u.cpu()) < 1e-4 and rel_err(db.cpu(), db_u.cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("batch_dice", [0, 1])
 @pytest.mark.parametrize("N,K,V3", [(2, 3, (8, 16, 8)), (3, 2, (5, 9, 11)), (1, 5, (4, 8, 8))])
 def test_dice_ce_fwd_bwd(N, K, V3, batch_dice):
