@@ -375,6 +375,9 @@ int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64);
  * 7 = v7, 8 = v8 where the layer has >= 64 output channels, 9 = v9 where the layer has 32 / 64 input channels and no
  * accumulation, v5 otherwise).  Process-wide, not thread-safe: a debug hook, not part of the production surface. */
 int lnn_debug_force_conv_kernel(int which);
+/* Parity tests only: pin the stride-2 conv forward kernel (-1 automatic, 0 the tile kernel, 1 the z-streaming kernel wherever
+ * it supports the layer: 32 / 64 input channels, output channels a multiple of 64, even extents).  Process-wide. */
+int lnn_debug_force_down2_kernel(int which);
 /* Parity tests only: number of z segments the v9 kernel cuts a column into (0 = automatic).  Process-wide. */
 int lnn_debug_set_v9_zseg(int segments);
 

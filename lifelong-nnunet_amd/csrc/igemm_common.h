@@ -62,3 +62,7 @@ int lnn_launch_up2_convT(hipStream_t s, ConvParams& p, const char* name);
 // resolution-halving kernels (igemm_down2.hip): stride-2 conv forward / transposed conv k2s2 dgrad
 int lnn_launch_down2_conv(hipStream_t s, ConvParams& p, const char* name);
 int lnn_launch_down2_convT_dgrad(hipStream_t s, ConvParams& p, const char* name);
+// z-streaming stride-2 3x3x3 conv forward (igemm_down2s.hip): C = 32 / 64, M % 64 == 0, even input extents
+bool lnn_down2s_supported(const ConvParams& p);
+int lnn_down2s_stats_slots(const ConvParams& p);
+int lnn_launch_down2s(hipStream_t s, ConvParams& p, const char* name);

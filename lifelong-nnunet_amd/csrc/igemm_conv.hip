@@ -419,6 +419,22 @@ bool use_up2() {
 }
 
 // LNN_DOWN2_V1=1 selects the generic kernel for stride-2 forward / convT dgrad (A/B measurements only)
+// stride-2 conv forward: z-streaming kernel (igemm_down2s.hip) for 32 / 64 input channels with >= 16 output planes;
+// lnn_debug_force_down2_kernel: -1 automatic, 0 the tile kernel (igemm_down2.hip), 1 the streaming kernel wherever supported
+int g_force_down2 = -1;
+bool use_down2s(const ConvParams& p) {
+    if (!lnn_down2s_supported(p)) return false;
+    if (g_force_down2 >= 0) return g_force_down2 == 1;
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("LNN_DOWN2S");
+        v = e ? (e[0] == '1' ? 1 : 0) : -1;
+    }
+    if (v == 0) return false;
+    if (v == 1) return true;
+    return p.Ld >= 16;
+}
+
 bool use_down2() {
     static int v = -1;
     if (v < 0) {
@@ -491,6 +507,12 @@ int check_act(const void* ptr, int ld, int C, const char* what) {
 
 }  // namespace
 
+extern "C" int lnn_debug_force_down2_kernel(int which) {
+    LNN_REQUIRE(which >= -1 && which <= 1, "lnn_debug_force_down2_kernel: %d is not one of -1, 0, 1", which);
+    g_force_down2 = which;
+    return LNN_OK;
+}
+
 extern "C" int lnn_debug_force_conv_kernel(int which) {
     LNN_REQUIRE(which == -1 || which == 1 || which == 5 || (which >= 7 && which <= 9), "lnn_debug_force_conv_kernel: %d is not one of -1, 1, 5, 7, 8, 9", which);
     g_force_conv = which;
@@ -545,7 +567,9 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
             p.taps.slot[t] = (unsigned char)t;
         }
         p.dbg = g_dbg;
-        if (stats_pws && use_v2() && use_v9(p) && ld_y == K) {      // fused InstanceNorm statistics (dense output tensor only)
+        // fused InstanceNorm statistics (dense output tensor only; the partials must fit the 1024 slots of lnn_instnorm_ws_doubles:
+        // true up to 256 CUs -- a larger part falls back to the separate statistics pass)
+        if (stats_pws && use_v2() && use_v9(p) && ld_y == K && lnn_conv_s1_v9_stats_slots(p) <= 1024) {
             p.stats_pws = stats_pws;
             const int rc = lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9,stats)");
             *stats_slots = p.stats_nblk;
@@ -556,6 +580,16 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         if (use_v2() && use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,v7)");
         if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
+    }
+    if (use_down2() && use_down2s(p)) {
+        for (int t = 0; t < 27; ++t) p.taps.slot[t] = (unsigned char)t;
+        if (stats_pws && ld_y == K && lnn_down2s_stats_slots(p) <= 1024) {      // fused InstanceNorm statistics (dense output tensor only)
+            p.stats_pws = stats_pws;
+            const int rc = lnn_launch_down2s(s, p, "lnn_conv3d_fwd(s2,down2s,stats)");
+            *stats_slots = p.stats_nblk;
+            return rc;
+        }
+        return lnn_launch_down2s(s, p, "lnn_conv3d_fwd(s2,down2s)");
     }
     if (use_down2()) return lnn_launch_down2_conv(s, p, "lnn_conv3d_fwd(s2,down2)");
     {

@@ -19,6 +19,9 @@
 //     stores drop out-of-volume lanes the same way, so the steady-state loop has no branches;
 //   * the z halo is free (a column is walked continuously); the in-plane halo is shared between neighbouring blocks
 //     through the XCD's L2: blocks are placed so that the 32 CUs of an XCD work on adjacent columns.
+// 128 input channels (NCK = 8, round 3): every wave is a chunk, four of them finalise one accumulator quad each (a lane's
+// 4 consecutive channels -> 8-byte stores) and receive 7 partial quads per plane; the ring shrinks to 4 slots (3 planes in
+// flight) so that 4 x 24 KB of planes + 2 x 28 KB of exchange fit the 160 KB.
 // LDS layout of a plane slab: [32-channel group][py][px (row stride PXS)][4 x 16 bytes]; the 16-byte piece index is
 // XOR-keyed with ((px >> 2) & 1) | ((py & 1) << 1): with the lane -> voxel map below every ds_read_b128 16-lane
 // group reads 16 distinct 16-byte bank slots for all 9 in-plane shifts (conflict free).  The DMA writes LDS linearly
@@ -78,7 +81,7 @@ __device__ __forceinline__ void lane_voxel9(int v, int& r, int& x) {   // see ig
 template <int NCK_, int NMB_, int NF_>
 struct V9 {
     static constexpr int NCK = NCK_, NMB = NMB_, NF = NF_;
-    static_assert(NCK * NMB * NF == 8 && (NCK == 2 || NCK == 4), "8 waves per block");
+    static_assert(NCK * NMB * NF == 8 && (NCK == 2 || NCK == 4 || NCK == 8), "8 waves per block");
     static constexpr int NG = NCK / 2;                       // 32-channel groups of the input
     static constexpr int NFX = NF >= 4 ? 2 : 1, NFY = NF / NFX;
     static constexpr int FY = 4 * NFY, FX = 8 * NFX;         // block footprint
@@ -88,9 +91,10 @@ struct V9 {
     static constexpr int GSLAB = DPW * 8 / NG * 1024;
     static_assert(GSLAB >= GRAW && (DPW * 8) % NG == 0, "slab padding");
     static constexpr int PLANE = NG * GSLAB;
-    static constexpr int D = 4, R = 5;                       // planes in flight / ring slots (R >= D + 1)
-    static constexpr int QN = 4 / NCK;                       // accumulator quads a wave finalises
-    static constexpr int EXB = NF * NMB * NCK * (NCK - 1) * QN * 1024;   // one partial-sum exchange buffer
+    static constexpr int D = NCK == 8 ? 3 : 4, R = D + 1;    // planes in flight / ring slots (R >= D + 1)
+    static constexpr int NFIN = NCK < 4 ? NCK : 4;           // waves of a (footprint, output block) group that finalise outputs
+    static constexpr int QN = 4 / NFIN;                      // accumulator quads a finalising wave owns
+    static constexpr int EXB = NF * NMB * NFIN * (NCK - 1) * QN * 1024;   // one partial-sum exchange buffer
     static constexpr int LDS = R * PLANE + 2 * EXB;
 };
 
@@ -106,7 +110,7 @@ template <int NCK_, int NMB_, int NF_, bool STATS>
 __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvParams p, const V9Launch q) {
     using K = V9<NCK_, NMB_, NF_>;
     constexpr int NCK = K::NCK, NMB = K::NMB, NFX = K::NFX, PXS = K::PXS, PY = K::PY, PX = K::PX;
-    constexpr int GSLAB = K::GSLAB, PLANE = K::PLANE, DPW = K::DPW, D = K::D, R = K::R, QN = K::QN, EXB = K::EXB;
+    constexpr int GSLAB = K::GSLAB, PLANE = K::PLANE, DPW = K::DPW, D = K::D, R = K::R, QN = K::QN, EXB = K::EXB, NFIN = K::NFIN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const exch = smem + R * PLANE;
 
@@ -149,11 +153,18 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
     const unsigned out_plane_bytes = (unsigned)p.Ho * p.Wo * p.ld_y * 2u;
 
     // ---- partial-sum exchange addresses ------------------------------------------------------------------------------
-    const int rbase = (gi * NCK + ck) * (NCK - 1) * QN * 1024 + lane * 16;
-    int wbase[NCK - 1];
+    // Finalising waves (ck < NFIN; all of them unless NCK = 8) rotate their MFMA rows by 8 QN ck, so their own output
+    // channels are accumulator quads [0, QN); accumulator quad a of a wave holds channel quad Q = (a + QN ck) & 3 (rotated)
+    // or a (not rotated) and goes to finaliser f = Q / QN, slot (ck - f - 1) mod NCK of its (NCK - 1) QN KB region.
+    const bool fin = NFIN == NCK || ck < NFIN;
+    const int rbase = (gi * NFIN + ck) * (NCK - 1) * QN * 1024 + lane * 16;
+    int wb[4];
 #pragma unroll
-    for (int jj = 1; jj < NCK; ++jj)
-        wbase[jj - 1] = ((gi * NCK + (ck + jj) % NCK) * (NCK - 1) + (NCK - jj - 1)) * QN * 1024 + lane * 16;
+    for (int a = 0; a < 4; ++a) {
+        const int Q = fin ? (a + QN * ck) & 3 : a;
+        const int f = Q / QN;
+        wb[a] = ((gi * NFIN + f) * (NCK - 1) + (ck - f - 1 + NCK) % NCK) * QN * 1024 + (Q % QN) * 1024 + lane * 16;
+    }
 
     half8 A[27];
     float biasv[4 * QN];
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             cur_mg = mg;
             // MFMA row rho of a wave with chunk role ck holds output channel m0 + ((rho + 8 QN ck) & 31): the rows a wave
             // finalises are always its accumulator quads [0, QN)
-            const int row = ((lane & 31) + 8 * QN * ck) & 31;
+            const int row = ((lane & 31) + (fin ? 8 * QN * ck : 0)) & 31;
 #pragma unroll
             for (int tl = 0; tl < 27; ++tl) {
                 const half_t* wp = p.wp + lnn_panel_off(p.taps.slot[tl], m0, 16 * ck, 27, p.KCpad);
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             }
 #pragma unroll
             for (int i = 0; i < 4 * QN; ++i) biasv[i] = 0.f;
-            if (p.bias) {
+            if (p.bias && fin) {
                 // the channels of this lane's own accumulator quads: quad qq, register i -> m0 + 8 QN ck + 8 qq + 4 hk + i
 #pragma unroll
                 for (int i = 0; i < 4 * QN; ++i) biasv[i] = p.bias[m0 + 8 * QN * ck + 8 * (i >> 2) + 4 * hk + (i & 3)];
@@ -253,11 +264,13 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         half_t* optr = yten + ((long)n * p.Do + (zs0 - 3)) * out_plane;      // plane of tprev = -1
         floatx4 pv[(NCK - 1) * QN];
         auto fin_load = [&](int tprev) {
+            if (!fin) return;
             const char* eb = exch + (tprev & 1) * EXB + rbase;
 #pragma unroll
             for (int s = 0; s < (NCK - 1) * QN; ++s) pv[s] = *reinterpret_cast<const floatx4*>(eb + s * 1024);
         };
         auto fin_store = [&](int tprev) {
+            if (!fin) return;
             const bool ov = tprev >= 2 && tprev < T;
             float fin[4 * QN];
 #pragma unroll
@@ -343,13 +356,11 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             for (int i = 0; i < 4 * QN; ++i) own[i] = acc[c][i];
             char* eb = exch + (t & 1) * EXB;
 #pragma unroll
-            for (int jj = 1; jj < NCK; ++jj)
-#pragma unroll
-                for (int qi = 0; qi < QN; ++qi) {
-                    const int r0 = (jj * QN + qi) * 4;
-                    const floatx4 w = {acc[c][r0], acc[c][r0 + 1], acc[c][r0 + 2], acc[c][r0 + 3]};
-                    *reinterpret_cast<floatx4*>(eb + wbase[jj - 1] + qi * 1024) = w;
-                }
+            for (int a = 0; a < 4; ++a) {
+                if (a < QN && fin) continue;                 // own quads stay in registers
+                const floatx4 w = {acc[c][4 * a], acc[c][4 * a + 1], acc[c][4 * a + 2], acc[c][4 * a + 3]};
+                *reinterpret_cast<floatx4*>(eb + wb[a]) = w;
+            }
             wait_vm<(D - 2) * DPW, true>();
             __builtin_amdgcn_s_barrier();
         };
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         if constexpr (STATS) {
             // this wave's 32 voxel lanes per half-wave hold the same channels: butterfly over the half, then lanes 0 / 32
             // add the item's sums to the wave's own slot row (out-of-volume voxel columns contribute nothing)
-            const bool lane_ok = svoff != (int)0x80000000;
+            const bool lane_ok = fin && svoff != (int)0x80000000;
             float* const prow0 = p.stats_pws + (((long)(blockIdx.x * K::NF + f)) * p.N + n) * p.M;
             const long astride = (long)p.stats_nblk * p.N * p.M;
 #pragma unroll
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 float a = lane_ok ? ssum[i] : 0.f, b2 = lane_ok ? ssq[i] : 0.f;
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64); }
-                if ((lane & 31) == 0) {
+                if (fin && (lane & 31) == 0) {
                     const int ch = m0 + 8 * QN * ck + 8 * (i >> 2) + 4 * hk + (i & 3);
                     prow0[ch] += a;
                     prow0[astride + ch] += b2;
@@ -439,7 +450,7 @@ extern "C" int lnn_debug_set_v9_zseg(int segments) {
 
 bool lnn_conv_s1_v9_supported(const ConvParams& p) {
     if (p.accumulate || p.os != 1) return false;
-    if (p.C != 32 && p.C != 64) return false;
+    if (p.C != 32 && p.C != 64 && p.C != 128) return false;
     if (p.M % 32 != 0) return false;
     if (p.ld_x % 8 != 0 || p.ld_y % 8 != 0) return false;
     if (p.csplit != 0x7fffffff && p.csplit % 32 != 0) return false;
@@ -460,12 +471,16 @@ static int v9_num_cu() {
 
 // slots of the fused-statistics partials (rows of N * M floats per accumulator): grid blocks x footprints per block
 int lnn_conv_s1_v9_stats_slots(const ConvParams& p) {
-    const int nf = p.C == 32 ? (p.M % 64 == 0 ? 2 : 4) : (p.M % 64 == 0 ? 1 : 2);
+    const int nf = p.C == 128 ? 1 : p.C == 32 ? (p.M % 64 == 0 ? 2 : 4) : (p.M % 64 == 0 ? 1 : 2);
     return (v9_num_cu() / 8 * 8 < 8 ? 8 : v9_num_cu() / 8 * 8) * nf;
 }
 
 int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name) {
     const int num_cu = v9_num_cu();
+    if (p.C == 128) {
+        if (p.stats_pws) return launch_v9<V9<8, 1, 1>, true>(s, p, num_cu, name);
+        return launch_v9<V9<8, 1, 1>, false>(s, p, num_cu, name);
+    }
     if (p.stats_pws) {
         // 32 -> 64 (the data-gradient shape of the top decoder conv) never feeds an InstanceNorm: no STATS instance for it
         if (p.C == 32) return launch_v9<V9<2, 1, 4>, true>(s, p, num_cu, name);

@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int NT = 256;
+typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int MAX_BLOCKS = 1024;   // blocks_for() cap; the workspace holds 2 fp32 partials per (block, n, c)
 constexpr int UNR = 4;     // independent vector loads in flight per thread
 
@@ -389,9 +390,9 @@ __global__ void in_lrelu_bwd_finalize_kernel(const double* ws, const float* pws,
 // level dz and z are 0.63 GB tensors while dlogits is 0.12 GB.  Here both passes rebuild what they need in registers:
 //   dz  = [prior dz, written by the transposed conv of the level above] + fp16( sum_k dlogits[k] w[k][c] )
 //   z   = fp16( lrelu(y * gamma*rstd + beta - mean*gamma*rstd) )   -- the forward pass's own expression, for d(seg w)
-// so pass 1 reads y (+ prior) + dlogits and pass 2 the same, writing dy over y.  Rounding points are those of the unfused
-// kernels (dz and z pass through fp16); lrelu' is taken at the forward expression t = y*sc + sh instead of gamma*xhat + beta
-// (equal up to fp32 rounding, i.e. except for |t| ~ 1e-7).  K <= 4 (compile-time K: the per-thread weight / partial arrays).
+// so pass 1 reads y (+ prior) + dlogits and pass 2 the same, writing dy over y.  Pass 2 keeps the unfused kernels' rounding
+// point (dz through fp16); pass 1 sums with dz and z in fp32.  lrelu' is taken at the forward expression t = y*sc + sh instead
+// of gamma*xhat + beta (equal up to fp32 rounding, i.e. except for |t| ~ 1e-7).  K <= 4 (compile-time K).
 template <int KT>
 __device__ __forceinline__ void seg_dz(const float (&d)[KT], const float (&wr)[KT][8], const half8* prior, half8& dzh) {
 #pragma unroll
@@ -465,21 +466,37 @@ __global__ __launch_bounds__(NT, (KT <= 3 && !PRIOR && QUAD) ? 3 : 2) void in_lr
         const half_t* yp = y + (long)n * V * C + rm.c8 * 8;
         const half_t* dp = dzp + (long)n * V * ld_dz + rm.c8 * 8;
         const float* dln = dl + (long)n * KT * V;
+        // ~15 fp32 operations per element, written on channel PAIRS so that they become packed (v_pk_*_f32) instructions:
+        // this pass is VALU-bound, not HBM-bound (0.75 GB for 315 M elements at the top level).  lrelu(t) = t * sel with
+        // sel = lrelu'(t) in {1, slope}; dz and z are used in fp32 here (the unfused kernels round both to fp16 in memory).
         auto accum = [&](const half8& x, const half8& pr, const float (&d)[KT]) {
-            half8 dzh;
-            seg_dz<KT>(d, wr, PRIOR ? &pr : nullptr, dzh);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xf = (float)x[e];
-                const float t = xf * sc[e] + sh[e];
-                const bool pos = t > 0.f;
-                const float zf = (float)(half_t)(pos ? t : t * slope);
-                const float xh = xf * rs[e] + nmr[e];
-                const float g = (float)dzh[e] * (pos ? 1.f : slope);
-                part[0][e] += g;
-                part[1][e] += g * xh;
+            for (int e = 0; e < 8; e += 2) {
+                const float2v xf = {(float)x[e], (float)x[e + 1]};
+                const float2v sc2 = {sc[e], sc[e + 1]}, sh2 = {sh[e], sh[e + 1]}, rs2 = {rs[e], rs[e + 1]}, nm2 = {nmr[e], nmr[e + 1]};
+                const float2v t = xf * sc2 + sh2;
+                const float2v sel = {t[0] > 0.f ? 1.f : slope, t[1] > 0.f ? 1.f : slope};
+                const float2v z = t * sel;
+                const float2v xh = xf * rs2 + nm2;
+                float2v dz = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < KT; ++k) part[2 + k][e] += d[k] * zf;
+                for (int k = 0; k < KT; ++k) {
+                    const float2v wk = {wr[k][e], wr[k][e + 1]};
+                    dz += wk * d[k];
+                }
+                if (PRIOR) dz += float2v{(float)pr[e], (float)pr[e + 1]};
+                const float2v g = dz * sel;
+                float2v p0 = {part[0][e], part[0][e + 1]}, p1 = {part[1][e], part[1][e + 1]};
+                p0 += g;
+                p1 += g * xh;
+                part[0][e] = p0[0]; part[0][e + 1] = p0[1];
+                part[1][e] = p1[0]; part[1][e + 1] = p1[1];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    float2v pk = {part[2 + k][e], part[2 + k][e + 1]};
+                    pk += z * d[k];
+                    part[2 + k][e] = pk[0]; part[2 + k][e + 1] = pk[1];
+                }
             }
         };
         const long end = vrange_end(V, rm), step = rm.VPB;

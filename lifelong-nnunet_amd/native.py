@@ -91,6 +91,7 @@ SIGNATURES = {
     "lnn_debug_tr16_probe": (_i, [_p, _p]),
     "lnn_debug_set_phase_buffer": (_i, [_p]),
     "lnn_debug_force_conv_kernel": (_i, [_i]),
+    "lnn_debug_force_down2_kernel": (_i, [_i]),
     "lnn_debug_set_v9_zseg": (_i, [_i]),
 }
 

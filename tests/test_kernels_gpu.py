@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from tests.gpu_utils import (DEV, View, from_cl_h, pack_conv_dgrad, pack_conv_fwd, pack_convT_dgrad,  # noqa: E402
+from tests.gpu_utils import (DEV, View, from_cl_h, pack, pack_conv_dgrad, pack_conv_fwd, pack_convT_dgrad,  # noqa: E402
                              pack_convT_fwd, q16, rel_err, to_cl_h)
 from lifelong_nnunet_amd import native as nat  # noqa: E402
 
@@ -436,7 +436,9 @@ def test_every_stride1_conv_kernel_variant(which):
     cases cover the four wave-role configurations of v9 (chunks x output blocks x footprints), forward and dgrad."""
     cases = [c for c in CONV_CASES if c[6] == 1] + [(1, 32, 96, 9, 8, 17, 1), (2, 128, 64, 8, 8, 8, 1), (1, 24, 160, 5, 6, 7, 1),
                                                     (1, 32, 64, 7, 9, 18, 1), (1, 64, 64, 6, 10, 9, 1), (2, 64, 128, 5, 12, 9, 1),
-                                                    (1, 32, 32, 37, 5, 21, 1)]
+                                                    (1, 32, 32, 37, 5, 21, 1),
+                                                    # 128 input channels: v9 with all eight waves as channel chunks (round 3)
+                                                    (1, 128, 128, 7, 9, 18, 1), (1, 128, 96, 5, 6, 10, 1), (1, 128, 256, 4, 5, 9, 1)]
     assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
     try:
         for (N, C, K, D, H, W, s) in cases:
@@ -448,7 +450,8 @@ def test_every_stride1_conv_kernel_variant(which):
 
 
 @pytest.mark.parametrize("N,C,K,D,H,W,cat", [(2, 32, 32, 9, 8, 17, 0), (1, 64, 32, 6, 10, 9, 1), (2, 64, 64, 5, 12, 9, 0),
-                                              (1, 16, 32, 5, 9, 11, 0), (1, 32, 32, 37, 5, 21, 0)])
+                                              (1, 16, 32, 5, 9, 11, 0), (1, 32, 32, 37, 5, 21, 0), (2, 128, 64, 34, 6, 10, 0),
+                                              (1, 128, 128, 33, 9, 9, 0), (2, 1, 32, 9, 10, 17, 0), (1, 1, 32, 4, 8, 8, 0)])
 def test_conv3d_fwd_in_stats(N, C, K, D, H, W, cat):
     """lnn_conv3d_fwd_in_stats == lnn_conv3d_fwd followed by lnn_instnorm_stats: the output bit for bit, mean / rstd to
     fp32 summation order (the z-streaming kernel takes the sums in its epilogue from the values it stores; for shapes it
@@ -457,7 +460,7 @@ def test_conv3d_fwd_in_stats(N, C, K, D, H, W, cat):
     w = _rand((K, C, 3, 3, 3), 2, 0.1)
     b = torch.randn(K, generator=torch.Generator().manual_seed(3)).to(DEV)
     xb, _ = to_cl_h(x)
-    wp = pack_conv_fwd(w.to(DEV))
+    wp = pack(w.to(DEV), 1, K, 27, 27, 1, 0) if C == 1 else pack_conv_fwd(w.to(DEV))    # first layer: taps are the contraction
     V = D * H * W
     ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=DEV)
     y1 = torch.zeros((N, D, H, W, K), dtype=torch.float16, device=DEV); y2 = torch.zeros_like(y1)
@@ -478,11 +481,52 @@ def test_conv3d_fwd_in_stats(N, C, K, D, H, W, cat):
     assert float((m1 - m2).abs().max()) <= 2e-6 * float(m1.abs().max()) + 1e-7 and float((r1 - r2).abs().max()) <= 2e-6 * float(r1.abs().max())
 
 
+@pytest.mark.parametrize("N,C,K,D,H,W", [(2, 32, 64, 16, 32, 16), (1, 32, 128, 34, 20, 36), (1, 64, 64, 12, 20, 36),
+                                         (1, 64, 128, 36, 12, 20), (1, 32, 64, 6, 18, 34)])
+def test_stride2_conv_streaming_kernel(N, C, K, D, H, W):
+    """igemm_down2s (z-streaming stride-2 conv forward, round 3) pinned by lnn_debug_force_down2_kernel(1): against
+    F.conv3d(stride=2, padding=1), against the tile kernel it replaces, and its fused InstanceNorm statistics against the
+    separate pass (output bit for bit, mean / rstd to fp32 summation order).  Ragged footprints (Ho, Wo not multiples of the
+    8 x 8 / 4 x 8 block footprint), both wave-role configurations (32 / 64 input channels), 1 and 2 output-channel groups."""
+    x = _rand((N, C, D, H, W), 1)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3))
+    ref = F.conv3d(x, w, b, stride=2, padding=1)
+    xb, _ = to_cl_h(x)
+    wp = pack_conv_fwd(w.to(DEV))
+    Do, Ho, Wo = ref.shape[2:]
+    V = Do * Ho * Wo
+    outs = {}
+    try:
+        for which in (0, 1):
+            assert nat.lib().lnn_debug_force_down2_kernel(which) == 0
+            yb = torch.full((N, Do, Ho, Wo, K), 7.0, dtype=torch.float16, device=DEV)
+            nat.call("lnn_conv3d_fwd", xb, C, wp, b.to(DEV), yb, K, N, D, H, W, C, K, 2)
+            outs[which] = yb
+            assert rel_err(from_cl_h(yb, K), ref) < 2e-3, which
+        assert rel_err(from_cl_h(outs[1], K), from_cl_h(outs[0], K)) < 1e-3
+        # output into a wider buffer at a channel offset (the engine never does this for a strided conv, the C-ABI allows it)
+        yw = torch.full((N, Do, Ho, Wo, K + 16), 7.0, dtype=torch.float16, device=DEV)
+        nat.call("lnn_conv3d_fwd", xb, C, wp, b.to(DEV), View(yw, 16), K + 16, N, D, H, W, C, K, 2)
+        assert torch.equal(yw[..., 16:], outs[1]) and bool((yw[..., :16] == 7.0).all())
+        # fused statistics
+        ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+        m1, r1, m2, r2 = (torch.zeros(N * K, device=DEV) for _ in range(4))
+        nat.call("lnn_instnorm_stats", outs[1], N, V, K, 1e-5, m1, r1, ws)
+        y2 = torch.zeros_like(outs[1])
+        nat.call("lnn_conv3d_fwd_in_stats", xb, None, C, 0, wp, b.to(DEV), y2, N, D, H, W, C, K, 2, 1e-5, m2, r2, ws, None, 0)
+        assert torch.equal(y2, outs[1])
+        assert float((m1 - m2).abs().max()) <= 2e-6 * float(m1.abs().max()) + 1e-7 and float((r1 - r2).abs().max()) <= 2e-6 * float(r1.abs().max())
+    finally:
+        nat.lib().lnn_debug_force_down2_kernel(-1)
+
+
+@pytest.mark.parametrize("C", [32, 128])
 @pytest.mark.parametrize("zseg", [2, 3, 5])
-def test_v9_z_segments(zseg):
+def test_v9_z_segments(zseg, C):
     """v9 walks a column of output planes; long columns can be cut into z segments (item = column x segment): every cut
     must reproduce the unsegmented result bit for bit (each segment re-reads one halo plane on either side)."""
-    N, C, K, D, H, W = 1, 32, 32, 23, 9, 17
+    N, K, D, H, W = 1, 32, 23, 9, 17
     x = _rand((N, C, D, H, W), 1)
     w = _rand((K, C, 3, 3, 3), 2, 0.1)
     b = torch.randn(K, generator=torch.Generator().manual_seed(3))

@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Lane-level numpy emulation of csrc/igemm_down2s.hip (index arithmetic only): x-parity de-interleaved LDS plane layout
+and XOR key, the DMA's lane -> source mapping, B-fragment reads, even / odd plane steps with two rolling accumulators,
+weight-row rotation, partial-sum exchange and the epilogue's lane -> channel map.  Runs on the CPU; compares with
+torch conv3d(stride=2, padding=1):   python tools/down2s_emulate.py"""
+import itertools
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from v9_emulate import lane_voxel
+
+
+class Cfg:
+    def __init__(s, NCK, NMB, NF):
+        s.NCK, s.NMB, s.NF = NCK, NMB, NF
+        s.NG = NCK // 2
+        s.NFX = 2 if NF >= 4 else 1
+        s.NFY = NF // s.NFX
+        s.FY, s.FX = 4 * s.NFY, 8 * s.NFX
+        s.PY, s.PX = 2 * s.FY + 1, 2 * s.FX + 1
+        s.PXH = s.FX + 1
+        s.PXHS = (s.PXH + 1) // 2 * 2
+        s.GRAW = s.PY * 2 * s.PXHS * 64
+        s.DPW = (s.NG * ((s.GRAW + 1023) // 1024) + 7) // 8
+        s.GSLAB = s.DPW * 8 // s.NG * 1024
+        assert s.GSLAB >= s.GRAW
+        s.PLANE = s.NG * s.GSLAB
+        s.D = 3 if NCK == 4 else 4
+        s.R = s.D + 1
+        s.QN = 4 // NCK
+        s.EXB = NF * NMB * NCK * (NCK - 1) * s.QN * 1024
+        s.ROWB = 2 * s.PXHS * 64
+
+
+def emulate(K, x, w, bias, S=1):
+    N, C, Di, Hi, Wi = x.shape
+    M = w.shape[0]
+    Do, Ho, Wo = Di // 2, Hi // 2, Wi // 2
+    assert C == 16 * K.NCK and M % (32 * K.NMB) == 0
+    xcl = x.permute(0, 2, 3, 4, 1).contiguous().numpy()
+    y = np.full((N, Do, Ho, Wo, M), np.nan, dtype=np.float32)
+    wn = w.numpy()
+    tiles_y, tiles_x = -(-Ho // K.FY), -(-Wo // K.FX)
+    L = -(-Do // S)
+    mgroups = M // (32 * K.NMB)
+    lds = np.zeros(K.R * K.PLANE // 2, dtype=np.float32)
+    exch = np.zeros((2, K.EXB // 4), dtype=np.float32)
+    for mg, n, zs, fyb, fxb in itertools.product(range(mgroups), range(N), range(S), range(tiles_y), range(tiles_x)):
+        y0, x0 = fyb * K.FY, fxb * K.FX
+        zs0, zs1 = zs * L, min(zs * L + L, Do)
+        if zs0 >= zs1:
+            continue
+        NO = zs1 - zs0 + 1
+        iy0, ix0 = 2 * y0 - 1, 2 * x0 - 1
+        zin0 = 2 * (zs0 - 1)
+        waves = []
+        for wave in range(8):
+            ck, mb, f = wave % K.NCK, (wave // K.NCK) % K.NMB, wave // (K.NCK * K.NMB)
+            fxi, fyi, gi = f % K.NFX, f // K.NFX, f * K.NMB + mb
+            m0 = 32 * (mg * K.NMB + mb)
+            st = dict(ck=ck, fxi=fxi, fyi=fyi, gi=gi, m0=m0, acc=np.zeros((2, 32, 32), np.float32), own=np.zeros((K.QN * 8, 32), np.float32))
+            A = np.zeros((27, 32, 16), np.float32)
+            for tl in range(27):
+                dz, dy, dx = tl // 9, (tl // 3) % 3, tl % 3
+                for rho in range(32):
+                    ch = m0 + ((rho + 8 * K.QN * ck) & 31)
+                    A[tl, rho] = wn[ch, 16 * ck:16 * ck + 16, dz, dy, dx]
+            st["A"] = A
+            waves.append(st)
+
+        def dma(dtp, slot):
+            zin = zin0 + dtp
+            zok = 1 <= dtp < 2 * NO and 0 <= zin < Di
+            for wave in range(8):
+                for k in range(K.DPW):
+                    j = wave * K.DPW + k
+                    gg = (j * 1024) // K.GSLAB
+                    for lane in range(64):
+                        cc = j * 64 + lane - gg * (K.GSLAB // 16)
+                        pos, pc = cc >> 2, cc & 3
+                        py, xpar, pxh = pos // (2 * K.PXHS), (pos // K.PXHS) & 1, pos % K.PXHS
+                        px = 2 * pxh + xpar
+                        key = ((pxh >> 2) & 1) | (((py >> 1) & 1) << 1)
+                        piece = pc ^ key
+                        iy, ix = iy0 + py, ix0 + px
+                        ok = zok and py < K.PY and px < K.PX and 0 <= iy < Hi and 0 <= ix < Wi
+                        dst = (slot * K.PLANE + j * 1024 + lane * 16) // 2
+                        if ok:
+                            c0 = 32 * gg + piece * 8
+                            lds[dst:dst + 8] = xcl[n, zin, iy, ix, c0:c0 + 8]
+                        else:
+                            lds[dst:dst + 8] = 0.0
+
+        def bfrag(st, slot, i):
+            dy, dx = i // 3, i % 3
+            B = np.zeros((16, 32), np.float32)
+            for lane in range(64):
+                hk, v = lane >> 5, lane & 31
+                vr, vx = lane_voxel(v)
+                oy, pxh = 4 * st["fyi"] + vr, 8 * st["fxi"] + vx + (dx >> 1)
+                h = dy >> 1
+                key = ((pxh >> 2) & 1) | (((oy + h) & 1) << 1)
+                ck = st["ck"]
+                lb = (ck >> 1) * K.GSLAB + ((2 * oy * 2 + (dx & 1)) * K.PXHS + pxh) * 64 + (((((ck & 1) << 1) | hk) ^ key) << 4)
+                a = (slot * K.PLANE + lb + dy * K.ROWB) // 2
+                B[8 * hk:8 * hk + 8, v] = lds[a:a + 8]
+            return B
+
+        def finalize(w):
+            o = zs0 - 1 + w
+            ov = 1 <= w < NO
+            for st in waves:
+                ck, gi = st["ck"], st["gi"]
+                fin = st["own"].copy()
+                rb = (gi * K.NCK + ck) * (K.NCK - 1) * K.QN * 1024
+                for s_ in range((K.NCK - 1) * K.QN):
+                    base = (rb + s_ * 1024) // 4
+                    pv = exch[w & 1][base:base + 256].reshape(64, 4)
+                    for lane in range(64):
+                        hk, v = lane >> 5, lane & 31
+                        qi = s_ % K.QN
+                        fin[qi * 8 + 4 * hk:qi * 8 + 4 * hk + 4, v] += pv[lane]
+                if not ov:
+                    continue
+                for lane in range(64):
+                    hk, v = lane >> 5, lane & 31
+                    vr, vx = lane_voxel(v)
+                    oy, ox = y0 + 4 * st["fyi"] + vr, x0 + 8 * st["fxi"] + vx
+                    if oy >= Ho or ox >= Wo:
+                        continue
+                    if K.NCK == 2:
+                        if hk == 0:
+                            lo, hi = fin[0:4, v], fin[4:8, v]
+                        else:
+                            lo, hi = fin[8:12, v], fin[12:16, v]
+                        ch = st["m0"] + 16 * ck + 8 * hk
+                        y[n, o, oy, ox, ch:ch + 8] = np.concatenate([lo, hi]) + bias[ch:ch + 8]
+                    else:
+                        ch = st["m0"] + 8 * ck + 4 * hk
+                        y[n, o, oy, ox, ch:ch + 4] = fin[4 * hk:4 * hk + 4, v] + bias[ch:ch + 4]
+
+        for tp in range(K.D):
+            dma(tp, tp % K.R)
+        dtp = K.D
+        for st in waves:
+            st["acc"][0][:] = 0
+        NW = (NO + 2) // 2 * 2
+        hs = 0
+        for w in range(NW):
+            CUR = w & 1
+            for ODD in (0, 1):
+                if not ODD:
+                    finalize(w - 1)
+                dma(dtp, dtp % K.R); dtp += 1
+                slot = hs % K.R
+                for st in waves:
+                    for i in range(9):
+                        B = bfrag(st, slot, i)
+                        if ODD:
+                            st["acc"][CUR] += st["A"][18 + i] @ B
+                            if i == 0:
+                                st["acc"][1 - CUR][:] = 0
+                            st["acc"][1 - CUR] += st["A"][i] @ B
+                        else:
+                            st["acc"][CUR] += st["A"][9 + i] @ B
+                if ODD:
+                    for st in waves:
+                        ck, gi = st["ck"], st["gi"]
+                        st["own"] = st["acc"][CUR][:8 * K.QN].copy()
+                        for jj in range(1, K.NCK):
+                            wb = ((gi * K.NCK + (ck + jj) % K.NCK) * (K.NCK - 1) + (K.NCK - jj - 1)) * K.QN * 1024
+                            for qi in range(K.QN):
+                                quad = jj * K.QN + qi
+                                base = (wb + qi * 1024) // 4
+                                blk = exch[w & 1][base:base + 256].reshape(64, 4)
+                                for lane in range(64):
+                                    hk, v = lane >> 5, lane & 31
+                                    blk[lane] = st["acc"][CUR][8 * quad + 4 * hk:8 * quad + 4 * hk + 4, v]
+                hs += 1
+    return torch.from_numpy(y).permute(0, 4, 1, 2, 3)
+
+
+def main():
+    torch.manual_seed(0)
+    cases = [((2, 2, 2), (1, 32, 64, 8, 18, 20)), ((4, 2, 1), (1, 64, 64, 6, 10, 18)), ((2, 2, 2), (1, 32, 128, 10, 8, 34))]
+    bad = 0
+    for cfg, (N, C, M, D, H, W) in cases:
+        x = torch.randn(N, C, D, H, W).half().float()
+        w = (torch.randn(M, C, 3, 3, 3) * 0.1).half().float()
+        b = torch.randn(M)
+        ref = F.conv3d(x, w, b, stride=2, padding=1)
+        for S in (1, 2):
+            got = emulate(Cfg(*cfg), x, w, b.numpy(), S=S)
+            err = float((got - ref).abs().max())
+            nan = int(torch.isnan(got).sum())
+            print(f"cfg {cfg} {C}->{M} @{D}x{H}x{W} S={S}: max err {err:.2e}  unwritten {nan}", flush=True)
+            bad += err > 1e-3 or nan > 0
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

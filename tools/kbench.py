@@ -13,6 +13,7 @@ LAYERS = {  # name: (N, C, K, D, H, W, stride)
     "dec4.0": (2, 64, 32, 160, 192, 160, 1), "enc0.1": (2, 32, 32, 160, 192, 160, 1),
     "dec3.0": (2, 128, 64, 80, 96, 80, 1), "enc1.1": (2, 64, 64, 80, 96, 80, 1),
     "dec2.0": (2, 256, 128, 40, 48, 40, 1), "enc3.1": (2, 256, 256, 20, 24, 20, 1),
+    "enc2.1": (2, 128, 128, 40, 48, 40, 1), "dec2.0d": (2, 128, 256, 40, 48, 40, 1),     # 128 input channels (v9 <8,1,1> since round 3)
     "dec4.0half": (2, 64, 32, 80, 96, 80, 1), "enc0.1half": (2, 32, 32, 80, 96, 80, 1),   # same layers, 1/8 of the voxels (fit the MALL)
     "enc1.0s2": (2, 32, 64, 160, 192, 160, 2), "enc2.0s2": (2, 64, 128, 80, 96, 80, 2),
 }
@@ -26,11 +27,13 @@ def main():
     ap.add_argument("--layers", default="dec4.0,enc0.1,dec3.0,enc1.1,dec2.0,enc1.0s2")
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--down2", type=int, default=-1, help="lnn_debug_force_down2_kernel: 0 tile kernel, 1 z-streaming kernel")
     ap.add_argument("--phases", action="store_true", help="print the v3 conv kernel's per-phase cycle split")
     ap.add_argument("--check", default="", help="comma list of forced kernels (e.g. 5,9): run fwd/dgrad with each and compare outputs")
     ap.add_argument("--wgrad-phases", action="store_true", help="print the stride-1 wgrad kernel's per-phase cycle split (LNN_WGRAD_DEBUG=4)")
     a = ap.parse_args()
     dev = "cuda:0"
+    nat.lib().lnn_debug_force_down2_kernel(a.down2)
     wdbg = None
     if a.wgrad_phases:
         wdbg = torch.zeros(6, dtype=torch.int64, device=dev)

@@ -33,9 +33,11 @@ class Cfg:
         s.DPW = (s.NG * ((s.GRAW + 1023) // 1024) + 7) // 8
         s.GSLAB = s.DPW * 8 // s.NG * 1024
         s.PLANE = s.NG * s.GSLAB
-        s.D, s.R = 4, 5
-        s.QN = 4 // NCK
-        s.EXB = NF * NMB * NCK * (NCK - 1) * s.QN * 1024
+        s.D = 3 if NCK == 8 else 4
+        s.R = s.D + 1
+        s.NFIN = min(NCK, 4)
+        s.QN = 4 // s.NFIN
+        s.EXB = NF * NMB * s.NFIN * (NCK - 1) * s.QN * 1024
 
 
 def emulate(cfg, x, w, bias, S=1, flip=False):
@@ -69,7 +71,7 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
                 slot = 26 - tl if flip else tl
                 dz, dy, dx = slot // 9, (slot // 3) % 3, slot % 3
                 for rho in range(32):
-                    ch = m0 + ((rho + 8 * K.QN * ck) & 31)
+                    ch = m0 + ((rho + (8 * K.QN * ck if ck < K.NFIN else 0)) & 31)
                     A[tl, rho] = wn[ch, 16 * ck:16 * ck + 16, dz, dy, dx]
             st["A"] = A
             waves.append(st)
@@ -116,8 +118,10 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
             ov = 2 <= tprev < T
             for st in waves:
                 ck, gi = st["ck"], st["gi"]
+                if ck >= K.NFIN:
+                    continue
                 fin = st["own"].copy()                      # rows: quad-in-Q * 8 + 4 hk + i  (MFMA rows of quads [0, QN))
-                rb = (gi * K.NCK + ck) * (K.NCK - 1) * K.QN * 1024
+                rb = (gi * K.NFIN + ck) * (K.NCK - 1) * K.QN * 1024
                 for s_ in range((K.NCK - 1) * K.QN):
                     base = (rb + s_ * 1024) // 4
                     pv = exch[tprev & 1][base:base + 256].reshape(64, 4)
@@ -169,22 +173,25 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
                 c = (U + 2) % 3
                 ck, gi = st["ck"], st["gi"]
                 st["own"] = st["acc"][c][:8 * K.QN].copy()
-                for jj in range(1, K.NCK):
-                    wb = ((gi * K.NCK + (ck + jj) % K.NCK) * (K.NCK - 1) + (K.NCK - jj - 1)) * K.QN * 1024
-                    for qi in range(K.QN):
-                        quad = jj * K.QN + qi
-                        base = (wb + qi * 1024) // 4
-                        blk = exch[t & 1][base:base + 256].reshape(64, 4)
-                        for lane in range(64):
-                            hk, v = lane >> 5, lane & 31
-                            blk[lane] = st["acc"][c][8 * quad + 4 * hk:8 * quad + 4 * hk + 4, v]
+                fin_w = ck < K.NFIN
+                for a in range(4):
+                    if a < K.QN and fin_w:
+                        continue
+                    Q = (a + K.QN * ck) & 3 if fin_w else a
+                    f_ = Q // K.QN
+                    wb = ((gi * K.NFIN + f_) * (K.NCK - 1) + (ck - f_ - 1 + K.NCK) % K.NCK) * K.QN * 1024 + (Q % K.QN) * 1024
+                    base = wb // 4
+                    blk = exch[t & 1][base:base + 256].reshape(64, 4)
+                    for lane in range(64):
+                        hk, v = lane >> 5, lane & 31
+                        blk[lane] = st["acc"][c][8 * a + 4 * hk:8 * a + 4 * hk + 4, v]
     return torch.from_numpy(y).permute(0, 4, 1, 2, 3)
 
 
 def main():
     torch.manual_seed(0)
     cases = [((2, 1, 4), (1, 32, 32, 5, 9, 18)), ((4, 1, 2), (1, 64, 32, 4, 9, 9)), ((2, 2, 2), (1, 32, 64, 5, 6, 10)),
-             ((4, 2, 1), (1, 64, 64, 4, 5, 9)), ((2, 1, 4), (1, 32, 96, 7, 8, 16))]
+             ((4, 2, 1), (1, 64, 64, 4, 5, 9)), ((2, 1, 4), (1, 32, 96, 7, 8, 16)), ((8, 1, 1), (1, 128, 64, 4, 5, 9))]
     bad = 0
     for cfg, (N, C, M, D, H, W) in cases:
         x = torch.randn(N, C, D, H, W).half().float()
