@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
         };
 
         // output plane finalised after the odd step of walked output w (z = zs0 - 1 + w): own quads + partial sums -> y
-        half_t* optr = p.y + ((long)n * p.Do + (zs0 - 1)) * out_plane;     // plane of w = 0
+        half_t* optr = p.y + ((long)n * p.Do + (zs0 - 2)) * out_plane;     // plane of the first call, fin_store(-1); never dereferenced below zs0
         floatx4 pv[(NCK - 1) * QN];
         auto fin_load = [&](int w) {
             const char* eb = exch + (w & 1) * EXB + rbase;

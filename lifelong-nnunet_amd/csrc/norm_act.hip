@@ -16,6 +16,20 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int MAX_BLOCKS = 1024;   // blocks_for() cap; the workspace holds 2 fp32 partials per (block, n, c)
 constexpr int UNR = 4;     // independent vector loads in flight per thread
 
+// streaming accesses of the big passes: non-temporal (nt) loads / stores when LNN_IN_NT=1 (A/B switch, measurements only)
+__device__ __forceinline__ half8 ld8(const half_t* p, int nt) {
+    return nt ? __builtin_nontemporal_load(reinterpret_cast<const half8*>(p)) : *reinterpret_cast<const half8*>(p);
+}
+__device__ __forceinline__ void st8(half_t* p, const half8& v, int nt) {
+    if (nt) __builtin_nontemporal_store(v, reinterpret_cast<half8*>(p));
+    else *reinterpret_cast<half8*>(p) = v;
+}
+int in_nt_flag() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LNN_IN_NT"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 struct RowMap {
     int C8, VPB, c8, vl;
     bool active;
@@ -142,7 +156,7 @@ __global__ void in_stats_finalize_kernel(const float* pws, int nblk, int NC, lon
 __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restrict__ y, half_t* __restrict__ z, int ld_z,
                                                           long V, int C, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float slope) {
+                                                          const float* __restrict__ beta, float slope, int nt) {
     const RowMap rm = row_map(C);
     if (!rm.active) return;
     const int n = blockIdx.y;
@@ -171,9 +185,9 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
     for (; v + (UNR - 1) * step < end; v += UNR * step) {
         half8 x[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+        for (int u = 0; u < UNR; ++u) x[u] = ld8(yp + (v + u * step) * C, nt);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) *reinterpret_cast<half8*>(zp + (v + u * step) * ld_z) = apply(x[u]);
+        for (int u = 0; u < UNR; ++u) st8(zp + (v + u * step) * ld_z, apply(x[u]), nt);
     }
     for (; v < end; v += step) *reinterpret_cast<half8*>(zp + v * ld_z) = apply(*reinterpret_cast<const half8*>(yp + v * C));
 }
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __re
 __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* __restrict__ y, const half_t* __restrict__ dz,
                                                                  int ld_dz, long V, int C, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float slope, float* pws) {
+                                                                 const float* __restrict__ beta, float slope, float* pws, int nt) {
     __shared__ float red[NT * 17];
     const RowMap rm = row_map(C);
     const int n = blockIdx.y;
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
             half8 x[U2], d[U2];
 #pragma unroll
             for (int u = 0; u < U2; ++u) {
-                x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+                x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);       // y and dz are read again by pass 2: cached loads
                 d[u] = *reinterpret_cast<const half8*>(dp + (v + u * step) * ld_dz);
             }
 #pragma unroll
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
                                                                 long V, int C, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float slope, const double* ws,
-                                                                float* pws) {
+                                                                float* pws, int nt) {
     __shared__ float red[NT * 9];
     const RowMap rm = row_map(C);
     const int n = blockIdx.y;
@@ -358,11 +372,11 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
             half8 x[U2], d[U2];
 #pragma unroll
             for (int u = 0; u < U2; ++u) {
-                x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
-                d[u] = *reinterpret_cast<const half8*>(dp + (v + u * step) * ld_dz);
+                x[u] = ld8(yp + (v + u * step) * C, nt);
+                d[u] = ld8(dp + (v + u * step) * ld_dz, nt);
             }
 #pragma unroll
-            for (int u = 0; u < U2; ++u) *reinterpret_cast<half8*>(yp + (v + u * step) * C) = grad(x[u], d[u]);
+            for (int u = 0; u < U2; ++u) st8(yp + (v + u * step) * C, grad(x[u], d[u]), nt);
         }
         for (; v < end; v += step)
             *reinterpret_cast<half8*>(yp + v * C) = grad(*reinterpret_cast<const half8*>(yp + v * C), *reinterpret_cast<const half8*>(dp + v * ld_dz));
@@ -699,7 +713,7 @@ extern "C" int lnn_instnorm_lrelu_fwd(lnn_stream_t s_, const void* y, void* z, i
     LNN_REQUIRE(z != nullptr && lnn_aligned16(z) && ld_z >= C && ld_z % 8 == 0, "lnn_instnorm_lrelu_fwd: bad z / ld_z");
     LNN_REQUIRE(mean && rstd && gamma && beta, "lnn_instnorm_lrelu_fwd: null parameter");
     hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z, ld_z,
-                       V, C, mean, rstd, gamma, beta, slope);
+                       V, C, mean, rstd, gamma, beta, slope, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_fwd");
     return LNN_OK;
 }
@@ -733,21 +747,21 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
     const int nblk = blocks_for(V, C);
     const dim3 grid(nblk, N);
     hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, grid, dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
-                       mean, rstd, gamma, beta, slope, pws);
+                       mean, rstd, gamma, beta, slope, pws, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(reduce)");
     hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
                        grad_unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(sums)");
     if (dbias) {
         hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<true>), grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
-                           rstd, gamma, beta, slope, ws, pws);
+                           rstd, gamma, beta, slope, ws, pws, in_nt_flag());
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
         hipLaunchKernelGGL(in_lrelu_bwd_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, ws, pws, nblk, N, C, dgamma,
                            dbeta, dbias, grad_unscale);
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(finalize)");
     } else {
         hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<false>), grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
-                           rstd, gamma, beta, slope, ws, pws);
+                           rstd, gamma, beta, slope, ws, pws, in_nt_flag());
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
     }
     return LNN_OK;

@@ -36,7 +36,8 @@ class GradAllReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = dist.is_initialized() and (self.world > 1 or force)   # force: exercise the path on one rank
         self.buckets = make_buckets(grad.numel(), max(1, bucket_bytes // grad.element_size()))
-        self.overlap = overlap and grad.is_cuda
+        # host tensors (gloo, CPU tests): the same watermark-driven bucket order, each all-reduce simply runs in line
+        self.overlap = overlap
         self.stream = torch.cuda.Stream() if grad.is_cuda else None
         self.next = 0
         self._used = set()
@@ -54,7 +55,7 @@ class GradAllReducer:
         if not self.active:
             return
         view = self.grad[lo:hi]
-        stream = stream if stream is not None else self.stream
+        stream = (stream if stream is not None else self.stream) if self.grad.is_cuda else None
         if stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())

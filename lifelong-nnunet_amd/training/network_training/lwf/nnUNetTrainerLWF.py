@@ -16,7 +16,9 @@ own ``run_iteration`` / ``calculate_target_logits`` produced):
     1x1x1 convs run on the body activations the training forward just produced (``engine.forward(body=False)``) instead
     of T extra full forwards;
   * the LwF branch also runs for the no-backprop iterations of the epoch loop (only ``freeze_run`` / ``do_val`` select the
-    plain branch, LWF.py:303), so ``batch_idx`` advances there too.
+    plain branch, LWF.py:303), so ``batch_idx`` advances there too;
+  * the plain branch of the freeze run / validation is UPSTREAM's base iteration (``super(nnUNetTrainerV2, self)``,
+    LWF.py:305): it does not clip the gradient norm at 12 (pinned by tests/golden/lwf_phase1_reference.*).
 MI355X-first differences that do not change results:
   * teacher logits and predictions stay in HBM (288 GB) instead of round-tripping through host memory
     (``.cpu()`` at LWF.py:343, HF.py:254); the KL is one fused device reduction instead of CPU fp32 ops.
@@ -121,6 +123,16 @@ class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
         self.loss.update_logits(all_pred_logits, self._targets(heads))
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, *args, **kwargs):
+        if self.freeze_run or self.do_val:
+            # LWF.py:303-308: ``super(nnUNetTrainerV2, self).run_iteration`` -- upstream's PLAIN iteration (zero_grad, forward,
+            # loss, backward, optimizer step): no clip_grad_norm_(12), which lives in nnUNetTrainerV2.run_iteration that
+            # this call skips -- followed by the head refresh.  Pinned by tests/golden/lwf_phase1_reference.* (the reference's
+            # method executed with gradient norms of 50+).
+            keep, self.max_grad_norm = self.max_grad_norm, None
+            try:
+                return super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
+            finally:
+                self.max_grad_norm = keep
         if not self._lwf_active():
             return super().run_iteration(data_generator, do_backprop, run_online_evaluation, *args, **kwargs)
         if self.same_batch_predictions:

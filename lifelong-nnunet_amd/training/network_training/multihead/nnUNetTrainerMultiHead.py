@@ -76,6 +76,7 @@ class nnUNetTrainerMultiHead:
         self.tasks_list_with_char = tasks_list_with_char
         # upstream nnUNetTrainerV2 constants
         self.initial_lr, self.weight_decay = 1e-2, 3e-5
+        self.max_grad_norm = 12.0       # clip_grad_norm_(parameters, 12) of the iteration (MH.py:629,640); None: no clipping
         self.max_num_epochs = 500
         self.num_batches_per_epoch, self.num_val_batches_per_epoch = 250, 50
         self.epoch = 0
@@ -231,7 +232,7 @@ class nnUNetTrainerMultiHead:
             inv = world_avg / scale
             self.last_inv_scale = inv
             self.optimizer.grad_norm_pass(inv)                    # unscale_ + the norm of clip_grad_norm_(…, 12)
-            self.optimizer.step(inv_scale=inv, max_norm=12.0)      # clip coefficient + inf-skip applied on device
+            self.optimizer.step(inv_scale=inv, max_norm=float(self.max_grad_norm or 0.0))   # clip coefficient + inf-skip on device
         if run_online_evaluation:
             self.run_online_evaluation(output, target)
             self._last_eval_keys = data_dict.get('keys')

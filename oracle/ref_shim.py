@@ -144,7 +144,32 @@ def maybe_to_torch(d):
     return d
 
 
-class nnUNetTrainerV2:
+class nnUNetTrainer:
+    """Stand-in for upstream ``nnUNetTrainer`` / ``NetworkTrainer`` (nnunet @ 77bc485, not in the reference tree): the ONE
+    upstream method the reference reaches around its own overrides -- ``super(nnUNetTrainerV2, self).run_iteration(...)`` in
+    the LwF freeze run (lwf/nnUNetTrainerLWF.py:303-305) lands on ``NetworkTrainer.run_iteration``, restated here from its
+    published form: zero_grad, forward, loss, backward, optimizer step -- NO gradient clipping (the clip at 12 lives in
+    ``nnUNetTrainerV2.run_iteration``, which that ``super`` call skips) and no head bookkeeping."""
+
+    def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False):
+        data_dict = next(data_generator)
+        data = maybe_to_torch(data_dict['data'])
+        target = maybe_to_torch(data_dict['target'])
+        self.optimizer.zero_grad()
+        assert not self.fp16, "the fixtures run the reference's fp32 branch on the CPU"
+        output = self.network(data)
+        del data
+        l = self.loss(output, target)
+        if do_backprop:
+            l.backward()
+            self.optimizer.step()
+        if run_online_evaluation:
+            self.run_online_evaluation(output, target)
+        del target
+        return l.detach().cpu().numpy()
+
+
+class nnUNetTrainerV2(nnUNetTrainer):
     """Inert base class: the reference's trainers only need it to exist; the methods we execute are the reference's own."""
 
     def __init__(self, *a, **k):

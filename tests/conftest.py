@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout(seconds): per-test limit (pytest-timeout; a no-op marker where the plugin is absent)")
 
 
 @pytest.fixture(scope="session")

@@ -170,6 +170,27 @@ def test_lwf_trainer_flow():
     from lifelong_nnunet_amd.losses import kl_logits
     assert abs(float(kl_logits(loss.pred_logits[0], loss.target_logits[0], 2.0)) - kl_o) <= 1e-4 * abs(kl_o) + 1e-9
     assert not all(torch.equal(body0[n], p) for n, p in tr.mh_network.body.named_parameters())   # phase 3 trains the body
+    # per-head validation while the LwF loss is live (LWF.py on_epoch_end sets do_val around it): plain iterations -- the
+    # teacher-logit index must not move, every head is evaluated, do_val is restored
+    tr.freeze_run, tr.loss = False, tr.LwFloss
+    idx, consumed = tr.batch_idx, []
+    orig_provider = tr.data_provider
+
+    def counting_provider(task, split, plans):
+        gen = orig_provider(task, split, plans)
+
+        class G:
+            def __iter__(self_):
+                return self_
+
+            def __next__(self_):
+                consumed.append(task)
+                return next(gen)
+        return G()
+    tr.data_provider = counting_provider
+    res = tr._perform_validation(num_batches=2)
+    assert tr.batch_idx == idx and tr.do_val is False and set(res.keys()) == {"taskA", "taskB"}
+    assert len(consumed) == 2 * 2 * 2        # per head and batch: one batch for the names, one for the prediction (tee(), MH.py:812-819)
 
 
 def test_sequential_trainer_heads_and_checkpoint():

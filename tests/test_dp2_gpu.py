@@ -1,0 +1,168 @@
+"""-m gpu: a REAL second rank on the 1-GPU test box -- two processes on ``cuda:0`` with the ``gloo`` backend (it all-reduces
+device tensors by staging them through host memory), running the HIP trainers data-parallel (SURVEY.md 8e "Verification":
+N ranks on shards == 1 rank on the concatenated batch).  Covered with two ranks: ``engine.backward(progress=)`` with the
+watermark-driven bucket launches, the gradient average folded into the optimiser, the global-norm clip after the exchange,
+``batch_dice=True`` (tp/fp/fn exchange inside the loss), the EWC trainer's deferred exchange, its parity-mode Fisher
+(square of the ALL-REDUCED gradient) and ``fisher_mode='accumulate'`` (Fisher arenas all-reduced once per task).
+RCCL itself (``nccl`` backend) needs one device per rank: it is exercised at world size 1 in tests/test_dp_gpu.py and by
+the driver's multi-GPU bench."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+TOY = {"patch_size": (16, 32, 16), "batch_size": 2, "num_pool": 2, "base_num_features": 8, "num_classes": 3,
+       "num_input_channels": 1}
+DEV = "cuda:0"
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _batches(n, B, seed):
+    from lifelong_nnunet_amd.synthetic import make_patch_batch
+    out = []
+    for i in range(n):
+        d, t = make_patch_batch(B, TOY["patch_size"], 2, seed=seed + i)
+        out.append({"data": d, "target": t, "keys": [f"c{j}" for j in range(B)]})
+    return out
+
+
+def _shard(b, r, per):
+    return {"data": b["data"][r * per:(r + 1) * per], "target": [t[r * per:(r + 1) * per] for t in b["target"]],
+            "keys": b["keys"][r * per:(r + 1) * per]}
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    solo = [dist.new_group([r]) for r in range(world)][rank]           # every rank creates all groups; keeps its own
+    try:
+        probe = torch.ones(4, device=DEV)
+        dist.all_reduce(probe)
+        assert float(probe[0]) == world
+    except Exception as e:                                              # a torch build whose gloo cannot take device tensors
+        if rank == 0:
+            out["unsupported"] = repr(e)
+        dist.destroy_process_group()
+        return
+    from lifelong_nnunet_amd import get_trainer_class
+    from lifelong_nnunet_amd.parallel import make_buckets
+    res = {}
+    for ext, bd in (("sequential", False), ("sequential", True), ("ewc", False)):
+        full = _batches(5, 2 * world, seed=300)                         # global batches of 2 x world patches
+        torch.manual_seed(7)
+        kw = dict(fisher_mode="last_batch") if ext == "ewc" else {}
+        # ---- data parallel: this rank's shard of every batch
+        dp = get_trainer_class(ext)("seg_outputs", "A", plans=dict(TOY), device=DEV, batch_dice=bd, **kw)
+        dp.initialize(True, num_epochs=1)
+        assert dp.dp is not None and dp.dp.active and dp.dp.world == world
+        dp.dp.buckets = make_buckets(dp.network.arena.grad.numel(), 4096)        # several buckets become final DURING backward
+        sd = [dp.network.state_dict()]
+        dist.broadcast_object_list(sd, src=0)                                   # same initial weights on every rank
+        dp.network.load_state_dict(sd[0])
+        dp.mh_network.update_after_iteration()
+        launches = []
+        orig = dp.dp._launch
+        dp.dp._launch = lambda lo, hi, stream=None: (launches.append((lo, hi, stream is not None)), orig(lo, hi, stream))[1]
+        ref = None
+        if rank == 0:
+            # ---- the oracle of this layer: ONE rank (its own single-rank group) on the concatenated batches
+            plans = dict(TOY); plans["batch_size"] = 2 * world
+            ref = get_trainer_class(ext)("seg_outputs", "A", plans=plans, device=DEV, batch_dice=bd, process_group=solo, **kw)
+            ref.initialize(True, num_epochs=1)
+            assert ref.dp is None
+            ref.network.load_state_dict(sd[0])
+            ref.mh_network.update_after_iteration()
+        ldp, lref = [], []
+        for b in full[:2]:
+            ldp.append(float(dp.run_iteration(iter([_shard(b, rank, 2)]), True)))
+            if ref is not None:
+                lref.append(float(ref.run_iteration(iter([b]), True)))
+        key = f"{ext}_bd{int(bd)}"
+        # every bucket exactly once per step, tail-first; with the deferred exchange (EWC) all of them after backward
+        n_b = len(dp.dp.buckets)
+        assert [l[:2] for l in launches[:n_b]] == dp.dp.buckets and len(launches) == 2 * n_b
+        res[key + "_during_backward"] = sum(l[2] for l in launches)
+        th = dp.network.arena.theta.clone()
+        gath = [torch.zeros_like(th) for _ in range(world)]
+        dist.all_gather(gath, th)
+        assert all(torch.equal(gath[0], g) for g in gath)                        # replicas stay bit-identical
+        if rank == 0:
+            # the loss a rank reports is its SHARD's loss (batch Dice: from the global sums); the mean over ranks is the full loss
+            res[key + "_theta"] = _rel(th, ref.network.arena.theta)
+            res[key + "_norm"] = abs(dp.last_grad_norm - ref.last_grad_norm) / ref.last_grad_norm
+        lt = torch.tensor(ldp, device=DEV)
+        dist.all_reduce(lt)
+        if rank == 0:
+            res[key + "_loss"] = max(abs(float(a) / world - b) / abs(b) for a, b in zip(lt, lref))
+        if ext == "ewc":
+            # parity-mode Fisher = square of the averaged gradient of the last after_train batch (EWC.py:252-310)
+            dp.num_batches_per_epoch = 2
+            dp.fisher["A"], dp.params["A"] = {}, {}
+            dp.tr_gen = iter([_shard(b, rank, 2) for b in full[2:4]])
+            dp.after_train()
+            if rank == 0:
+                ref.num_batches_per_epoch = 2
+                ref.fisher["A"], ref.params["A"] = {}, {}
+                ref.tr_gen = iter(full[2:4])
+                ref.after_train()
+                names = [n for n in dp.fisher["A"] if dp.fisher["A"][n].numel() > 1]
+                fa = torch.cat([dp.fisher["A"][n].reshape(-1) for n in names])
+                fb = torch.cat([ref.fisher["A"][n].reshape(-1) for n in names])
+                res["ewc_fisher_last_batch"] = _rel(fa, fb)
+            # accumulate mode: mean over ranks and batches of the squared per-(rank, batch) gradient == one rank walking
+            # over the union of the shards as separate batches
+            dp.fisher_mode = "accumulate"
+            dp.fisher["A"], dp.params["A"] = {}, {}
+            dp.tr_gen = iter([_shard(b, rank, 2) for b in full[2:4]])
+            dp.after_train()
+            if rank == 0:
+                plans = dict(TOY)
+                one = get_trainer_class("ewc")("seg_outputs", "A", plans=plans, device=DEV, process_group=solo, fisher_mode="accumulate")
+                one.initialize(True, num_epochs=1)
+                one.network.load_state_dict(dp.network.state_dict())
+                one.mh_network.update_after_iteration()
+                one.amp_grad_scaler.load_state_dict(dp.amp_grad_scaler.state_dict())
+                one.num_batches_per_epoch = 2 * world
+                one.fisher["A"], one.params["A"] = {}, {}
+                one.tr_gen = iter([_shard(b, r, 2) for b in full[2:4] for r in range(world)])
+                one.after_train()
+                fa = torch.cat([dp.fisher["A"][n].reshape(-1) for n in names])
+                fb = torch.cat([one.fisher["A"][n].reshape(-1) for n in names])
+                res["ewc_fisher_accumulate"] = _rel(fa, fb)
+        del dp, ref
+        torch.cuda.empty_cache()
+    if rank == 0:
+        out.update(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(420)
+def test_two_ranks_on_one_gpu_match_the_single_rank_step():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    out = dict(out)
+    if "unsupported" in out:
+        pytest.skip("gloo cannot all-reduce device tensors in this build: " + out["unsupported"])
+    print("2-rank HIP data parallel vs 1 rank on the concatenated batch:", out)
+    for key in ("sequential_bd0", "sequential_bd1", "ewc_bd0"):
+        assert out[key + "_loss"] < 1e-4, (key, out)
+        assert out[key + "_theta"] < 2e-5, (key, out)            # fp16 runs: order of the weight-gradient atomics / of the rank sum
+        assert out[key + "_norm"] < 1e-3, (key, out)
+    assert out["sequential_bd0_during_backward"] > 0 and out["sequential_bd1_during_backward"] > 0
+    assert out["ewc_bd0_during_backward"] == 0                   # deferred: the penalty's autograd node adds to the arena after backward
+    assert out["ewc_fisher_last_batch"] < 2e-2 and out["ewc_fisher_accumulate"] < 1e-4, out

@@ -371,3 +371,56 @@ def test_evaluator_summary_matches_the_reference_arithmetic():
     sm = summarize(got)
     assert sm["mask_1"]["Dice"]["n"] == 4 and sm["mask_2"]["Dice"]["n"] == 5
     assert abs(sm["mask_1"]["Dice"]["mean"] - np.mean([got[f"case_{i}"]["mask_1"]["Dice"] for i in range(4)])) < 1e-12
+
+
+def test_load_checkpoint_written_by_the_reference_classes(golden_dir):
+    """tests/golden/checkpoint_reference.* (oracle/make_goldens_checkpoint.py): ``state_dict()`` of the REFERENCE's
+    ``MultiHead_Module`` (two heads, head B trained for three steps) and of the ``torch.optim.SGD`` that trained it -- what
+    MH.py:1164-1197 / upstream ``save_checkpoint`` put into a ``.model`` file.  ``load_checkpoint_ram`` (MH.py:1278-1313)
+    must rebuild both heads, the running model, the per-parameter momentum buffers and the epoch from it, and
+    ``save_checkpoint`` must write the same state dict back, key for key and bit for bit."""
+    import json
+    from collections import OrderedDict
+    from lifelong_nnunet_amd import get_trainer_class
+    meta = json.load(open(os.path.join(golden_dir, "checkpoint_reference.json")))
+    arr = np.load(os.path.join(golden_dir, "checkpoint_reference.npz"))
+    sd = OrderedDict((k, torch.from_numpy(arr["sd::" + k])) for k in meta["state_dict_keys"])
+    opt_state = {i: {"momentum_buffer": torch.from_numpy(arr[f"opt::{i}"])} for i in meta["optimizer_state_indices"]}
+    group = dict(meta["optimizer_group"], params=meta["optimizer_params"], maximize=False, foreach=None, differentiable=False, fused=None)
+    ckpt = {"epoch": meta["epoch"], "state_dict": OrderedDict(("module." + k, v) for k, v in sd.items()),      # DataParallel prefix, as upstream strips it
+            "optimizer_state_dict": {"state": opt_state, "param_groups": [group]}, "lr_scheduler_state_dict": None,
+            "plot_stuff": ([0.5, 0.4], [0.6, 0.5], [], []), "best_stuff": (None, None, None)}
+    plans = {"patch_size": (16, 16, 16), "batch_size": 2, "num_pool": 2, "base_num_features": 8, "num_classes": 3, "num_input_channels": 1}
+    tr = get_trainer_class("multihead")("seg_outputs", "taskA", plans=plans, device="cpu")
+    tr.initialize(True, num_epochs=5)
+    # the reference keeps the head list / active task in <ext>_trained_on.pkl (MH.py:1174-1180, 1283-1290)
+    tr.already_trained_on = {"0": {"tasks_at_time_of_checkpoint": meta["heads"], "active_task_at_time_of_checkpoint": meta["active_task"]}}
+    tr.load_checkpoint_ram(ckpt, train=True)
+    assert list(tr.mh_network.heads.keys()) == meta["heads"] and str(tr.mh_network.active_task) == meta["active_task"]
+    got = tr.mh_network.state_dict()
+    assert list(got.keys()) == meta["state_dict_keys"]
+    for k in meta["state_dict_keys"]:
+        assert torch.equal(got[k].cpu(), sd[k]), k
+    # the running model carries body + the ACTIVE head (B); head A is a different tensor set
+    model = dict(tr.network.named_parameters())
+    for n, p in model.items():
+        assert torch.equal(p.detach().cpu(), sd["model." + n])
+        if n.startswith("seg_outputs."):
+            assert torch.equal(p.detach().cpu(), sd["heads.taskB." + n])
+    assert any(not torch.equal(sd["heads.taskA." + n], sd["heads.taskB." + n]) for n in model if n.startswith("seg_outputs."))
+    # momentum buffers: torch.optim.SGD indexes the TRAINABLE parameters in network.parameters() order
+    names = [n for n, _ in tr.optimizer._trainable()]
+    assert names == meta["optimizer_param_names"]
+    by_name = dict(tr.network._named)
+    for i in meta["optimizer_state_indices"]:
+        s = by_name[names[i]]._lnn_slot
+        assert torch.equal(tr.network.arena.momentum[s.offset:s.offset + s.numel].cpu(), opt_state[i]["momentum_buffer"].reshape(-1)), names[i]
+    assert set(range(len(names))) - set(meta["optimizer_state_indices"]) == {names.index("seg_outputs.0.weight")}   # never stepped: no state
+    assert tr.epoch == meta["epoch"] and tr.all_tr_losses == [0.5, 0.4] and tr.optimizer.param_groups[0]["lr"] == meta["optimizer_group"]["lr"]
+    # ... and the way back: the checkpoint this trainer writes equals the reference's, tensor for tensor
+    out = tr.save_checkpoint(None)
+    assert list(out["state_dict"].keys()) == meta["state_dict_keys"]
+    assert all(torch.equal(out["state_dict"][k], sd[k]) for k in sd)
+    assert sorted(out["optimizer_state_dict"]["state"].keys()) == meta["optimizer_state_indices"]
+    assert all(torch.equal(out["optimizer_state_dict"]["state"][i]["momentum_buffer"], opt_state[i]["momentum_buffer"])
+               for i in meta["optimizer_state_indices"])

@@ -248,7 +248,8 @@ def test_instnorm_lrelu_seg_bwd_fused(N, C, K, V3, prior):
     assert rel_err(dw.cpu(), 0.5 * w.grad.view(K, C)) < 1e-3
     # same rounding points as the unfused pair: agreement to fp32 summation order (dy differs by at most an fp16 ulp where it does)
     assert rel_err(from_cl_h(yb, C), from_cl_h(yb_u, C)) < 1e-3
-    assert rel_err(dw.cpu(), dw_u.cpu()) < 1e-4 and rel_err(dg.cpu(), dg_u.cpu()) < 1e-4 and rel_err(db.cpu(), db_u.cpu()) < 1e-4
+    # (the fused reduction keeps dz and z in fp32 where the unfused pair rounds both to fp16 in memory: 2^-11 noise per element)
+    assert rel_err(dw.cpu(), dw_u.cpu()) < 1e-3 and rel_err(dg.cpu(), dg_u.cpu()) < 1e-3 and rel_err(db.cpu(), db_u.cpu()) < 1e-3
 
 
 @pytest.mark.parametrize("batch_dice", [0, 1])

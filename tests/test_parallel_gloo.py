@@ -40,9 +40,19 @@ def _worker(rank, world, port, out):
     assert len(red.buckets) > 3
     red.begin()
     # simulate backward progress: watermarks walk from the tail to the head of the arena
+    launched = []
+    orig = red._launch
+    red._launch = lambda lo, hi, stream=None: (launched.append((lo, hi)), orig(lo, hi, stream))[1]
+    seen_before_finish = 0
     for wm in range(flat.numel(), -1, -flat.numel() // 7):
         red.progress(wm)
+        assert all(lo >= wm for lo, hi in launched)          # only buckets that lie entirely behind the watermark
+        seen_before_finish = len(launched)
+    assert 0 < seen_before_finish <= len(red.buckets)
+    red.progress(0)                                          # backward has reached the head of the arena
+    assert len(launched) == len(red.buckets)                 # the watermark walk itself drove the whole exchange (not finish())
     red.finish()
+    assert launched == red.buckets                           # tail-first, each bucket exactly once
     flat *= red.averaging_factor
     if rank == 0:
         net.zero_grad()
