@@ -163,7 +163,7 @@ def regulariser_rooflines(trainer, plans):
     lg = torch.randn((B, K, V), device=dev)
     lt = torch.randn((B, K, V), device=dev)
     lab = torch.randint(0, K, (B, V), device=dev).float()
-    kl_out, kl_ws = torch.zeros(1, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    kl_out, kl_ws = torch.zeros(1, device=dev), torch.zeros(nat.query("lnn_kl_logits_ws_doubles", B), dtype=torch.float64, device=dev)
     dws = torch.zeros(nat.query("lnn_dice_ce_ws_doubles", B, K), dtype=torch.float64, device=dev)
     dl = torch.empty_like(lg)
     cases = {

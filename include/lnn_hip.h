@@ -260,10 +260,12 @@ int lnn_softmax_finalize(lnn_stream_t s, float* agg, const float* nb, int K, lon
 /* ------------------------------------------------------------------------------------------------
  * LwF distillation (deep_supervision.py:194-196):
  *   out = (1/N) sum_{n,k,v} softmax(t/T)_k * (logsoftmax(t/T)_k - logsoftmax(y/T)_k)
- * pred / teach: (N,K,V) fp32.  out: one float.  ws: >= 1 double.
+ * pred / teach: (N,K,V) fp32.  out: one float.  ws: >= lnn_kl_logits_ws_doubles(N) doubles of scratch (per-block partial
+ * sums, folded in a fixed order: the result is deterministic; contents on entry do not matter).
  * ---------------------------------------------------------------------------------------------- */
 int lnn_kl_logits(lnn_stream_t s, const float* pred, const float* teach, int N, int K, long V, float T,
                   float* out, double* ws);
+size_t lnn_kl_logits_ws_doubles(int N);
 
 /* ------------------------------------------------------------------------------------------------
  * PLOP / POD (plop/nnUNetTrainerPLOP.py, pod/nnUNetTrainerPOD.py; deep_supervision.py:217-381, embeddings.py:3-41).

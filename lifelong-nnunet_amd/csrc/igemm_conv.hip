@@ -582,7 +582,6 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
     }
     if (use_down2() && use_down2s(p)) {
-        for (int t = 0; t < 27; ++t) p.taps.slot[t] = (unsigned char)t;
         if (stats_pws && ld_y == K && lnn_down2s_stats_slots(p) <= 1024) {      // fused InstanceNorm statistics (dense output tensor only)
             p.stats_pws = stats_pws;
             const int rc = lnn_launch_down2s(s, p, "lnn_conv3d_fwd(s2,down2s,stats)");
@@ -756,6 +755,7 @@ extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy
     p.N = N; p.Di = 2 * D; p.Hi = 2 * H; p.Wi = 2 * W; p.Do = D; p.Ho = H; p.Wo = W;
     p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16); p.wtaps = 8;
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 1; p.pad_lo = 0; p.accumulate = accumulate;
+    if (use_down2() && use_down2s(p)) return lnn_launch_down2s(s, p, "lnn_convT3d_k2s2_dgrad(down2s)");
     if (use_down2()) return lnn_launch_down2_convT_dgrad(s, p, "lnn_convT3d_k2s2_dgrad(down2)");
     constexpr int PY = 2 * 7 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=8
     p.taps.ntaps = 8;

@@ -18,6 +18,9 @@
 // ((pxh >> 2) & 1) | (((py >> 1) & 1) << 1); the DMA writes LDS linearly, so the key (and the de-interleave) is applied to
 // the SOURCE address each lane fetches.  Wave roles, weight-row rotation, partial-sum exchange, v_permlane32_swap epilogue
 // and the InstanceNorm-statistics epilogue are those of v9 (NCK chunks x NMB output blocks x NF footprints = 8 waves).
+// EXT = 2: the data gradient of the 2x2x2 stride-2 transposed conv (`tu`, nnViTUNetTrainer.py:122) is the same gather with 8 taps
+// and no padding: out[l] = sum_{d in {0,1}^3} W[d] in[2 l + d] -- even plane: taps dz = 0, odd plane: dz = 1, one accumulator,
+// no overlap between output planes (4 MFMAs per wave and plane: purely bound by the 4x larger input).
 #include "igemm_common.h"
 
 namespace {
@@ -64,15 +67,20 @@ __device__ __forceinline__ void lane_voxel_d(int v, int& r, int& x) {   // see i
     else { r = 3; x = v - 24; }
 }
 
-template <int NCK_, int NMB_, int NF_>
+template <int NCK_, int NMB_, int NF_, int EXT_ = 3>
 struct D2 {
-    static constexpr int NCK = NCK_, NMB = NMB_, NF = NF_;
+    static constexpr int NCK = NCK_, NMB = NMB_, NF = NF_, EXT = EXT_;
+    static_assert(EXT == 2 || EXT == 3, "3x3x3 pad 1 or 2x2x2 pad 0");
+    static constexpr int PAD = EXT == 3 ? 1 : 0;
+    static constexpr int LEND = EXT == 3 ? 1 : 0;            // walked outputs in front of a segment that only lend their odd plane
+    static constexpr int NIP = EXT * EXT, NTAPS = EXT * EXT * EXT;   // in-plane taps, taps
+    static constexpr int NB = NIP % 3 == 0 ? 3 : 2;          // B-fragment register ring (reads run NB - 1 ahead of the MFMAs)
     static_assert(NCK * NMB * NF == 8 && (NCK == 2 || NCK == 4), "8 waves per block");
     static constexpr int NG = NCK / 2;                       // 32-channel groups of the input
     static constexpr int NFX = NF >= 4 ? 2 : 1, NFY = NF / NFX;
     static constexpr int FY = 4 * NFY, FX = 8 * NFX;         // block footprint (output voxels)
-    static constexpr int PY = 2 * FY + 1, PX = 2 * FX + 1;   // input patch of a plane
-    static constexpr int PXH = FX + 1, PXHS = (PXH + 1) / 2 * 2;   // positions per x-parity row; even stride: rows start 256-byte aligned
+    static constexpr int PY = 2 * FY + EXT - 2, PX = 2 * FX + EXT - 2;   // input patch of a plane
+    static constexpr int PXH = (PX + 1) / 2, PXHS = (PXH + 1) / 2 * 2;   // positions per x-parity row; even stride: rows start 256-byte aligned
     static constexpr int GRAW = PY * 2 * PXHS * 64;          // bytes of one group slab
     static constexpr int DPW = (NG * ((GRAW + 1023) / 1024) + 7) / 8;   // DMA instructions per wave per plane
     static constexpr int GSLAB = DPW * 8 / NG * 1024;
@@ -91,9 +99,10 @@ struct D2Launch {
 };
 
 // p: x / ld_x / Di,Hi,Wi = input, y / ld_y / Do,Ho,Wo = output (= Ld,Lh,Lw), p.C in {32, 64}, p.M % (32 NMB) == 0, pad 1.
-template <int NCK_, int NMB_, int NF_, bool STATS>
+template <int NCK_, int NMB_, int NF_, int EXT_, bool STATS>
 __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p, const D2Launch q) {
-    using K = D2<NCK_, NMB_, NF_>;
+    using K = D2<NCK_, NMB_, NF_, EXT_>;
+    constexpr int EXT = K::EXT, PAD = K::PAD, LEND = K::LEND, NIP = K::NIP, NTAPS = K::NTAPS, NB = K::NB;
     constexpr int NCK = K::NCK, NMB = K::NMB, NFX = K::NFX, PXHS = K::PXHS, PY = K::PY, PX = K::PX;
     constexpr int GSLAB = K::GSLAB, PLANE = K::PLANE, DPW = K::DPW, D = K::D, R = K::R, QN = K::QN, EXB = K::EXB;
     constexpr int ROWB = 2 * PXHS * 64;                      // bytes of one input row (both parities)
@@ -143,11 +152,11 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
     for (int jj = 1; jj < NCK; ++jj)
         wbase[jj - 1] = ((gi * NCK + (ck + jj) % NCK) * (NCK - 1) + (NCK - jj - 1)) * QN * 1024 + lane * 16;
 
-    half8 A[27];
+    half8 A[NTAPS];
     float biasv[4 * QN];
     int cur_mg = -1;
     floatx16 acc[2];
-    half8 b[3];
+    half8 b[NB];
     float own[4 * QN];
 #pragma unroll
     for (int i = 0; i < 4 * QN; ++i) own[i] = 0.f;
@@ -168,17 +177,17 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
         const int mg = it / p.N;
         const int y0 = fyb * K::FY, x0 = fxb * K::FX;                      // output coordinates of the footprint
         const int zs0 = zs * q.L, zs1 = min(zs0 + q.L, p.Ld);              // output planes [zs0, zs1)
-        // walked output planes o = zs0 - 1 .. zs1 - 1 (the first only lends its odd plane to zs0); plane step hs covers
-        // input plane zin = 2 (zs0 - 1) + hs
-        const int NO = zs1 - zs0 + 1;
+        // walked output planes o = zs0 - LEND .. zs1 - 1 (3x3x3: the first only lends its odd plane to zs0); plane step hs
+        // covers input plane zin = 2 (zs0 - LEND) + hs
+        const int NO = zs1 - zs0 + LEND;
 
         const int m0 = 32 * (mg * NMB + mb);
         if (mg != cur_mg) {
             cur_mg = mg;
             const int row = ((lane & 31) + 8 * QN * ck) & 31;
 #pragma unroll
-            for (int tl = 0; tl < 27; ++tl) {
-                const half_t* wp = p.wp + lnn_panel_off(p.taps.slot[tl], m0, 16 * ck, 27, p.KCpad);
+            for (int tl = 0; tl < NTAPS; ++tl) {
+                const half_t* wp = p.wp + lnn_panel_off(tl, m0, 16 * ck, NTAPS, p.KCpad);
                 A[tl] = *reinterpret_cast<const half8*>(wp + row * 16 + hk * 8);
             }
 #pragma unroll
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
         float ssum[4 * QN], ssq[4 * QN];
 #pragma unroll
         for (int i = 0; i < 4 * QN; ++i) ssum[i] = ssq[i] = 0.f;
-        const int iy0 = 2 * y0 - 1, ix0 = 2 * x0 - 1;                      // input coordinates of patch position (0, 0)
+        const int iy0 = 2 * y0 - PAD, ix0 = 2 * x0 - PAD;                  // input coordinates of patch position (0, 0)
         int dvoff[DPW];
 #pragma unroll
         for (int k = 0; k < DPW; ++k) {
@@ -211,14 +220,14 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
         }
 
         const long in_plane = (long)p.Hi * p.Wi * p.ld_x, out_plane = (long)p.Ho * p.Wo * p.ld_y;
-        const int zin0 = 2 * (zs0 - 1);                                    // input plane of step 0 (may be negative)
+        const int zin0 = 2 * (zs0 - LEND);                                 // input plane of step 0 (may be negative)
         const half_t* din = p.x + ((long)n * p.Di + zin0) * in_plane;
         int dtp = 0, dslot_off = 0;
         const int nsteps_in = 2 * NO;                                      // plane steps that carry data
         auto dma = [&]() {                  // next input plane of this item -> next ring slot
             const int zin = zin0 + dtp;
             // the even plane of the lending output (step 0) contributes nothing: fetch zeros instead of touching memory
-            const bool zok = dtp >= 1 && dtp < nsteps_in && zin >= 0 && zin < p.Di;
+            const bool zok = dtp >= LEND && dtp < nsteps_in && zin >= 0 && zin < p.Di;
             const int nrec = zok ? (int)in_plane_bytes : 0;
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)din, 0, nrec, 0x00020000);
 #pragma unroll
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
         };
 
         // output plane finalised after the odd step of walked output w (z = zs0 - 1 + w): own quads + partial sums -> y
-        half_t* optr = p.y + ((long)n * p.Do + (zs0 - 2)) * out_plane;     // plane of the first call, fin_store(-1); never dereferenced below zs0
+        half_t* optr = p.y + ((long)n * p.Do + (zs0 - LEND - 1)) * out_plane;   // plane of the first call, fin_store(-1); never dereferenced below zs0
         floatx4 pv[(NCK - 1) * QN];
         auto fin_load = [&](int w) {
             const char* eb = exch + (w & 1) * EXB + rbase;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
             for (int s = 0; s < (NCK - 1) * QN; ++s) pv[s] = *reinterpret_cast<const floatx4*>(eb + s * 1024);
         };
         auto fin_store = [&](int w) {
-            const bool ov = w >= 1 && w < NO;
+            const bool ov = w >= LEND && w < NO;
             float fin[4 * QN];
 #pragma unroll
             for (int i = 0; i < 4 * QN; ++i) fin[i] = own[i];
@@ -282,8 +291,8 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
             }
         };
 
-        auto ldb = [&](int slot_off, int i) -> half8 {      // i = dy * 3 + dx (compile time after unrolling)
-            const int dy = i / 3, dx = i % 3;
+        auto ldb = [&](int slot_off, int i) -> half8 {      // i = dy * EXT + dx (compile time after unrolling)
+            const int dy = i / EXT, dx = i % EXT;
             return *reinterpret_cast<const half8*>(smem + slot_off + lbase[dx][dy >> 1] + dy * ROWB);
         };
 
@@ -292,8 +301,8 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
         for (int tp = 0; tp < D; ++tp) dma();
         wait_vm<(D - 2) * DPW, false>();
         __builtin_amdgcn_s_barrier();
-        b[0] = ldb(0, 0);
-        b[1] = ldb(0, 1);
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) b[i] = ldb(0, i);
         int ro = 0;
 
         // one input plane.  ODD: taps dz = 2 into acc[CUR] (completing it) and dz = 0 into acc[1 - CUR] (starting the next
@@ -305,15 +314,21 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
             dma();
             const int rn = ro + PLANE == R * PLANE ? 0 : ro + PLANE;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                if constexpr (!ODD) { if (i == 3) fin_store(w - 1); }
-                const int ii = i + 2;
-                b[ii % 3] = ii < 9 ? ldb(ro, ii) : ldb(rn, ii - 9);
-                if constexpr (ODD) {
-                    acc[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[18 + i], b[i % 3], acc[CUR], 0, 0, 0);
-                    acc[1 - CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], b[i % 3], i == 0 ? zero16 : acc[1 - CUR], 0, 0, 0);
+            for (int i = 0; i < NIP; ++i) {
+                if constexpr (!ODD) { if (i == (NIP > 4 ? 3 : 1)) fin_store(w - 1); }
+                const int ii = i + NB - 1;
+                b[ii % NB] = ii < NIP ? ldb(ro, ii) : ldb(rn, ii - NIP);
+                if constexpr (EXT == 3) {
+                    if constexpr (ODD) {
+                        acc[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[18 + i], b[i % NB], acc[CUR], 0, 0, 0);
+                        acc[1 - CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], b[i % NB], i == 0 ? zero16 : acc[1 - CUR], 0, 0, 0);
+                    } else {
+                        acc[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[9 + i], b[i % NB], acc[CUR], 0, 0, 0);
+                    }
                 } else {
-                    acc[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[9 + i], b[i % 3], acc[CUR], 0, 0, 0);
+                    // 2x2x2: even plane = taps dz 0 (starting the output plane), odd plane = taps dz 1 (completing it)
+                    acc[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(ODD ? NIP : 0) + i], b[i % NB],
+                                                                      (!ODD && i == 0) ? zero16 : acc[CUR], 0, 0, 0);
                 }
             }
             ro = rn;
@@ -337,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
 
         // walked outputs w = 0 .. NO - 1 (two plane steps each) + one more even step that stores the last output, in rounds
         // of two outputs (static accumulator roles); the padding steps run on zero planes and store nothing
-        acc[0] = zero16;                                     // the lending output's accumulator (never stored)
+        acc[0] = zero16;                                     // (3x3x3) the lending output's accumulator, never stored
         const int NW = (NO + 1 + 1) / 2 * 2;
 #pragma unroll 1
         for (int w = 0; w < NW; w += 2) {
@@ -380,7 +395,7 @@ int launch_d2(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
         const int L = lnn_cdiv(p.Ld, S);
         if ((long)(S - 1) * L >= p.Ld) continue;                    // empty last segment
         const long items = cols * S;
-        const double cost = (double)lnn_cdiv(lnn_cdiv(items, 8), G / 8) * (2 * (L + 2) + 4);
+        const double cost = (double)lnn_cdiv(lnn_cdiv(items, 8), G / 8) * (2 * (L + 1 + K::LEND) + 4);
         if (cost < best * 0.97) { best = cost; bestS = S; }
     }
     D2Launch q;
@@ -392,14 +407,14 @@ int launch_d2(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
     const int grid = q.nslots * 8;
     static bool attr_set = false;     // per instantiation; idempotent attribute of the code object
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_down2s_kernel<K::NCK, K::NMB, K::NF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_down2s_kernel<K::NCK, K::NMB, K::NF, K::EXT, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
         attr_set = true;
     }
     if (STATS) {
         p.stats_nblk = grid * K::NF;
         hipMemsetAsync(p.stats_pws, 0, sizeof(float) * 2 * (size_t)p.stats_nblk * p.N * p.M, s);
     }
-    hipLaunchKernelGGL((igemm_down2s_kernel<K::NCK, K::NMB, K::NF, STATS>), dim3(grid), dim3(512), K::LDS, s, p, q);
+    hipLaunchKernelGGL((igemm_down2s_kernel<K::NCK, K::NMB, K::NF, K::EXT, STATS>), dim3(grid), dim3(512), K::LDS, s, p, q);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }
@@ -417,7 +432,8 @@ int d2_num_cu() {
 }  // namespace
 
 bool lnn_down2s_supported(const ConvParams& p) {
-    if (p.accumulate || p.pad_lo != 1) return false;
+    if (p.accumulate) return false;
+    if (!((p.pad_lo == 1 && p.wtaps == 27) || (p.pad_lo == 0 && p.wtaps == 8))) return false;
     if (p.C != 32 && p.C != 64) return false;
     if (p.M % 64 != 0) return false;
     if (p.ld_x % 8 != 0 || p.ld_y % 8 != 0) return false;
@@ -434,6 +450,10 @@ int lnn_down2s_stats_slots(const ConvParams& p) {
 
 int lnn_launch_down2s(hipStream_t s, ConvParams& p, const char* name) {
     const int num_cu = d2_num_cu();
+    if (p.wtaps == 8) {                 // transposed-conv data gradient: never feeds an InstanceNorm, no statistics instance
+        if (p.C == 32) return launch_d2<D2<2, 2, 2, 2>, false>(s, p, num_cu, name);
+        return launch_d2<D2<4, 2, 1, 2>, false>(s, p, num_cu, name);
+    }
     if (p.C == 32) {
         if (p.stats_pws) return launch_d2<D2<2, 2, 2>, true>(s, p, num_cu, name);
         return launch_d2<D2<2, 2, 2>, false>(s, p, num_cu, name);

@@ -422,26 +422,59 @@ __global__ __launch_bounds__(NT) void online_dice_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------- LwF KL
+// KL(softmax(t/T) || softmax(y/T)) summed over classes and voxels.  KT > 0: compile-time class count; VEC = 4: four consecutive
+// voxels per thread through 16-byte loads of every class plane (the scalar version with one fp64 atomicAdd per block sat at
+// 1.9 TB/s); per-block fp32 partials + a fixed-order fp64 finalize (deterministic, no workspace memset).
+template <int KT, int VEC>
 __global__ __launch_bounds__(NT) void kl_logits_kernel(const float* __restrict__ pred, const float* __restrict__ teach, int K,
-                                                       long V, float inv_t, double* ws) {
+                                                       long V, float inv_t, float* __restrict__ pws) {
+    constexpr int KK = KT > 0 ? KT : KMAX;
     __shared__ float sm[NT / 64];
     const int n = blockIdx.y;
     const float* pn = pred + (long)n * K * V;
     const float* tn = teach + (long)n * K * V;
     float acc[1] = {0.f};
-    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < V; v += (long)gridDim.x * NT) {
-        float pt[KMAX], xt[KMAX], lse_t, py[KMAX], xy[KMAX], lse_y;
-        softmax_k(tn, V, v, K, inv_t, pt, lse_t, xt);
-        softmax_k(pn, V, v, K, inv_t, py, lse_y, xy);
+    for (long v = ((long)blockIdx.x * NT + threadIdx.x) * VEC; v < V; v += (long)gridDim.x * NT * VEC) {
+        float xt[KMAX][VEC], xy[KMAX][VEC];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (k < K) acc[0] += pt[k] * ((xt[k] - lse_t) - (xy[k] - lse_y));
+        for (int k = 0; k < KK; ++k)
+            if (KT > 0 || k < K) {
+                if (VEC == 4) {
+                    const floatx4 a = *reinterpret_cast<const floatx4*>(tn + (long)k * V + v);
+                    const floatx4 b = *reinterpret_cast<const floatx4*>(pn + (long)k * V + v);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { xt[k][e] = a[e] * inv_t; xy[k][e] = b[e] * inv_t; }
+                } else {
+                    xt[k][0] = tn[(long)k * V + v] * inv_t;
+                    xy[k][0] = pn[(long)k * V + v] * inv_t;
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float a[KMAX], b[KMAX], pt[KMAX], py[KMAX], lse_t, lse_y;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) { a[k] = xt[k][e]; b[k] = xy[k][e]; }
+            softmax_regs<KT>(a, K, pt, lse_t);
+            softmax_regs<KT>(b, K, py, lse_y);
+#pragma unroll
+            for (int k = 0; k < KK; ++k)
+                if (KT > 0 || k < K) acc[0] += pt[k] * ((a[k] - lse_t) - (b[k] - lse_y));
+        }
     }
     block_sum<1>(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(ws, (double)acc[0]);
+    if (threadIdx.x == 0) pws[(long)n * gridDim.x + blockIdx.x] = acc[0];
 }
-__global__ void kl_finalize_kernel(const double* ws, int N, float* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(ws[0] / (double)N);
+__global__ __launch_bounds__(NT) void kl_finalize_kernel(const float* __restrict__ pws, int nparts, int N, float* out) {
+    __shared__ double red[NT];
+    double s = 0;
+    for (int b = threadIdx.x; b < nparts; b += NT) s += (double)pws[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)N);
 }
 
 // ---------------------------------------------------------------------------------------- MiB: CE and unbiased KD
@@ -728,15 +761,22 @@ extern "C" int lnn_softmax_finalize(lnn_stream_t s_, float* agg, const float* nb
     return LNN_OK;
 }
 
+extern "C" size_t lnn_kl_logits_ws_doubles(int N) { return ((size_t)N * 1024 + 1) / 2 + 1; }      // fp32 partial per (sample, block)
+
 extern "C" int lnn_kl_logits(lnn_stream_t s_, const float* pred, const float* teach, int N, int K, long V, float T,
                              float* out, double* ws) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(pred && teach && out && ws, "lnn_kl_logits: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX && T > 0.f, "lnn_kl_logits: K=%d / T unsupported", K);
-    hipMemsetAsync(ws, 0, sizeof(double), s);
-    hipLaunchKernelGGL(kl_logits_kernel, dim3(vox_blocks(V), N), dim3(NT), 0, s, pred, teach, K, V, 1.f / T, ws);
+    const int nblk = vox_blocks(V);
+    float* pws = reinterpret_cast<float*>(ws);
+    const bool vec = (V & 3) == 0 && lnn_aligned16(pred) && lnn_aligned16(teach);
+#define LNN_KL(KT, VEC) hipLaunchKernelGGL((kl_logits_kernel<KT, VEC>), dim3(nblk, N), dim3(NT), 0, s, pred, teach, K, V, 1.f / T, pws)
+    if (vec) { if (K == 3) LNN_KL(3, 4); else if (K == 2) LNN_KL(2, 4); else if (K == 4) LNN_KL(4, 4); else LNN_KL(0, 4); }
+    else { if (K == 3) LNN_KL(3, 1); else if (K == 2) LNN_KL(2, 1); else if (K == 4) LNN_KL(4, 1); else LNN_KL(0, 1); }
+#undef LNN_KL
     LNN_CHECK_LAUNCH("lnn_kl_logits");
-    hipLaunchKernelGGL(kl_finalize_kernel, dim3(1), dim3(64), 0, s, ws, N, out);
+    hipLaunchKernelGGL(kl_finalize_kernel, dim3(1), dim3(NT), 0, s, pws, nblk * N, N, out);
     LNN_CHECK_LAUNCH("lnn_kl_logits(finalize)");
     return LNN_OK;
 }

@@ -375,7 +375,7 @@ def kl_logits(pred, teach, temperature):
     N, K = p.shape[:2]
     V = p[0, 0].numel()
     out = torch.empty(1, device=dev)
-    ws = torch.empty(1, dtype=torch.float64, device=dev)
+    ws = torch.empty(nat.query("lnn_kl_logits_ws_doubles", N), dtype=torch.float64, device=dev)
     nat.call("lnn_kl_logits", p, t, N, K, V, float(temperature), out, ws)
     return out[0]
 

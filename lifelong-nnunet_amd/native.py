@@ -61,6 +61,7 @@ SIGNATURES = {
     "lnn_dice_ce_ws_doubles": (_sz, [_i, _i]),
     "lnn_online_dice_counts": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "lnn_kl_logits": (_i, [_p, _p, _p, _i, _i, _l, _f, _p, _p]),
+    "lnn_kl_logits_ws_doubles": (_sz, [_i]),
     "lnn_plop_pseudo_labels": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "lnn_local_pod": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _f, _i, _p, _p, _p]),
     "lnn_ewc_penalty_fwd": (_i, [_p, _p, _p, _p, _l, _f, _p, _p]),

@@ -295,7 +295,8 @@ def test_kl_logits_golden(golden_dir):
         for i in range(2):
             p = torch.from_numpy(d[f"pred_{i}"]).to(DEV); t = torch.from_numpy(d[f"teach_{i}"]).to(DEV)
             N, K = p.shape[:2]; V = p[0, 0].numel()
-            out = torch.zeros(1, device=DEV); ws = torch.zeros(1, dtype=torch.float64, device=DEV)
+            out = torch.zeros(1, device=DEV)
+            ws = torch.full((nat.query("lnn_kl_logits_ws_doubles", N),), float("nan"), dtype=torch.float64, device=DEV)    # contents must not matter
             nat.call("lnn_kl_logits", p, t, N, K, V, float(T), out, ws)
             exp = float(d[f"kl{i}_T{T}"])
             assert abs(float(out) - exp) <= 1e-5 * abs(exp)
@@ -518,6 +519,31 @@ def test_stride2_conv_streaming_kernel(N, C, K, D, H, W):
         nat.call("lnn_conv3d_fwd_in_stats", xb, None, C, 0, wp, b.to(DEV), y2, N, D, H, W, C, K, 2, 1e-5, m2, r2, ws, None, 0)
         assert torch.equal(y2, outs[1])
         assert float((m1 - m2).abs().max()) <= 2e-6 * float(m1.abs().max()) + 1e-7 and float((r1 - r2).abs().max()) <= 2e-6 * float(r1.abs().max())
+    finally:
+        nat.lib().lnn_debug_force_down2_kernel(-1)
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W", [(2, 64, 32, 8, 16, 8), (1, 128, 64, 17, 10, 18), (1, 64, 32, 3, 9, 17), (1, 128, 32, 6, 4, 8)])
+def test_convT_dgrad_streaming_kernel(N, C, K, D, H, W):
+    """The 2x2x2 variant of igemm_down2s (data gradient of the transposed conv: 8 taps, no padding, 32 / 64 gathered channels
+    = K) pinned by lnn_debug_force_down2_kernel(1): against autograd through F.conv_transpose3d and against the tile kernel."""
+    x = _rand((N, C, D, H, W), 1).requires_grad_(True)
+    w = _rand((C, K, 2, 2, 2), 2, 0.1).requires_grad_(True)
+    ref = F.conv_transpose3d(x, w, None, stride=2)
+    dy = _rand(ref.shape, 4)
+    ref.backward(dy)
+    dyb, _ = to_cl_h(dy, ld=K + 8, offset=8)
+    wp = pack_convT_dgrad(w.detach().to(DEV))
+    outs = {}
+    try:
+        for which in (0, 1):
+            assert nat.lib().lnn_debug_force_down2_kernel(which) == 0
+            dxb = torch.full((N, D, H, W, C + 16), 7.0, dtype=torch.float16, device=DEV)
+            nat.call("lnn_convT3d_k2s2_dgrad", View(dyb, 8), K + 8, wp, dxb, C + 16, N, D, H, W, C, K, 0)
+            assert rel_err(from_cl_h(dxb, C), x.grad) < 3e-3, which
+            assert bool((dxb[..., C:] == 7.0).all())
+            outs[which] = dxb
+        assert rel_err(from_cl_h(outs[1], C), from_cl_h(outs[0], C)) < 1e-3
     finally:
         nat.lib().lnn_debug_force_down2_kernel(-1)
 

@@ -14,14 +14,16 @@ from v9_emulate import lane_voxel
 
 
 class Cfg:
-    def __init__(s, NCK, NMB, NF):
-        s.NCK, s.NMB, s.NF = NCK, NMB, NF
+    def __init__(s, NCK, NMB, NF, EXT=3):
+        s.NCK, s.NMB, s.NF, s.EXT = NCK, NMB, NF, EXT
+        s.PAD = s.LEND = 1 if EXT == 3 else 0
+        s.NIP, s.NTAPS = EXT * EXT, EXT ** 3
         s.NG = NCK // 2
         s.NFX = 2 if NF >= 4 else 1
         s.NFY = NF // s.NFX
         s.FY, s.FX = 4 * s.NFY, 8 * s.NFX
-        s.PY, s.PX = 2 * s.FY + 1, 2 * s.FX + 1
-        s.PXH = s.FX + 1
+        s.PY, s.PX = 2 * s.FY + EXT - 2, 2 * s.FX + EXT - 2
+        s.PXH = (s.PX + 1) // 2
         s.PXHS = (s.PXH + 1) // 2 * 2
         s.GRAW = s.PY * 2 * s.PXHS * 64
         s.DPW = (s.NG * ((s.GRAW + 1023) // 1024) + 7) // 8
@@ -36,6 +38,7 @@ class Cfg:
 
 
 def emulate(K, x, w, bias, S=1):
+    """x (N,C,Di,Hi,Wi); w (M,C,EXT,EXT,EXT) in the gather orientation out[l] = sum_d W[d] in[2l + d - pad]."""
     N, C, Di, Hi, Wi = x.shape
     M = w.shape[0]
     Do, Ho, Wo = Di // 2, Hi // 2, Wi // 2
@@ -53,18 +56,18 @@ def emulate(K, x, w, bias, S=1):
         zs0, zs1 = zs * L, min(zs * L + L, Do)
         if zs0 >= zs1:
             continue
-        NO = zs1 - zs0 + 1
-        iy0, ix0 = 2 * y0 - 1, 2 * x0 - 1
-        zin0 = 2 * (zs0 - 1)
+        NO = zs1 - zs0 + K.LEND
+        iy0, ix0 = 2 * y0 - K.PAD, 2 * x0 - K.PAD
+        zin0 = 2 * (zs0 - K.LEND)
         waves = []
         for wave in range(8):
             ck, mb, f = wave % K.NCK, (wave // K.NCK) % K.NMB, wave // (K.NCK * K.NMB)
             fxi, fyi, gi = f % K.NFX, f // K.NFX, f * K.NMB + mb
             m0 = 32 * (mg * K.NMB + mb)
             st = dict(ck=ck, fxi=fxi, fyi=fyi, gi=gi, m0=m0, acc=np.zeros((2, 32, 32), np.float32), own=np.zeros((K.QN * 8, 32), np.float32))
-            A = np.zeros((27, 32, 16), np.float32)
-            for tl in range(27):
-                dz, dy, dx = tl // 9, (tl // 3) % 3, tl % 3
+            A = np.zeros((K.NTAPS, 32, 16), np.float32)
+            for tl in range(K.NTAPS):
+                dz, dy, dx = tl // K.NIP, (tl // K.EXT) % K.EXT, tl % K.EXT
                 for rho in range(32):
                     ch = m0 + ((rho + 8 * K.QN * ck) & 31)
                     A[tl, rho] = wn[ch, 16 * ck:16 * ck + 16, dz, dy, dx]
@@ -73,7 +76,7 @@ def emulate(K, x, w, bias, S=1):
 
         def dma(dtp, slot):
             zin = zin0 + dtp
-            zok = 1 <= dtp < 2 * NO and 0 <= zin < Di
+            zok = K.LEND <= dtp < 2 * NO and 0 <= zin < Di
             for wave in range(8):
                 for k in range(K.DPW):
                     j = wave * K.DPW + k
@@ -95,7 +98,7 @@ def emulate(K, x, w, bias, S=1):
                             lds[dst:dst + 8] = 0.0
 
         def bfrag(st, slot, i):
-            dy, dx = i // 3, i % 3
+            dy, dx = i // K.EXT, i % K.EXT
             B = np.zeros((16, 32), np.float32)
             for lane in range(64):
                 hk, v = lane >> 5, lane & 31
@@ -110,8 +113,8 @@ def emulate(K, x, w, bias, S=1):
             return B
 
         def finalize(w):
-            o = zs0 - 1 + w
-            ov = 1 <= w < NO
+            o = zs0 - K.LEND + w
+            ov = K.LEND <= w < NO
             for st in waves:
                 ck, gi = st["ck"], st["gi"]
                 fin = st["own"].copy()
@@ -157,15 +160,20 @@ def emulate(K, x, w, bias, S=1):
                 dma(dtp, dtp % K.R); dtp += 1
                 slot = hs % K.R
                 for st in waves:
-                    for i in range(9):
+                    for i in range(K.NIP):
                         B = bfrag(st, slot, i)
-                        if ODD:
-                            st["acc"][CUR] += st["A"][18 + i] @ B
-                            if i == 0:
-                                st["acc"][1 - CUR][:] = 0
-                            st["acc"][1 - CUR] += st["A"][i] @ B
+                        if K.EXT == 3:
+                            if ODD:
+                                st["acc"][CUR] += st["A"][18 + i] @ B
+                                if i == 0:
+                                    st["acc"][1 - CUR][:] = 0
+                                st["acc"][1 - CUR] += st["A"][i] @ B
+                            else:
+                                st["acc"][CUR] += st["A"][9 + i] @ B
                         else:
-                            st["acc"][CUR] += st["A"][9 + i] @ B
+                            if not ODD and i == 0:
+                                st["acc"][CUR][:] = 0
+                            st["acc"][CUR] += st["A"][(K.NIP if ODD else 0) + i] @ B
                 if ODD:
                     for st in waves:
                         ck, gi = st["ck"], st["gi"]
@@ -185,13 +193,17 @@ def emulate(K, x, w, bias, S=1):
 
 def main():
     torch.manual_seed(0)
-    cases = [((2, 2, 2), (1, 32, 64, 8, 18, 20)), ((4, 2, 1), (1, 64, 64, 6, 10, 18)), ((2, 2, 2), (1, 32, 128, 10, 8, 34))]
+    cases = [((2, 2, 2, 3), (1, 32, 64, 8, 18, 20)), ((4, 2, 1, 3), (1, 64, 64, 6, 10, 18)), ((2, 2, 2, 3), (1, 32, 128, 10, 8, 34)),
+             ((2, 2, 2, 2), (1, 32, 64, 8, 18, 20)), ((4, 2, 1, 2), (1, 64, 128, 6, 10, 18))]
+    if len(sys.argv) > 1:
+        cases = [c for c in cases if c[0][3] == int(sys.argv[1])]
     bad = 0
     for cfg, (N, C, M, D, H, W) in cases:
+        E = cfg[3]
         x = torch.randn(N, C, D, H, W).half().float()
-        w = (torch.randn(M, C, 3, 3, 3) * 0.1).half().float()
+        w = (torch.randn(M, C, E, E, E) * 0.1).half().float()
         b = torch.randn(M)
-        ref = F.conv3d(x, w, b, stride=2, padding=1)
+        ref = F.conv3d(x, w, b, stride=2, padding=1 if E == 3 else 0)
         for S in (1, 2):
             got = emulate(Cfg(*cfg), x, w, b.numpy(), S=S)
             err = float((got - ref).abs().max())
