@@ -184,6 +184,18 @@ int lnn_instnorm_lrelu_seg_bwd(lnn_stream_t s, void* y_inout_h, const void* dz_p
                                const float* rstd, const float* gamma, const float* beta, float slope, float* dgamma,
                                float* dbeta, float grad_unscale, double* ws);
 size_t lnn_instnorm_lrelu_seg_bwd_ws_doubles(int N, int C);
+/* The FIRST block of the network (Conv3d(1 -> K) + InstanceNorm + LeakyReLU; no data gradient is needed behind it): pass 1 of
+ * lnn_instnorm_lrelu_bwd alone -- ws[(n*C + c)*3 + {0,1}] = sum g, sum g*xhat, dgamma / dbeta (+)= -- with y left untouched;
+ * lnn_conv3d_wgrad_c1_in_bwd then builds dy = gamma*rstd*(g - s1/V - xhat*s2/V) tile by tile while it stages the weight
+ * gradient's operand, so dy never exists in memory (the apply pass and the re-read of dy disappear).
+ * ws: >= lnn_instnorm_ws_doubles(N, C), the same workspace for both calls.  dwp: the C == 1 panel of lnn_conv3d_wgrad;
+ * parts / parts_elems: deterministic-mode scratch as in lnn_conv3d_wgrad_det, or NULL / 0. */
+int lnn_instnorm_lrelu_bwd_sums(lnn_stream_t s, const void* y_h, const void* dz_h, int ld_dz, int N, long V, int C,
+                                const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                                float* dgamma, float* dbeta, float grad_unscale, double* ws);
+int lnn_conv3d_wgrad_c1_in_bwd(lnn_stream_t s, const void* x_h, const void* y_h, const void* dz_h, int ld_dz, float* dwp, int N,
+                               int D, int H, int W, int K, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, float slope, const double* ws, float* parts, long parts_elems);
 
 /* ------------------------------------------------------------------------------------------------
  * seg_outputs[u]: nn.Conv3d 1x1x1, no bias (test_MultiHead_Module.py:427-431).

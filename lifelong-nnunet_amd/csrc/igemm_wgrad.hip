@@ -40,6 +40,13 @@ struct WgradParams {
     int part_writers = 1;
     int debug = 0;                    // LNN_WGRAD_DEBUG (measurements only): 1 = skip the epilogue atomics, 4 = phase timers
     unsigned long long* dbgbuf = nullptr;   // LNN_WGRAD_PHASEBUF: 6 x u64 {issue, mfma, barrier1, store, barrier2, tiles}
+    // first layer with the InstanceNorm / LeakyReLU backward folded in (lnn_conv3d_wgrad_c1_in_bwd): p = y (the conv output, NOT
+    // overwritten), gz = dL/dz; dy = gamma*rstd * (g - s1/V - xhat * s2/V) is rebuilt per tile from the sums of the reduce pass
+    const half_t* gz = nullptr;
+    int ld_gz = 0;
+    const float *in_mean = nullptr, *in_rstd = nullptr, *in_gamma = nullptr, *in_beta = nullptr;
+    const double* in_sums = nullptr;       // [(n * M + m) * 3 + {0, 1}] = sum g, sum g * xhat
+    float in_slope = 0.f;
     WTapTable taps;
 };
 
@@ -624,7 +631,10 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_s2_v2_kernel(const WgradPa
 // First layer (C == 1): DWP[0][m][tap] += sum_l dy[l, m] * x[l + tap - 1]     (tap padded to 32)
 // A = dy^T by transpose reads, B[voxel][tap] gathered from a single-channel LDS tile.
 // ------------------------------------------------------------------------------------------------
-template <int TZ, int TY>
+// FUSED: the operand tile is dy of the first block's InstanceNorm + LeakyReLU, rebuilt from y and dL/dz while it is staged (the
+// normalisation backward's apply pass -- read dz, read y, write dy -- and this kernel's read of dy disappear: the first layer has
+// no data gradient, so nothing else needs dy).
+template <int TZ, int TY, bool FUSED>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
     constexpr int TX = 8, TV = TZ * TY * TX, PZ = TZ + 2, PY = TY + 2, PX = TX + 2, P = PZ * PY * PX;
     constexpr int ROWB = 80, XN = (P + 255) / 256, PN = TV * 4 / 256;
@@ -646,6 +656,29 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
     // load -> barrier -> compute -> barrier without overlap left it at 1.7 TB/s
     half_t xr[XN];
     half8 pr[PN];
+    half8 gr[FUSED ? PN : 1];
+    float fsc[8], fsh[8], fca[8], fcb[8];      // FUSED: per-channel constants of this thread's octet (idx & 3 = tid & 3) for sample fn
+    int fn = -1;
+    // FUSED: dy of the staged tile from (y, dz): same expressions as in_lrelu_seg_bwd_apply_kernel (norm_act.hip).  Out-of-volume
+    // voxels carry y = dz = 0 -> their dy would be the constant ca, not 0: the loader's zero fill is applied AFTER the transform
+    // through the per-load ok mask kept in mk.
+    unsigned mk = 0;
+    auto load_consts = [&](int n) {
+        const float invV = 1.0f / ((float)p.Ld * (float)p.Lh * (float)p.Lw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = m0 + (tid & 3) * 8 + e;
+            const bool ok = c < p.M;
+            const float rs = ok ? p.in_rstd[n * p.M + c] : 0.f, mu = ok ? p.in_mean[n * p.M + c] : 0.f;
+            const float ga = ok ? p.in_gamma[c] : 0.f, be = ok ? p.in_beta[c] : 0.f;
+            const float m1 = ok ? (float)(p.in_sums[((long)n * p.M + c) * 3 + 0] * (double)invV) : 0.f;
+            const float m2 = ok ? (float)(p.in_sums[((long)n * p.M + c) * 3 + 1] * (double)invV) : 0.f;
+            fsc[e] = ga * rs;
+            fsh[e] = be - mu * fsc[e];
+            fca[e] = -fsc[e] * (m1 - mu * rs * m2);
+            fcb[e] = -fsc[e] * rs * m2;
+        }
+    };
     auto load_tile = [&](int tile) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -674,8 +707,17 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
             const bool ok = lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M;
             const half8 val = *reinterpret_cast<const half8*>(p.p + (ok ? (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8 : 0));
             pr[i] = ok ? val : zero8;
+            if constexpr (FUSED) {
+                mk = i == 0 ? (ok ? 1u : 0u) : (mk | ((ok ? 1u : 0u) << i));
+                const half8 g = *reinterpret_cast<const half8*>(p.gz + (ok ? (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_gz + m0 + c8 * 8 : 0));
+                gr[i] = ok ? g : zero8;
+            }
+        }
+        if constexpr (FUSED) {
+            if (n != fn) { fn = n; load_consts(n); }       // (a block's tile range rarely crosses a sample)
         }
     };
+
     load_tile(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                                   // every wave is done with the previous tile image
@@ -685,7 +727,17 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
 #pragma unroll
         for (int i = 0; i < PN; ++i) {
             const int idx = i * 256 + tid;
-            *reinterpret_cast<half8*>(pl + (idx >> 2) * ROWB + (idx & 3) * 16) = pr[i];
+            half8 v = pr[i];
+            if constexpr (FUSED) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xf = (float)pr[i][e];
+                    const float t = xf * fsc[e] + fsh[e];
+                    const float g = (float)gr[i][e] * (t > 0.f ? 1.f : p.in_slope);
+                    v[e] = ((mk >> i) & 1u) ? (half_t)(fsc[e] * g + (xf * fcb[e] + fca[e])) : (half_t)0;
+                }
+            }
+            *reinterpret_cast<half8*>(pl + (idx >> 2) * ROWB + (idx & 3) * 16) = v;
         }
         __syncthreads();
         if (tile + 1 < t_end) load_tile(tile + 1);        // in flight during the MFMAs below and the next barrier
@@ -1368,8 +1420,12 @@ extern "C" size_t lnn_wgrad_panel_elems(int ntaps, int M, int KC) {
 }
 
 namespace {
+struct C1Fused {          // lnn_conv3d_wgrad_c1_in_bwd: see WgradParams::gz
+    const void* gz; int ld_gz; const float *mean, *rstd, *gamma, *beta; float slope; const double* sums;
+};
 int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int ld_x, const void* dy, int ld_dy, float* dwp, int N,
-                      int Di, int Hi, int Wi, int C, int K, int stride, float* parts = nullptr, long parts_elems = 0) {
+                      int Di, int Hi, int Wi, int C, int K, int stride, float* parts = nullptr, long parts_elems = 0,
+                      const C1Fused* fused = nullptr) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_wgrad: stride %d unsupported", stride);
     LNN_REQUIRE(dwp != nullptr, "lnn_conv3d_wgrad: null panel");
@@ -1381,6 +1437,11 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
     p.N = N; p.Qd = Di; p.Qh = Hi; p.Qw = Wi;
     p.Ld = (Di - 1) / stride + 1; p.Lh = (Hi - 1) / stride + 1; p.Lw = (Wi - 1) / stride + 1;
     p.M = K; p.C = C; p.Mpad = lnn_round_up(K, 32); p.Cpad = lnn_round_up(C, 32); p.pad_lo = 1;
+    if (fused) {
+        LNN_REQUIRE(C == 1, "lnn_conv3d_wgrad_c1_in_bwd: first layer (C == 1) only");
+        p.gz = (const half_t*)fused->gz; p.ld_gz = fused->ld_gz; p.in_mean = fused->mean; p.in_rstd = fused->rstd;
+        p.in_gamma = fused->gamma; p.in_beta = fused->beta; p.in_slope = fused->slope; p.in_sums = fused->sums;
+    }
     if (C == 1) {
         LNN_REQUIRE(stride == 1 && x != nullptr, "lnn_conv3d_wgrad: C == 1 path needs stride 1");
         constexpr int TZ = 4, TY = 8;
@@ -1393,7 +1454,8 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
         dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)(p.Mpad / 32));
         const long slot_elems = (long)p.Mpad * 32;
         if (int e = wg_prepare_parts(p, grid.x, 4, slot_elems, "lnn_conv3d_wgrad(C=1)")) return e;            // writers: the 4 waves
-        hipLaunchKernelGGL((wgrad_c1_kernel<TZ, TY>), grid, dim3(256), 0, s, p);
+        if (p.gz) hipLaunchKernelGGL((wgrad_c1_kernel<TZ, TY, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wgrad_c1_kernel<TZ, TY, false>), grid, dim3(256), 0, s, p);
         LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(C=1)");
         return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(C=1,reduce)");
     }
@@ -1429,6 +1491,16 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
 extern "C" int lnn_conv3d_wgrad(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N,
                                 int Di, int Hi, int Wi, int C, int K, int stride) {
     return conv3d_wgrad_impl(s, x, nullptr, 0, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, stride);
+}
+
+extern "C" int lnn_conv3d_wgrad_c1_in_bwd(lnn_stream_t s, const void* x, const void* y, const void* dz, int ld_dz, float* dwp, int N,
+                                          int D, int H, int W, int K, const float* mean, const float* rstd, const float* gamma,
+                                          const float* beta, float slope, const double* ws, float* parts, long parts_elems) {
+    LNN_REQUIRE(y && dz && lnn_aligned16(y) && lnn_aligned16(dz) && ld_dz >= K && ld_dz % 8 == 0, "lnn_conv3d_wgrad_c1_in_bwd: bad y / dz / ld_dz");
+    LNN_REQUIRE(mean && rstd && gamma && beta && ws, "lnn_conv3d_wgrad_c1_in_bwd: null parameter");
+    LNN_REQUIRE(parts == nullptr || lnn_aligned16(parts), "lnn_conv3d_wgrad_c1_in_bwd: scratch misaligned");
+    const C1Fused f{dz, ld_dz, mean, rstd, gamma, beta, slope, ws};
+    return conv3d_wgrad_impl(s, x, nullptr, 0, 1, y, K, dwp, N, D, H, W, 1, K, 1, parts, parts_elems, &f);
 }
 
 extern "C" int lnn_conv3d_wgrad_cat(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* dy, int ld_dy,

@@ -128,8 +128,12 @@ __device__ __forceinline__ double sum_partials(const float* pws, int a, int nblk
     double s = 0;
     if (i < NC) {
         const float* p = pws + (long)a * nblk * NC + i;
-#pragma unroll 4
-        for (int b = sl; b < nblk; b += 16) s += (double)p[(long)b * NC];
+        int b = sl;
+        for (; b + 48 < nblk; b += 64) {          // four independent loads in flight (the dependent chain was latency-bound)
+            const float a0 = p[(long)b * NC], a1 = p[(long)(b + 16) * NC], a2 = p[(long)(b + 32) * NC], a3 = p[(long)(b + 48) * NC];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; b < nblk; b += 16) s += (double)p[(long)b * NC];
     }
     __syncthreads();
     red[threadIdx.x] = s;
@@ -195,14 +199,19 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
 // InstanceNorm + LeakyReLU + the 1x1x1 segmentation head of the SAME activation (decoder blocks that feed a seg head): the head
 // reads the fp16-rounded z this kernel has in registers, so the separate seg pass over z (0.63 GB at the top level) disappears.
 // A voxel's C/8 threads are adjacent lanes (C/8 a power of two <= 64): butterfly over them, lane c8 == 0 writes the K logits.
+// STAGED (C in [32, 512], V % 4 == 0): the K logits of the UNR * VPB consecutive voxels a block handles per trip go through LDS
+// and leave as 16-byte stores of complete runs; written directly (one lane in C/8 stores 4 bytes per class) every wave-wide
+// store covered 64 bytes and the kernel ran at 3.1 TB/s at the top level, behind the plain normalisation pass + a separate head.
 constexpr int SEG_KMAX = 8;
+template <bool STAGED>
 __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __restrict__ y, half_t* __restrict__ z, int ld_z,
                                                               long V, int C, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float slope,
                                                               const float* __restrict__ segw, float* __restrict__ logits, int K) {
+    __shared__ __attribute__((aligned(16))) float lg[STAGED ? 2 * SEG_KMAX * UNR * 64 : 4];
     const RowMap rm = row_map(C);
-    if (!rm.active) return;
+    if (!STAGED && !rm.active) return;                 // (STAGED: C / 8 is a power of two, every thread is active)
     const int n = blockIdx.y;
     float sc[8], sh[8], w[SEG_KMAX][8];
 #pragma unroll
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __re
     float* ln = logits + (long)n * K * V;
     const long end = vrange_end(V, rm), step = rm.VPB;
     // the block's range is a multiple of VPB, so all C8 lanes of a voxel are in or out together
-    auto one = [&](const half8& x, long v) {
+    auto one = [&](const half8& x, long v, float* stage) {
         half8 o;
         float pk[SEG_KMAX];
 #pragma unroll
@@ -241,18 +250,44 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __re
         if (rm.c8 == 0) {
 #pragma unroll
             for (int k = 0; k < SEG_KMAX; ++k)
-                if (k < K) ln[(long)k * V + v] = pk[k];
+                if (k < K) {
+                    if (stage) stage[k * (UNR * 64)] = pk[k];
+                    else ln[(long)k * V + v] = pk[k];
+                }
         }
     };
     long v = vrange_begin(V, rm) + rm.vl;
-    for (; v + (UNR - 1) * step < end; v += UNR * step) {      // UNR loads in flight per thread, as the plain forward pass
-        half8 x[UNR];
+    if constexpr (STAGED) {
+        // block-uniform trips over runs of UNR * VPB consecutive voxels [base, base + run): thread (vl, u) handles voxel
+        // base + u * VPB + vl; double-buffered staging, one barrier per trip
+        const long run = (long)UNR * step;
+        long base = vrange_begin(V, rm);
+        int it = 0;
+        for (; base + run <= end; base += run, ++it) {
+            float* buf = lg + (it & 1) * (SEG_KMAX * UNR * 64);
+            half8 x[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+            for (int u = 0; u < UNR; ++u) x[u] = *reinterpret_cast<const half8*>(yp + (base + rm.vl + u * step) * C);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) one(x[u], v + u * step);
+            for (int u = 0; u < UNR; ++u) one(x[u], base + rm.vl + u * step, buf + u * step + rm.vl);
+            __syncthreads();
+            const int q4 = (int)(run >> 2);                  // 16-byte pieces per class
+            for (int t = threadIdx.x; t < K * q4; t += NT) {
+                const int k = t / q4, j = t - k * q4;
+                *reinterpret_cast<floatx4*>(ln + (long)k * V + base + 4 * j) = *reinterpret_cast<const floatx4*>(buf + k * (UNR * 64) + 4 * j);
+            }
+        }
+        v = base + rm.vl;
+    } else {
+        for (; v + (UNR - 1) * step < end; v += UNR * step) {      // UNR loads in flight per thread, as the plain forward pass
+            half8 x[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) x[u] = *reinterpret_cast<const half8*>(yp + (v + u * step) * C);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) one(x[u], v + u * step, nullptr);
+        }
     }
-    for (; v < end; v += step) one(*reinterpret_cast<const half8*>(yp + v * C), v);
+    for (; v < end; v += step) one(*reinterpret_cast<const half8*>(yp + v * C), v, nullptr);
 }
 
 // pass 1 of backward: s1 = sum g, s2 = sum g*xhat with g = dz * lrelu'(gamma*xhat+beta)
@@ -578,11 +613,23 @@ __global__ void in_lrelu_seg_bwd_sums_kernel(const float* pws, int nblk, int N, 
         if (dbeta) atomicAdd(dbeta + i % C, (float)(s0 * unscale));
         return;
     }
+    // d seg_w: 16 consecutive entries (k * C + c) x 16 slices of the N * nblk block partials (partial b of entry i sits at
+    // pseg[b * K * C + i]); 4 independent loads in flight per thread -- with one the 128 dependent round trips of a slice took 30 us
     const float* pseg = pws + 2l * nblk * N * C;
-    const int i = (blockIdx.x - nb_in) * 16 + ii;          // entry k * C + c; partial b of it sits at pseg[b * K * C + i]
+    const int i = (blockIdx.x - nb_in) * 16 + ii;
+    const int nparts = nblk * N;
     double s = 0;
-    if (i < K * C)
-        for (int b = sl; b < nblk * N; b += 16) s += (double)pseg[(long)b * K * C + i];
+    if (i < K * C) {
+        const float* pp = pseg + i;
+        const long stride = (long)K * C;
+        int b = sl;
+        for (; b + 48 < nparts; b += 64) {
+            const float a0 = pp[(long)b * stride], a1 = pp[(long)(b + 16) * stride], a2 = pp[(long)(b + 32) * stride],
+                        a3 = pp[(long)(b + 48) * stride];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; b < nparts; b += 16) s += (double)pp[(long)b * stride];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0 && i < K * C) {
@@ -729,8 +776,12 @@ extern "C" int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s_, const void* y, void* 
     LNN_REQUIRE(K >= 1 && K <= SEG_KMAX && (C8 & (C8 - 1)) == 0 && C8 <= 64,
                 "lnn_instnorm_lrelu_seg_fwd: K=%d / C=%d unsupported (K <= %d, C/8 a power of two <= 64): use lnn_instnorm_lrelu_fwd + lnn_seg1x1_fwd",
                 K, C, SEG_KMAX);
-    hipLaunchKernelGGL(in_lrelu_seg_fwd_kernel, dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z, ld_z, V, C,
-                       mean, rstd, gamma, beta, slope, seg_w, logits, K);
+    // staged logits stores: whole 16-byte pieces need V % 4 == 0 (every class plane starts aligned) and runs of >= 4 voxels
+    const bool staged = C8 >= 4 && (V & 3) == 0 && lnn_aligned16(logits);
+    if (staged) hipLaunchKernelGGL((in_lrelu_seg_fwd_kernel<true>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z,
+                                   ld_z, V, C, mean, rstd, gamma, beta, slope, seg_w, logits, K);
+    else hipLaunchKernelGGL((in_lrelu_seg_fwd_kernel<false>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z,
+                            ld_z, V, C, mean, rstd, gamma, beta, slope, seg_w, logits, K);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_fwd");
     return LNN_OK;
 }
@@ -805,5 +856,25 @@ extern "C" int lnn_instnorm_lrelu_seg_bwd(lnn_stream_t s_, void* y, const void* 
     }
 #undef LNN_SB
 #undef LNN_SBQ
+    return LNN_OK;
+}
+
+// Pass 1 of the backward alone (reduce + sums): ws[(n * C + c) * 3 + {0, 1}] = sum g, sum g * xhat and the affine gradients; y is
+// not touched.  For the first block, whose pass 2 lives inside its weight gradient (lnn_conv3d_wgrad_c1_in_bwd).
+extern "C" int lnn_instnorm_lrelu_bwd_sums(lnn_stream_t s_, const void* y, const void* dz, int ld_dz, int N, long V, int C,
+                                           const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                                           float* dgamma, float* dbeta, float grad_unscale, double* ws) {
+    hipStream_t s = (hipStream_t)s_;
+    if (int e = check_common(y, N, V, C, "lnn_instnorm_lrelu_bwd_sums")) return e;
+    LNN_REQUIRE(dz != nullptr && lnn_aligned16(dz) && ld_dz >= C && ld_dz % 8 == 0, "lnn_instnorm_lrelu_bwd_sums: bad dz / ld_dz");
+    LNN_REQUIRE(mean && rstd && gamma && beta && ws, "lnn_instnorm_lrelu_bwd_sums: null parameter");
+    float* pws = reinterpret_cast<float*>(ws + (size_t)N * C * 3);
+    const int nblk = blocks_for(V, C);
+    hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, dim3(nblk, N), dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
+                       mean, rstd, gamma, beta, slope, pws, in_nt_flag());
+    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(reduce)");
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
+                       grad_unscale);
+    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(sums)");
     return LNN_OK;
 }

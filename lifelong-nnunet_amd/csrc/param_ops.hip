@@ -106,6 +106,21 @@ __global__ __launch_bounds__(NT) void pack_weights_batched_kernel(const float* _
 // cache lines per wave-wide load: 0.38 ms per step at 0.66 TB/s).  Here a block owns one such unit: it reads the
 // 32 x 16 x ntaps source elements in SOURCE order (runs of 16 x 27 or 32 x 27 consecutive floats), transposes through
 // LDS and writes the run with 16-byte stores.
+// NTAPS: compile-time tap count (27 / 8 / 1): e % ntaps and e / ntaps are 54 runtime integer divisions per thread and unit
+// otherwise -- the kernel sat at 1.85 TB/s, bound by that arithmetic, not by memory.
+template <int NTAPS>
+__device__ __forceinline__ void pack_unit_load(const float* __restrict__ sp, half_t* tile, int TS, int mb, int ck, int M, int KC, long sm,
+                                               long skc, long st, bool kc_inner) {
+    constexpr int E = 512 * NTAPS;
+    for (int e = threadIdx.x; e < E; e += NT) {
+        const int t = e % NTAPS, r = e / NTAPS;
+        const int kcl = kc_inner ? r % 16 : r / 32, ml = kc_inner ? r / 16 : r % 32;
+        const int m = mb * 32 + ml, kc = ck * 16 + kcl;
+        const float v = (m < M && kc < KC) ? sp[m * sm + kc * skc + t * st] : 0.f;
+        tile[t * TS + ml * 16 + kcl] = (half_t)v;
+    }
+}
+
 __global__ __launch_bounds__(NT) void pack_weights_tiled_kernel(const float* __restrict__ src, half_t* __restrict__ dst,
                                                                 const long* __restrict__ desc, int n) {
     constexpr int TS = 520;                        // tap pitch in LDS (halves): 512 + 8 keeps consecutive taps on different banks
@@ -132,12 +147,17 @@ __global__ __launch_bounds__(NT) void pack_weights_tiled_kernel(const float* __r
         const bool kc_inner = skc < sm;            // forward orientation: (kc, t) runs inside a row; dgrad: (m, t) runs
         const int E = 512 * ntaps;
         const float* sp = src + d[0];
-        for (int e = threadIdx.x; e < E; e += NT) {
-            const int t = e % ntaps, r = e / ntaps;
-            const int kcl = kc_inner ? r % 16 : r / 32, ml = kc_inner ? r / 16 : r % 32;
-            const int m = mb * 32 + ml, kc = ck * 16 + kcl;
-            const float v = (m < M && kc < KC) ? sp[m * sm + kc * skc + t * st] : 0.f;
-            tile[t * TS + ml * 16 + kcl] = (half_t)v;
+        if (ntaps == 27) pack_unit_load<27>(sp, tile, TS, mb, ck, M, KC, sm, skc, st, kc_inner);
+        else if (ntaps == 8) pack_unit_load<8>(sp, tile, TS, mb, ck, M, KC, sm, skc, st, kc_inner);
+        else if (ntaps == 1) pack_unit_load<1>(sp, tile, TS, mb, ck, M, KC, sm, skc, st, kc_inner);
+        else {
+            for (int e = threadIdx.x; e < E; e += NT) {
+                const int t = e % ntaps, r = e / ntaps;
+                const int kcl = kc_inner ? r % 16 : r / 32, ml = kc_inner ? r / 16 : r % 32;
+                const int m = mb * 32 + ml, kc = ck * 16 + kcl;
+                const float v = (m < M && kc < KC) ? sp[m * sm + kc * skc + t * st] : 0.f;
+                tile[t * TS + ml * 16 + kcl] = (half_t)v;
+            }
         }
         __syncthreads();
         half_t* out = dst + d[1] + ((long)mb * nck + ck) * ntaps * 512;
@@ -417,6 +437,22 @@ namespace {
 // Tiled unpack: the element-wise kernel reads the fp32 panel [tap][Mpad][KCpad] with a stride of Mpad*KCpad between the taps
 // of a destination run.  A block owns 8 rows x 32 channels x all taps: panel reads in 128-byte segments, LDS transpose,
 // destination writes in DESTINATION order (runs of 32 x ntaps or 8 x ntaps consecutive floats).
+template <int NTAPS>
+__device__ __forceinline__ void unpack_unit_store(float* __restrict__ op, const float* tile, int m0, int kc0, int M, int KC, long sm,
+                                                  long skc, long st, bool kc_inner, float scale, int accumulate) {
+    constexpr int E = 8 * 32 * NTAPS;
+    for (int e = threadIdx.x; e < E; e += NT) {
+        const int t = e % NTAPS, r = e / NTAPS;
+        const int kcl = kc_inner ? r % 32 : r / 8, ml = kc_inner ? r / 32 : r % 8;
+        const int m = m0 + ml, kc = kc0 + kcl;
+        if (m < M && kc < KC) {
+            float* o = op + m * sm + kc * skc + t * st;
+            const float v = scale * tile[(ml * 32 + kcl) * NTAPS + t];
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void unpack_wgrad_tiled_kernel(const float* __restrict__ dwp, float* __restrict__ dst,
                                                                 const long* __restrict__ desc, int n, float scale, int accumulate) {
     __shared__ long ufirst[DESC_MAX + 1];
@@ -450,14 +486,19 @@ __global__ __launch_bounds__(NT) void unpack_wgrad_tiled_kernel(const float* __r
         const long sm = d[2], skc = d[3], st = d[4];
         const bool kc_inner = skc < sm;
         float* op = dst + d[1];
-        for (int e = threadIdx.x; e < E; e += NT) {
-            const int t = e % ntaps, r = e / ntaps;
-            const int kcl = kc_inner ? r % 32 : r / 8, ml = kc_inner ? r / 32 : r % 8;
-            const int m = m0 + ml, kc = kc0 + kcl;
-            if (m < M && kc < KC) {
-                float* o = op + m * sm + kc * skc + t * st;
-                const float v = scale * tile[(ml * 32 + kcl) * ntaps + t];
-                *o = accumulate ? *o + v : v;
+        if (ntaps == 27) unpack_unit_store<27>(op, tile, m0, kc0, M, KC, sm, skc, st, kc_inner, scale, accumulate);
+        else if (ntaps == 8) unpack_unit_store<8>(op, tile, m0, kc0, M, KC, sm, skc, st, kc_inner, scale, accumulate);
+        else if (ntaps == 1) unpack_unit_store<1>(op, tile, m0, kc0, M, KC, sm, skc, st, kc_inner, scale, accumulate);
+        else {
+            for (int e = threadIdx.x; e < E; e += NT) {
+                const int t = e % ntaps, r = e / ntaps;
+                const int kcl = kc_inner ? r % 32 : r / 8, ml = kc_inner ? r / 32 : r % 8;
+                const int m = m0 + ml, kc = kc0 + kcl;
+                if (m < M && kc < KC) {
+                    float* o = op + m * sm + kc * skc + t * st;
+                    const float v = scale * tile[(ml * 32 + kcl) * ntaps + t];
+                    *o = accumulate ? *o + v : v;
+                }
             }
         }
         __syncthreads();

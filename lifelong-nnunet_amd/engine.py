@@ -372,6 +372,8 @@ class UNetEngine:
         self.fuse_in_stats = os.environ.get("LNN_NO_FUSED_IN_STATS", "0") != "1"     # A/B switch (measurements only)
         # seg head backward folded into the InstanceNorm backward of the block that feeds it (dL/dz never written): A/B switch
         self.fuse_seg_bwd = os.environ.get("LNN_NO_FUSED_SEG_BWD", "0") != "1"
+        # first block: pass 2 of its InstanceNorm backward rebuilt inside its weight gradient (dy never written): A/B switch
+        self.fuse_first_bwd = os.environ.get("LNN_NO_FUSED_FIRST_BWD", "0") != "1"
         # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
         # little room), kept because it is the natural hook for per-sample pipelining across GPUs / larger batches
         self.sample_lanes = os.environ.get("LNN_SAMPLE_LANES", "0") == "1"
@@ -639,6 +641,24 @@ class UNetEngine:
                                  item.gz.ld, self.pview(seg.w), dl[n0:], self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
                                  nn, V, K, item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta),
                                  LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws)
+                    elif item.x is None and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
+                        # the first block has no data gradient: only the sums of its normalisation backward are taken here,
+                        # dy is rebuilt tile by tile inside the weight gradient below (lnn_conv3d_wgrad_c1_in_bwd)
+                        nat.call("lnn_instnorm_lrelu_bwd_sums", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
+                                 item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                                 self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws)
+                        D, H, W = item.in_dims
+
+                        def first_wgrad(item=item, K=K, D=D, H=H, W=W):
+                            det = self._det_scratch()
+                            nat.call("lnn_conv3d_wgrad_c1_in_bwd", at(self.image, n0), at(item.y, n0), at(item.gz, n0), item.gz.ld,
+                                     self._pn(item.panel), nn, D, H, W, K, item.mean[n0 * K:], item.rstd[n0 * K:],
+                                     self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, ws, det,
+                                     0 if det is None else det.numel())
+                            if per_layer_unpack:
+                                unpack(item)
+                        on_side(lambda: self._probed("wgrad", item, first_wgrad))
+                        continue
                     else:
                         nat.call("lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
                                  item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,

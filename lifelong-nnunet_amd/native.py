@@ -51,6 +51,8 @@ SIGNATURES = {
     "lnn_instnorm_ws_doubles": (_sz, [_i, _i]),
     "lnn_instnorm_lrelu_seg_bwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _f, _p]),
     "lnn_instnorm_lrelu_seg_bwd_ws_doubles": (_sz, [_i, _i]),
+    "lnn_instnorm_lrelu_bwd_sums": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _f, _p]),
+    "lnn_conv3d_wgrad_c1_in_bwd": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _l]),
     "lnn_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),
     "lnn_seg1x1_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _l, _i, _i, _i, _f, _p]),
     "lnn_seg1x1_bwd_ws_floats": (_sz, [_i, _i]),

@@ -204,6 +204,85 @@ def test_seg1x1_fwd_bwd(N, C, K, V3):
     assert rel_err(dw.cpu(), 2.0 * w.grad.view(K, C)) < 1e-4
 
 
+@pytest.mark.parametrize("N,C,K,V3", [(2, 32, 3, (24, 16, 20)), (1, 64, 2, (12, 10, 18)), (1, 32, 3, (5, 9, 11)), (2, 8, 3, (4, 8, 8)),
+                                      (1, 128, 5, (8, 8, 12)), (1, 256, 3, (4, 6, 4))])
+def test_instnorm_lrelu_seg_fwd_fused(N, C, K, V3):
+    """lnn_instnorm_lrelu_seg_fwd == lnn_instnorm_lrelu_fwd + lnn_seg1x1_fwd: z bit for bit, logits to fp32 summation order.
+    Shapes cover the LDS-staged logits stores (C >= 32, V % 4 == 0: several block trips plus a tail), the direct stores
+    (C = 8; V % 4 != 0) and K up to 5."""
+    y = q16(_rand((N, C) + V3, 1) * 2 + 0.5)
+    g = torch.Generator().manual_seed(9)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    w = (torch.randn((K, C), generator=g) * 0.2).to(DEV)
+    V = V3[0] * V3[1] * V3[2]
+    yb, _ = to_cl_h(y)
+    mean = torch.empty(N * C, device=DEV); rstd = torch.empty(N * C, device=DEV)
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, C), dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", yb, N, V, C, 1e-5, mean, rstd, ws)
+    z1 = torch.zeros((N,) + V3 + (C + 8,), dtype=torch.float16, device=DEV); z2 = torch.zeros_like(z1)
+    l1 = torch.full((N, K) + V3, 7.0, device=DEV); l2 = torch.full((N, K) + V3, 9.0, device=DEV)
+    nat.call("lnn_instnorm_lrelu_fwd", yb, z1, C + 8, N, V, C, mean, rstd, gamma, beta, 0.01)
+    nat.call("lnn_seg1x1_fwd", z1, C + 8, w, l1, N, V, C, K)
+    nat.call("lnn_instnorm_lrelu_seg_fwd", yb, z2, C + 8, N, V, C, mean, rstd, gamma, beta, 0.01, w, l2, K)
+    assert torch.equal(z1, z2)
+    assert float((l1 - l2).abs().max()) <= 2e-6 * float(l1.abs().max())
+
+
+@pytest.mark.parametrize("N,K,D,H,W", [(2, 32, 9, 13, 17), (1, 32, 16, 16, 16), (3, 64, 5, 8, 9)])
+def test_first_layer_wgrad_with_folded_norm_backward(N, K, D, H, W):
+    """lnn_instnorm_lrelu_bwd_sums + lnn_conv3d_wgrad_c1_in_bwd (dy of the first block rebuilt inside its weight gradient) against
+    autograd through leaky_relu(instance_norm(conv3d(x))) and against the unfused pair lnn_instnorm_lrelu_bwd + lnn_conv3d_wgrad;
+    y must stay untouched.  Ragged tiles, several samples per block range, 2 output-channel blocks."""
+    x = _rand((N, 1, D, H, W), 1)
+    w = (_rand((K, 1, 3, 3, 3), 2, 0.3)).requires_grad_(True)
+    g = torch.Generator().manual_seed(9)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(K, generator=g)).requires_grad_(True)
+    V = D * H * W
+    xb = x.half().to(DEV).reshape(N, D, H, W).contiguous()
+    wp = pack(w.detach().to(DEV), 1, K, 27, 27, 1, 0)
+    yb = torch.zeros((N, D, H, W, K), dtype=torch.float16, device=DEV)
+    nat.call("lnn_conv3d_fwd", xb, 1, wp, None, yb, K, N, D, H, W, 1, K, 1)
+    y = from_cl_h(yb, K).requires_grad_(True)                  # the reference continues from the fp16 y the kernel stored
+    z = F.leaky_relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    dz = _rand(z.shape, 4)
+    z.backward(dz)
+    yconv = F.conv3d(x, w, None, padding=1)
+    yconv.backward(y.grad)                                     # dL/dw from the reference dy
+    mean = torch.empty(N * K, device=DEV); rstd = torch.empty(N * K, device=DEV)
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", yb, N, V, K, 1e-5, mean, rstd, ws)
+    ga, be = gamma.detach().to(DEV), beta.detach().to(DEV)
+    dzb, _ = to_cl_h(dz, ld=K + 8)
+    # unfused pair
+    y_u = yb.clone()
+    dg_u = torch.zeros(K, device=DEV); db_u = torch.zeros(K, device=DEV)
+    nat.call("lnn_instnorm_lrelu_bwd", y_u, dzb, K + 8, N, V, K, mean, rstd, ga, be, 0.01, dg_u, db_u, None, 1.0, ws)
+    p_u = torch.zeros(nat.query("lnn_wgrad_panel_elems", 1, K, 27), device=DEV)
+    nat.call("lnn_conv3d_wgrad", xb, 1, y_u, K, p_u, N, D, H, W, 1, K, 1)
+    # folded
+    y_f = yb.clone()
+    dg = torch.zeros(K, device=DEV); db = torch.zeros(K, device=DEV)
+    nat.call("lnn_instnorm_lrelu_bwd_sums", y_f, dzb, K + 8, N, V, K, mean, rstd, ga, be, 0.01, dg, db, 1.0, ws)
+    pf = torch.zeros_like(p_u)
+    nat.call("lnn_conv3d_wgrad_c1_in_bwd", xb, y_f, dzb, K + 8, pf, N, D, H, W, K, mean, rstd, ga, be, 0.01, ws, None, 0)
+    assert torch.equal(y_f, yb)
+    assert torch.equal(dg, dg_u) and torch.equal(db, db_u)
+    dw_u = torch.zeros((K, 1, 3, 3, 3), device=DEV); dw_f = torch.zeros_like(dw_u)
+    nat.call("lnn_unpack_wgrad", p_u, dw_u, 1, K, 27, 27, 1, 0, 1.0, 0)
+    nat.call("lnn_unpack_wgrad", pf, dw_f, 1, K, 27, 27, 1, 0, 1.0, 0)
+    assert rel_err(dw_f.cpu(), w.grad) < 2e-3
+    assert rel_err(dw_f.cpu(), dw_u.cpu()) < 1e-3
+    # deterministic mode: ordered reduction of per-writer panel copies, two calls bit-identical
+    det = torch.empty(8 * 1024 * 1024, device=DEV)
+    outs = []
+    for _ in range(2):
+        pd = torch.zeros_like(p_u)
+        nat.call("lnn_conv3d_wgrad_c1_in_bwd", xb, y_f, dzb, K + 8, pd, N, D, H, W, K, mean, rstd, ga, be, 0.01, ws, det, det.numel())
+        outs.append(pd)
+    assert torch.equal(outs[0], outs[1]) and rel_err(outs[0].cpu(), pf.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("prior", [False, True])
 @pytest.mark.parametrize("N,C,K,V3", [(2, 32, 3, (8, 16, 8)), (1, 8, 2, (5, 9, 11)), (2, 320, 3, (3, 4, 3)), (1, 64, 4, (7, 8, 8))])
 def test_instnorm_lrelu_seg_bwd_fused(N, C, K, V3, prior):
