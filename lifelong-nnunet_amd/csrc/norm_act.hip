@@ -122,9 +122,8 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__
 
 // Finalize kernels: 256 threads = 16 (n,c) entries x 16 slices of the block partials; returns the fp64 total of
 // entry i = blockIdx.x * 16 + (threadIdx.x & 15) for accumulator a (valid in the threads with slice 0).
-__device__ __forceinline__ double sum_partials(const float* pws, int a, int nblk, int NC, double* red) {
+__device__ __forceinline__ double sum_partials_at(const float* pws, int a, int nblk, int NC, double* red, int i) {
     const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + ii;
     double s = 0;
     if (i < NC) {
         const float* p = pws + (long)a * nblk * NC + i;
@@ -143,6 +142,10 @@ __device__ __forceinline__ double sum_partials(const float* pws, int a, int nblk
         for (int k = 1; k < 16; ++k) s += red[k * 16 + ii];
     }
     return s;
+}
+
+__device__ __forceinline__ double sum_partials(const float* pws, int a, int nblk, int NC, double* red) {
+    return sum_partials_at(pws, a, nblk, NC, red, blockIdx.x * 16 + (threadIdx.x & 15));
 }
 
 __global__ void in_stats_finalize_kernel(const float* pws, int nblk, int NC, long V, float eps, float* mean, float* rstd) {
@@ -199,9 +202,8 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
 // InstanceNorm + LeakyReLU + the 1x1x1 segmentation head of the SAME activation (decoder blocks that feed a seg head): the head
 // reads the fp16-rounded z this kernel has in registers, so the separate seg pass over z (0.63 GB at the top level) disappears.
 // A voxel's C/8 threads are adjacent lanes (C/8 a power of two <= 64): butterfly over them, lane c8 == 0 writes the K logits.
-// STAGED (C in [32, 512], V % 4 == 0): the K logits of the UNR * VPB consecutive voxels a block handles per trip go through LDS
-// and leave as 16-byte stores of complete runs; written directly (one lane in C/8 stores 4 bytes per class) every wave-wide
-// store covered 64 bytes and the kernel ran at 3.1 TB/s at the top level, behind the plain normalisation pass + a separate head.
+// STAGED (C in [32, 512], V % 4 == 0; A/B variant, off by default): the K logits of the UNR * VPB consecutive voxels a block
+// handles per trip go through LDS and leave as 16-byte stores of complete runs instead of 64-byte pieces per wave-wide store.
 constexpr int SEG_KMAX = 8;
 template <bool STAGED>
 __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __restrict__ y, half_t* __restrict__ z, int ld_z,
@@ -345,17 +347,27 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
 
 // ws[(n*C + c)*3 + {0,1}] = s1, s2 (fp64 totals of the partials)
 // also adds the affine-parameter gradients (dbeta = sum g, dgamma = sum g * xhat): they do not depend on pass 2
+// One thread group per CHANNEL, samples walked in order: the affine gradients are one ordered fp64 sum over n and ONE add per
+// call and channel (bit-reproducible for any batch size; the atomic only serves two sample lanes adding from two streams,
+// and two operands commute).  NC = N * C, grid = ceil(C / 16).
 __global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, int C, double* ws, float* dgamma, float* dbeta,
                                          float unscale) {
     __shared__ double red[256];
-    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s0 = sum_partials(pws, 0, nblk, NC, red), s1 = sum_partials(pws, 1, nblk, NC, red);
-    if (i >= NC || (threadIdx.x >> 4) != 0) return;
-    ws[(long)i * 3 + 0] = s0;
-    ws[(long)i * 3 + 1] = s1;
-    // atomics: N samples (and, with sample lanes, two HIP streams) add into the same channel
-    if (dgamma) atomicAdd(dgamma + i % C, (float)(s1 * unscale));
-    if (dbeta) atomicAdd(dbeta + i % C, (float)(s0 * unscale));
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int N = NC / C;
+    double g0 = 0, g1 = 0;
+    for (int n = 0; n < N; ++n) {
+        const int i = c < C ? n * C + c : NC;          // (out-of-range lanes take part in the barriers of sum_partials_at)
+        const double s0 = sum_partials_at(pws, 0, nblk, NC, red, i), s1 = sum_partials_at(pws, 1, nblk, NC, red, i);
+        if (c < C && (threadIdx.x >> 4) == 0) {
+            ws[(long)i * 3 + 0] = s0;
+            ws[(long)i * 3 + 1] = s1;
+            g0 += s0; g1 += s1;
+        }
+    }
+    if (c >= C || (threadIdx.x >> 4) != 0) return;
+    if (dgamma) atomicAdd(dgamma + c, (float)(g1 * unscale));
+    if (dbeta) atomicAdd(dbeta + c, (float)(g0 * unscale));
 }
 
 // pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V), in place over y; DBIAS: db partial = sum dy (the conv-bias gradient; it is
@@ -602,15 +614,22 @@ __global__ void in_lrelu_seg_bwd_sums_kernel(const float* pws, int nblk, int N, 
                                              float* dbeta, float* dsegw, float unscale) {
     __shared__ double red[256];
     const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    if ((int)blockIdx.x < nb_in) {
+    if ((int)blockIdx.x < nb_in) {                     // as in_lrelu_bwd_sums_kernel: per channel, samples in order
         const int NC = N * C;
-        const int i = blockIdx.x * 16 + ii;
-        const double s0 = sum_partials(pws, 0, nblk, NC, red), s1 = sum_partials(pws, 1, nblk, NC, red);
-        if (i >= NC || sl != 0) return;
-        ws[(long)i * 3 + 0] = s0;
-        ws[(long)i * 3 + 1] = s1;
-        if (dgamma) atomicAdd(dgamma + i % C, (float)(s1 * unscale));
-        if (dbeta) atomicAdd(dbeta + i % C, (float)(s0 * unscale));
+        const int c = blockIdx.x * 16 + ii;
+        double g0 = 0, g1 = 0;
+        for (int n = 0; n < N; ++n) {
+            const int i = c < C ? n * C + c : NC;
+            const double s0 = sum_partials_at(pws, 0, nblk, NC, red, i), s1 = sum_partials_at(pws, 1, nblk, NC, red, i);
+            if (c < C && sl == 0) {
+                ws[(long)i * 3 + 0] = s0;
+                ws[(long)i * 3 + 1] = s1;
+                g0 += s0; g1 += s1;
+            }
+        }
+        if (c >= C || sl != 0) return;
+        if (dgamma) atomicAdd(dgamma + c, (float)(g1 * unscale));
+        if (dbeta) atomicAdd(dbeta + c, (float)(g0 * unscale));
         return;
     }
     // d seg_w: 16 consecutive entries (k * C + c) x 16 slices of the N * nblk block partials (partial b of entry i sits at
@@ -777,7 +796,11 @@ extern "C" int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s_, const void* y, void* 
                 "lnn_instnorm_lrelu_seg_fwd: K=%d / C=%d unsupported (K <= %d, C/8 a power of two <= 64): use lnn_instnorm_lrelu_fwd + lnn_seg1x1_fwd",
                 K, C, SEG_KMAX);
     // staged logits stores: whole 16-byte pieces need V % 4 == 0 (every class plane starts aligned) and runs of >= 4 voxels
-    const bool staged = C8 >= 4 && (V & 3) == 0 && lnn_aligned16(logits);
+    // Measured on MI355X (C2 top level, 1.38 GB): staged 502 us vs direct 450 us -- the per-trip barrier costs more than the
+    // 64-byte stores it removes; kept behind LNN_SEG_FWD_STAGED=1 for A/B, off by default.
+    static int want_staged = -1;
+    if (want_staged < 0) { const char* e = getenv("LNN_SEG_FWD_STAGED"); want_staged = (e && e[0] == '1') ? 1 : 0; }
+    const bool staged = want_staged && C8 >= 4 && (V & 3) == 0 && lnn_aligned16(logits);
     if (staged) hipLaunchKernelGGL((in_lrelu_seg_fwd_kernel<true>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z,
                                    ld_z, V, C, mean, rstd, gamma, beta, slope, seg_w, logits, K);
     else hipLaunchKernelGGL((in_lrelu_seg_fwd_kernel<false>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z,
@@ -800,7 +823,7 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
     hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, grid, dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
                        mean, rstd, gamma, beta, slope, pws, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(reduce)");
-    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
                        grad_unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(sums)");
     if (dbias) {
@@ -835,7 +858,7 @@ extern "C" int lnn_instnorm_lrelu_seg_bwd(lnn_stream_t s_, void* y, const void* 
     const int nblk = blocks_for(V, C);
     const dim3 grid(nblk, N);
     const half_t* pr = (const half_t*)dz_prior;
-    const int nb_in = lnn_cdiv(N * C, 16);
+    const int nb_in = lnn_cdiv(C, 16);
 #define LNN_SB(KT, PRIOR) do { if (C % 32 == 0) LNN_SBQ(KT, PRIOR, true); else LNN_SBQ(KT, PRIOR, false); } while (0)
 #define LNN_SBQ(KT, PRIOR, QUAD)                                                                                                     \
     do {                                                                                                                             \
@@ -873,7 +896,7 @@ extern "C" int lnn_instnorm_lrelu_bwd_sums(lnn_stream_t s_, const void* y, const
     hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, dim3(nblk, N), dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
                        mean, rstd, gamma, beta, slope, pws, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(reduce)");
-    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
                        grad_unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(sums)");
     return LNN_OK;

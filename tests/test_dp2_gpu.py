@@ -64,6 +64,7 @@ def _worker(rank, world, port, out):
         full = _batches(5, 2 * world, seed=300)                         # global batches of 2 x world patches
         torch.manual_seed(7)
         kw = dict(fisher_mode="last_batch") if ext == "ewc" else {}
+        kw["deterministic_wgrad"] = True           # ordered weight-gradient reductions: what is left is the fp32 order of the rank sum
         # ---- data parallel: this rank's shard of every batch
         dp = get_trainer_class(ext)("seg_outputs", "A", plans=dict(TOY), device=DEV, batch_dice=bd, **kw)
         dp.initialize(True, num_epochs=1)
@@ -130,7 +131,8 @@ def _worker(rank, world, port, out):
             dp.after_train()
             if rank == 0:
                 plans = dict(TOY)
-                one = get_trainer_class("ewc")("seg_outputs", "A", plans=plans, device=DEV, process_group=solo, fisher_mode="accumulate")
+                one = get_trainer_class("ewc")("seg_outputs", "A", plans=plans, device=DEV, process_group=solo, fisher_mode="accumulate",
+                                               deterministic_wgrad=True)
                 one.initialize(True, num_epochs=1)
                 one.network.load_state_dict(dp.network.state_dict())
                 one.mh_network.update_after_iteration()

@@ -160,12 +160,15 @@ def test_sliding_window_kernels_exact_properties():
     assert prob.shape == (3, 5, 30, 17) and np.allclose(prob, ref[:, :5], atol=2e-6)
 
 
-def test_fp16_step_is_bit_reproducible_with_deterministic_wgrad():
+@pytest.mark.parametrize("B", [2, 3])
+def test_fp16_step_is_bit_reproducible_with_deterministic_wgrad(B):
     """``deterministic_wgrad``: the fp32 atomics of the weight-gradient kernels are the only order-dependent arithmetic of the
     fp16 step; with the ordered reduction two runs from the same weights on the same batches end on bit-identical parameters
-    (and agree with the default path to the rounding of the summation order)."""
+    (and agree with the default path to the rounding of the summation order).  Batch size 3: the affine InstanceNorm
+    gradients sum over the samples -- an ordered loop in the sums kernels, not one atomic per sample (with three operands
+    the order would matter)."""
     torch.manual_seed(3)
-    batches = [make_patch_batch(2, (16, 32, 16), 3, seed=900 + i) for i in range(3)]
+    batches = [make_patch_batch(B, (16, 32, 16), 3, seed=900 + i) for i in range(3)]
     ref = Generic_UNet(1, 8, 3, 3, device=DEV)
     init = {k: v.clone() for k, v in ref.state_dict().items()}
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, call F: folded first-layer backward, staged seg-forward stores, faster finalize / pack kernels: tests, bench, profile
-TAG=${1:-r3f}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-r3g}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 ulimit -c 0
 timeout 900 python -m pytest tests -q -m gpu --timeout=300 > $OUT/pytest.log 2>&1; grep -E "^FAILED|^ERROR|passed|failed" $OUT/pytest.log | tail -15
