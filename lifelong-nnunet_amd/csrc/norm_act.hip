@@ -144,6 +144,44 @@ __device__ __forceinline__ double sum_partials_at(const float* pws, int a, int n
     return s;
 }
 
+// Both accumulators (a = 0, 1) of TWO entries i0, i1 (pass NC for "none") with one pair of barriers: red4 holds 4 x 256 doubles.
+// Results valid in the threads with slice 0: out[2 * e + a].
+__device__ __forceinline__ void sum_partials_pair(const float* pws, int nblk, int NC, double* red4, int i0, int i1, double (&out)[4]) {
+    const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    double s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int i = e ? i1 : i0;
+        if (i < NC) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float* p = pws + (long)a * nblk * NC + i;
+                double acc = 0;
+                int b = sl;
+                for (; b + 48 < nblk; b += 64) {
+                    const float a0 = p[(long)b * NC], a1 = p[(long)(b + 16) * NC], a2 = p[(long)(b + 32) * NC], a3 = p[(long)(b + 48) * NC];
+                    acc += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+                }
+                for (; b < nblk; b += 16) acc += (double)p[(long)b * NC];
+                s[2 * e + a] = acc;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red4[j * 256 + threadIdx.x] = s[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double t = s[j];
+        if (sl == 0) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) t += red4[j * 256 + k * 16 + ii];
+        }
+        out[j] = t;
+    }
+}
+
 __device__ __forceinline__ double sum_partials(const float* pws, int a, int nblk, int NC, double* red) {
     return sum_partials_at(pws, a, nblk, NC, red, blockIdx.x * 16 + (threadIdx.x & 15));
 }
@@ -352,17 +390,21 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
 // and two operands commute).  NC = N * C, grid = ceil(C / 16).
 __global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, int C, double* ws, float* dgamma, float* dbeta,
                                          float unscale) {
-    __shared__ double red[256];
+    __shared__ double red[4 * 256];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
     const int N = NC / C;
     double g0 = 0, g1 = 0;
-    for (int n = 0; n < N; ++n) {
-        const int i = c < C ? n * C + c : NC;          // (out-of-range lanes take part in the barriers of sum_partials_at)
-        const double s0 = sum_partials_at(pws, 0, nblk, NC, red, i), s1 = sum_partials_at(pws, 1, nblk, NC, red, i);
+    for (int n = 0; n < N; n += 2) {                   // two samples per barrier pair
+        const int i0 = c < C ? n * C + c : NC, i1 = (c < C && n + 1 < N) ? (n + 1) * C + c : NC;
+        double o[4];
+        sum_partials_pair(pws, nblk, NC, red, i0, i1, o);
         if (c < C && (threadIdx.x >> 4) == 0) {
-            ws[(long)i * 3 + 0] = s0;
-            ws[(long)i * 3 + 1] = s1;
-            g0 += s0; g1 += s1;
+            ws[(long)i0 * 3 + 0] = o[0]; ws[(long)i0 * 3 + 1] = o[1];
+            g0 += o[0]; g1 += o[1];
+            if (i1 < NC) {
+                ws[(long)i1 * 3 + 0] = o[2]; ws[(long)i1 * 3 + 1] = o[3];
+                g0 += o[2]; g1 += o[3];
+            }
         }
     }
     if (c >= C || (threadIdx.x >> 4) != 0) return;
@@ -612,19 +654,23 @@ __global__ __launch_bounds__(NT, (KT <= 3 && !PRIOR && QUAD) ? 3 : 2) void in_lr
 // blocks [0, nb_in): the (n, c) totals of pass 1 (= in_lrelu_bwd_sums_kernel); blocks [nb_in, ..): d seg_w[k][c] += unscale * total
 __global__ void in_lrelu_seg_bwd_sums_kernel(const float* pws, int nblk, int N, int C, int K, int nb_in, double* ws, float* dgamma,
                                              float* dbeta, float* dsegw, float unscale) {
-    __shared__ double red[256];
+    __shared__ double red[4 * 256];
     const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
     if ((int)blockIdx.x < nb_in) {                     // as in_lrelu_bwd_sums_kernel: per channel, samples in order
         const int NC = N * C;
         const int c = blockIdx.x * 16 + ii;
         double g0 = 0, g1 = 0;
-        for (int n = 0; n < N; ++n) {
-            const int i = c < C ? n * C + c : NC;
-            const double s0 = sum_partials_at(pws, 0, nblk, NC, red, i), s1 = sum_partials_at(pws, 1, nblk, NC, red, i);
+        for (int n = 0; n < N; n += 2) {
+            const int i0 = c < C ? n * C + c : NC, i1 = (c < C && n + 1 < N) ? (n + 1) * C + c : NC;
+            double o[4];
+            sum_partials_pair(pws, nblk, NC, red, i0, i1, o);
             if (c < C && sl == 0) {
-                ws[(long)i * 3 + 0] = s0;
-                ws[(long)i * 3 + 1] = s1;
-                g0 += s0; g1 += s1;
+                ws[(long)i0 * 3 + 0] = o[0]; ws[(long)i0 * 3 + 1] = o[1];
+                g0 += o[0]; g1 += o[1];
+                if (i1 < NC) {
+                    ws[(long)i1 * 3 + 0] = o[2]; ws[(long)i1 * 3 + 1] = o[3];
+                    g0 += o[2]; g1 += o[3];
+                }
             }
         }
         if (c >= C || sl != 0) return;
