@@ -1,203 +1,23 @@
 // Implicit-GEMM 3-D convolution family on gfx950 MFMA (v_mfma_f32_32x32x16_f16), channels-last fp16:
-// the C-ABI entry points, the kernel selection, and the GENERIC first-version kernel.
+// the C-ABI entry points, the kernel selection, and the first-layer (C == 1) kernel.
 //
 // Production kernels (one file each, selected in the wrappers at the bottom of this file):
 //   stride-1 conv fwd / dgrad   igemm_conv_v2.hip (v5), igemm_conv_v7.hip (>= 128 input channels, small volumes),
 //                               igemm_conv_v8.hip (>= 64 output channels)
 //   stride-2 conv fwd, convT dgrad      igemm_down2.hip          stride-2 dgrad, convT fwd      igemm_up2.hip
-// The generic template below covers every "gather taps -> contract channels" op of the U-Net with one non-pipelined
-// kernel (stride-2 dgrad / transposed conv forward as 8 launches, one per output parity class); it is kept as the
-// A/B baseline behind LNN_CONV_V1 / LNN_UP2_V1 / LNN_DOWN2_V1 and lnn_debug_force_conv_kernel(1):
+// (The generic first-version kernel -- one non-pipelined kernel for every op, stride-2 dgrad as 8 launches -- was the A/B
+// baseline of rounds 1-2 and was removed in round 3; profiles/r01_* hold its numbers.)
 //
 //   OUT[n, os*l+par, m] = bias[m] + sum_{tap} sum_{c} IN[n, IS*l + off(tap) - pad_lo, c] * WP[slot(tap)][m][c]
 //
 // GEMM view per tap: D[m][voxel] += A[m][c] * B[c][voxel]  (A = weight panel rows, B = input voxels),
 // i.e. MFMA rows = output channels, MFMA columns = 32 output voxels, so that each lane ends up with 4
 // consecutive output channels of one voxel per accumulator quad -> 8-byte channels-last stores.
-//
-// Generic kernel: block = 256 threads = 4 waves; block tile = (TZ x TY x 8) loop voxels x (32*MT) output channels.
-// Input channels are processed in chunks of CK; the (halo) input tile of the chunk is staged once in
-// LDS and reused by all taps; weight panels are staged per tap group.
-// LDS rows are padded by 16 B (row pitch 16*odd) so the 16-byte fragment reads are conflict free.
 #include "lnn_common.h"
 #include "igemm_common.h"
 #include <cstdlib>
 
 namespace {
-
-template <int IS, int EXT, int TZ, int TY, int CK, int MT>
-struct ConvCfg {
-    static constexpr int TX = 8;
-    static constexpr int VT = TZ * TY * TX / 128;  // 32-voxel MFMA tiles per wave
-    static constexpr int PZ = IS * (TZ - 1) + EXT, PY = IS * (TY - 1) + EXT, PX = IS * (TX - 1) + EXT;
-    static constexpr int P = PZ * PY * PX;
-    static constexpr int POSB = CK * 2 + 16;   // bytes per tile position
-    static constexpr int WROWB = CK * 2 + 16;  // bytes per weight row
-    static constexpr int MB = 32 * MT;         // output channels per block
-    static constexpr int MAXG = 27;
-    static constexpr int xbytes = P * POSB;
-    static constexpr int wbytes(int tpg) { return tpg * MB * WROWB; }
-};
-
-template <int IS, int EXT, int TZ, int TY, int CK, int MT>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvParams p) {
-    using Cfg = ConvCfg<IS, EXT, TZ, TY, CK, MT>;
-    constexpr int TX = Cfg::TX, VT = Cfg::VT, PY = Cfg::PY, PX = Cfg::PX, P = Cfg::P;
-    constexpr int POSB = Cfg::POSB, WROWB = Cfg::WROWB, MB = Cfg::MB;
-    constexpr int CH8 = CK / 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xl = smem;
-    char* wl = smem + Cfg::xbytes;
-    // tap tables live in LDS: indexing the kernarg copy dynamically makes hipcc emit dependent VMEM loads
-    // (a global_load + s_waitcnt vmcnt(0) per tap in the MFMA loop, and a gather per staged weight vector)
-    // (carved from the END of the dynamic region: a static __shared__ object would shift the dynamic base off
-    // its 16-byte alignment, cdna_hip_programming.md Guideline 17)
-    int* tap_pos = reinterpret_cast<int*>(smem + Cfg::xbytes + Cfg::wbytes(p.taps.taps_per_group));
-    int* tap_slot = tap_pos + 32;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 27) { tap_pos[tid] = p.taps.pos_off[tid]; tap_slot[tid] = p.taps.slot[tid]; }
-    // ---- tile decode -----------------------------------------------------------------------------
-    int t = blockIdx.x;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y; t /= p.tiles_y;
-    const int tz = t % p.tiles_z; t /= p.tiles_z;
-    const int n = t;
-    const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
-    const int iz0 = IS * lz0 - p.pad_lo, iy0 = IS * ly0 - p.pad_lo, ix0 = IS * lx0 - p.pad_lo;
-    const int m0 = blockIdx.y * MB;
-
-    // per-lane voxel positions of the wave's VT MFMA tiles
-    const int v = lane & 31, hk = lane >> 5;
-    int lanepos[VT];
-#pragma unroll
-    for (int vt = 0; vt < VT; ++vt) {
-        const int tile = wave * VT + vt;
-        const int z = tile / (TY / 4), y = (tile % (TY / 4)) * 4 + (v >> 3), x = v & 7;
-        lanepos[vt] = ((IS * z * PY + IS * y) * PX + IS * x) * POSB + hk * 16;
-    }
-    const int wlane = (lane & 31) * WROWB + hk * 16;
-
-    floatx16 acc[MT][VT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < VT; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-
-    const long xbase_n = (long)n * p.Di * p.Hi * p.Wi;
-    const int ntaps = p.taps.ntaps, tpg = p.taps.taps_per_group;
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    for (int c0 = 0; c0 < p.C; c0 += CK) {
-        __syncthreads();  // previous chunk's readers are done with xl / wl
-        // ---- stage the input tile of this channel chunk ------------------------------------------
-        // batches of 4 UNCONDITIONAL loads (invalid lanes read element 0 and are zeroed on the LDS write)
-        for (int base = 0; base < P * CH8; base += 1024) {
-            half8 r[4];
-            unsigned ok = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = min(base + i * 256 + tid, P * CH8 - 1);
-                const int pos = idx / CH8, c8 = idx % CH8;
-                const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-                const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-                const bool v_ok = (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi &&
-                                  (unsigned)ix < (unsigned)p.Wi && c0 + c8 * 8 < p.C;
-                const long off = v_ok ? (xbase_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + c0 + c8 * 8 : 0;
-                r[i] = *reinterpret_cast<const half8*>(p.x + off);
-                ok |= (v_ok ? 1u : 0u) << i;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = base + i * 256 + tid;
-                if (idx < P * CH8)
-                    *reinterpret_cast<half8*>(xl + (idx / CH8) * POSB + (idx % CH8) * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
-            }
-        }
-        for (int g0 = 0; g0 < ntaps; g0 += tpg) {
-            const int gn = min(tpg, ntaps - g0);
-            if (g0 > 0) __syncthreads();  // readers of the previous weight group are done
-            // ---- stage the weight panels of this tap group ---------------------------------------
-            const int wtot = gn * MB * CH8;
-            for (int base = 0; base < wtot; base += 1024) {
-                half8 r[4];
-                unsigned ok = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = min(base + i * 256 + tid, wtot - 1);
-                    const int c8 = idx % CH8, rr = (idx / CH8) % MB, tl = idx / (CH8 * MB);
-                    const int slot = tap_slot[g0 + tl];
-                    const bool v_ok = m0 + rr < p.Mpad && c0 + c8 * 8 < p.KCpad;
-                    const long off = v_ok ? lnn_panel_off(slot, m0 + rr, c0 + c8 * 8, p.wtaps, p.KCpad) : 0;
-                    r[i] = *reinterpret_cast<const half8*>(p.wp + off);
-                    ok |= (v_ok ? 1u : 0u) << i;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = base + i * 256 + tid;
-                    if (idx < wtot) {
-                        const int c8 = idx % CH8, rr = (idx / CH8) % MB, tl = idx / (CH8 * MB);
-                        *reinterpret_cast<half8*>(wl + (tl * MB + rr) * WROWB + c8 * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- MFMA over the taps of the group -------------------------------------------------
-            for (int tl = 0; tl < gn; ++tl) {
-                const int xo = __builtin_amdgcn_readfirstlane(tap_pos[g0 + tl]) * POSB;
-                const char* wrow = wl + tl * MB * WROWB + wlane;
-#pragma unroll
-                for (int k16 = 0; k16 < CK / 16; ++k16) {
-                    half8 a[MT], b[VT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        a[mt] = *reinterpret_cast<const half8*>(wrow + mt * 32 * WROWB + k16 * 32);
-#pragma unroll
-                    for (int vt = 0; vt < VT; ++vt)
-                        b[vt] = *reinterpret_cast<const half8*>(xl + lanepos[vt] + xo + k16 * 32);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int vt = 0; vt < VT; ++vt)
-                            acc[mt][vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[vt], acc[mt][vt], 0, 0, 0);
-                }
-            }
-        }
-    }
-
-    // ---- epilogue: lane holds voxel (lane&31) x channels {8*q + 4*hk + 0..3} per accumulator quad ----
-#pragma unroll
-    for (int vt = 0; vt < VT; ++vt) {
-        const int tile = wave * VT + vt;
-        const int lz = lz0 + tile / (TY / 4), ly = ly0 + (tile % (TY / 4)) * 4 + (v >> 3), lx = lx0 + (v & 7);
-        if (lz >= p.Ld || ly >= p.Lh || lx >= p.Lw) continue;
-        const int oz = p.os * lz + p.par_z, oy = p.os * ly + p.par_y, ox = p.os * lx + p.par_x;
-        half_t* yrow = p.y + ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.ld_y;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + mt * 32 + q * 8 + hk * 4;
-                if (m >= p.M) continue;
-                float r0 = acc[mt][vt][q * 4 + 0], r1 = acc[mt][vt][q * 4 + 1], r2 = acc[mt][vt][q * 4 + 2],
-                      r3 = acc[mt][vt][q * 4 + 3];
-                if (p.bias) {
-                    const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + m);
-                    r0 += bv[0]; r1 += bv[1]; r2 += bv[2]; r3 += bv[3];
-                }
-                half4* dst = reinterpret_cast<half4*>(yrow + m);
-                if (p.accumulate) {
-                    const half4 old = *dst;
-                    r0 += (float)old[0]; r1 += (float)old[1]; r2 += (float)old[2]; r3 += (float)old[3];
-                }
-                half4 o = {(half_t)r0, (half_t)r1, (half_t)r2, (half_t)r3};
-                *dst = o;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // First layer (C == 1): im2col inside LDS, taps are the contraction dimension (27 -> 32).
@@ -340,57 +160,13 @@ __global__ __launch_bounds__(256, 3) void conv_c1_fwd_kernel(const ConvParams p,
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-template <int IS, int EXT, int TZ, int TY, int CK, int MT>
-int launch_igemm(hipStream_t s, ConvParams& p, const char* name) {
-    using Cfg = ConvCfg<IS, EXT, TZ, TY, CK, MT>;
-    p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, Cfg::TX);
-    // weight taps per group: as many as fit next to the input tile in <= 64 KB total (2 blocks / CU); the
-    // input-stride-2 tiles are large (69 KB), there one block per CU with all taps resident beats 27 regroupings
-    const int budget = (IS == 2 ? 150 : 64) * 1024 - Cfg::xbytes;
-    int tpg = budget / (Cfg::MB * Cfg::WROWB);
-    if (tpg < 1) tpg = 1;
-    if (tpg > p.taps.ntaps) tpg = p.taps.ntaps;
-    if (p.taps.ntaps == 27) tpg = tpg >= 27 ? 27 : (tpg >= 9 ? 9 : (tpg >= 3 ? 3 : 1));
-    p.taps.taps_per_group = tpg;
-    const size_t lds = Cfg::xbytes + Cfg::wbytes(tpg) + 256;   // + tap tables
-    auto kern = igemm_conv_kernel<IS, EXT, TZ, TY, CK, MT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    dim3 grid((unsigned)((long)p.N * p.tiles_z * p.tiles_y * p.tiles_x), (unsigned)lnn_cdiv(p.M, Cfg::MB));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    LNN_CHECK_LAUNCH(name);
-    return LNN_OK;
-}
-
-template <int IS, int EXT, int TZ, int TY>
-int dispatch_ck_mt(hipStream_t s, ConvParams& p, const char* name) {
-    const bool ck32 = p.C > 16;
-    const bool mt2 = p.M > 32;
-    if (ck32) return mt2 ? launch_igemm<IS, EXT, TZ, TY, 32, 2>(s, p, name) : launch_igemm<IS, EXT, TZ, TY, 32, 1>(s, p, name);
-    return mt2 ? launch_igemm<IS, EXT, TZ, TY, 16, 2>(s, p, name) : launch_igemm<IS, EXT, TZ, TY, 16, 1>(s, p, name);
-}
-
 // debug hook: phase-cycle accumulators for the v3 kernel (tools/kbench.py --phases)
 static unsigned long long* g_dbg = nullptr;
 extern "C" int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64) { g_dbg = (unsigned long long*)dev_ptr_6x_u64; return LNN_OK; }
 
-// LNN_CONV_V1=1 selects the non-pipelined kernel for the stride-1 convs (A/B measurements only)
 // runtime override for the parity tests (lnn_debug_force_conv_kernel): -1 = automatic selection,
-// 1 = generic first version, 5 / 7 / 8 / 9 = that stride-1 kernel for every layer it supports
+// 5 / 7 / 8 / 9 = that stride-1 kernel for every layer it supports
 int g_force_conv = -1;
-
-bool use_v2() {
-    if (g_force_conv >= 0) return g_force_conv != 1;
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LNN_CONV_V1");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v == 1;
-}
 
 // v9 (z-streaming, register-resident weights): the kernel for the 32- / 64-input-channel layers of the two highest
 // resolutions.  LNN_CONV_V9=0 forbids it (A/B measurements); lnn_debug_force_conv_kernel(9) forces it wherever supported.
@@ -408,17 +184,6 @@ bool use_v9(const ConvParams& p) {
     return p.Ld >= 32;
 }
 
-// LNN_UP2_V1=1 selects the one-launch-per-parity-class path for stride-2 dgrad / convT forward (A/B measurements only)
-bool use_up2() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LNN_UP2_V1");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-// LNN_DOWN2_V1=1 selects the generic kernel for stride-2 forward / convT dgrad (A/B measurements only)
 // stride-2 conv forward: z-streaming kernel (igemm_down2s.hip) for 32 / 64 input channels with >= 16 output planes;
 // lnn_debug_force_down2_kernel: -1 automatic, 0 the tile kernel (igemm_down2.hip), 1 the streaming kernel wherever supported
 int g_force_down2 = -1;
@@ -433,15 +198,6 @@ bool use_down2s(const ConvParams& p) {
     if (v == 0) return false;
     if (v == 1) return true;
     return p.Ld >= 16;
-}
-
-bool use_down2() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LNN_DOWN2_V1");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v == 1;
 }
 
 // v7 (two single-buffered 8-wave blocks per CU) vs v5 (one double-buffered block with resident weights): measured
@@ -514,7 +270,7 @@ extern "C" int lnn_debug_force_down2_kernel(int which) {
 }
 
 extern "C" int lnn_debug_force_conv_kernel(int which) {
-    LNN_REQUIRE(which == -1 || which == 1 || which == 5 || (which >= 7 && which <= 9), "lnn_debug_force_conv_kernel: %d is not one of -1, 1, 5, 7, 8, 9", which);
+    LNN_REQUIRE(which == -1 || which == 5 || (which >= 7 && which <= 9), "lnn_debug_force_conv_kernel: %d is not one of -1, 5, 7, 8, 9", which);
     g_force_conv = which;
     return LNN_OK;
 }
@@ -569,19 +325,18 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         p.dbg = g_dbg;
         // fused InstanceNorm statistics (dense output tensor only; the partials must fit the 1024 slots of lnn_instnorm_ws_doubles:
         // true up to 256 CUs -- a larger part falls back to the separate statistics pass)
-        if (stats_pws && use_v2() && use_v9(p) && ld_y == K && lnn_conv_s1_v9_stats_slots(p) <= 1024) {
+        if (stats_pws && use_v9(p) && ld_y == K && lnn_conv_s1_v9_stats_slots(p) <= 1024) {
             p.stats_pws = stats_pws;
             const int rc = lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9,stats)");
             *stats_slots = p.stats_nblk;
             return rc;
         }
-        if (use_v2() && use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9)");
-        if (use_v2() && use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_fwd(s1,v8)");
-        if (use_v2() && use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,v7)");
-        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
-        return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_fwd(s1)");
+        if (use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9)");
+        if (use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_fwd(s1,v8)");
+        if (use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,v7)");
+        return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
     }
-    if (use_down2() && use_down2s(p)) {
+    if (use_down2s(p)) {
         if (stats_pws && ld_y == K && lnn_down2s_stats_slots(p) <= 1024) {      // fused InstanceNorm statistics (dense output tensor only)
             p.stats_pws = stats_pws;
             const int rc = lnn_launch_down2s(s, p, "lnn_conv3d_fwd(s2,down2s,stats)");
@@ -590,24 +345,13 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         }
         return lnn_launch_down2s(s, p, "lnn_conv3d_fwd(s2,down2s)");
     }
-    if (use_down2()) return lnn_launch_down2_conv(s, p, "lnn_conv3d_fwd(s2,down2)");
-    {
-        constexpr int PY = 2 * 7 + 3, PX = 2 * 7 + 3;  // TZ=2, TY=8, TX=8
-        for (int t = 0; t < 27; ++t) {
-            p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
-            p.taps.slot[t] = (unsigned char)t;
-        }
-        const bool mt2 = p.M > 32;
-        return mt2 ? launch_igemm<2, 3, 2, 8, 16, 2>(s, p, "lnn_conv3d_fwd(s2)")
-                   : launch_igemm<2, 3, 2, 8, 16, 1>(s, p, "lnn_conv3d_fwd(s2)");
-    }
+    return lnn_launch_down2_conv(s, p, "lnn_conv3d_fwd(s2,down2)");
 }
 
 int check_cat(const void* b, int c_a, int C, int stride, const char* what) {
     LNN_REQUIRE(b != nullptr && lnn_aligned16(b), "%s: second tensor null/misaligned", what);
     LNN_REQUIRE(stride == 1, "%s: stride 1 only", what);
     LNN_REQUIRE(c_a > 0 && c_a < C && c_a % 32 == 0 && (C - c_a) % 8 == 0, "%s: split %d of %d channels must be a multiple of 32", what, c_a, C);
-    LNN_REQUIRE(use_v2(), "%s: not supported by the generic first-version kernel (forced kernel 1)", what);
     return LNN_OK;
 }
 }  // namespace
@@ -669,38 +413,14 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
         p.dbg = g_dbg;
-        if (use_v2() && use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad(s1,v9)");
-        if (use_v2() && use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_dgrad(s1,v8)");
-        if (use_v2() && use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_dgrad(s1,v7)");
-        if (use_v2()) return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
-        return dispatch_ck_mt<1, 3, 4, 8>(s, p, "lnn_conv3d_dgrad(s1)");
+        if (use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad(s1,v9)");
+        if (use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_dgrad(s1,v8)");
+        if (use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_dgrad(s1,v7)");
+        return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
     }
     // stride 2: dx[2l+par] = sum over taps d with (par - d + 1) even: dy[l + (par - d + 1)/2]
     //   par = 0 -> d = 1 (offset 0);  par = 1 -> d = 0 (offset +1), d = 2 (offset 0)
-    if (use_up2()) return lnn_launch_up2_dgrad(s, p, "lnn_conv3d_dgrad(s2,up2)");
-    int rc = LNN_OK;
-    for (int cls = 0; cls < 8 && rc == LNN_OK; ++cls) {
-        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-        ConvParams q = p;
-        q.os = 2; q.par_z = pz; q.par_y = py; q.par_x = px; q.pad_lo = 0;
-        q.Ld = (Di - pz + 1) / 2; q.Lh = (Hi - py + 1) / 2; q.Lw = (Wi - px + 1) / 2;
-        if (q.Ld <= 0 || q.Lh <= 0 || q.Lw <= 0) {
-            continue;
-        }
-        constexpr int PY = 8 + 1, PX = 8 + 1;  // IS=1, EXT=2, TZ=4, TY=8
-        int nt = 0;
-        const int dzs[2][2] = {{1, -1}, {0, 2}}, offs[2][2] = {{0, 0}, {1, 0}}, cnt[2] = {1, 2};
-        for (int a = 0; a < cnt[pz]; ++a)
-            for (int b = 0; b < cnt[py]; ++b)
-                for (int c = 0; c < cnt[px]; ++c) {
-                    q.taps.pos_off[nt] = (unsigned short)((offs[pz][a] * PY + offs[py][b]) * PX + offs[px][c]);
-                    q.taps.slot[nt] = (unsigned char)(dzs[pz][a] * 9 + dzs[py][b] * 3 + dzs[px][c]);
-                    ++nt;
-                }
-        q.taps.ntaps = nt;
-        rc = dispatch_ck_mt<1, 2, 4, 8>(s, q, "lnn_conv3d_dgrad(s2)");
-    }
-    return rc;
+    return lnn_launch_up2_dgrad(s, p, "lnn_conv3d_dgrad(s2,up2)");
 }
 }  // namespace
 
@@ -732,15 +452,7 @@ extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s_, const void* x, int ld_x, co
     p.N = N; p.Di = D; p.Hi = H; p.Wi = W; p.Do = 2 * D; p.Ho = 2 * H; p.Wo = 2 * W;
     p.C = C; p.M = K; p.Mpad = lnn_round_up(K, 32); p.KCpad = lnn_round_up(C, 16); p.wtaps = 8;
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 2; p.pad_lo = 0;
-    if (use_up2()) return lnn_launch_up2_convT(s, p, "lnn_convT3d_k2s2_fwd(up2)");
-    int rc = LNN_OK;
-    for (int cls = 0; cls < 8 && rc == LNN_OK; ++cls) {
-        ConvParams q = p;
-        q.par_z = cls >> 2; q.par_y = (cls >> 1) & 1; q.par_x = cls & 1;
-        q.taps.ntaps = 1; q.taps.pos_off[0] = 0; q.taps.slot[0] = (unsigned char)cls;
-        rc = dispatch_ck_mt<1, 1, 4, 8>(s, q, "lnn_convT3d_k2s2_fwd");
-    }
-    return rc;
+    return lnn_launch_up2_convT(s, p, "lnn_convT3d_k2s2_fwd(up2)");
 }
 
 extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx,
@@ -755,15 +467,6 @@ extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy
     p.N = N; p.Di = 2 * D; p.Hi = 2 * H; p.Wi = 2 * W; p.Do = D; p.Ho = H; p.Wo = W;
     p.C = K; p.M = C; p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16); p.wtaps = 8;
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 1; p.pad_lo = 0; p.accumulate = accumulate;
-    if (use_down2() && use_down2s(p)) return lnn_launch_down2s(s, p, "lnn_convT3d_k2s2_dgrad(down2s)");
-    if (use_down2()) return lnn_launch_down2_convT_dgrad(s, p, "lnn_convT3d_k2s2_dgrad(down2)");
-    constexpr int PY = 2 * 7 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=8
-    p.taps.ntaps = 8;
-    for (int t = 0; t < 8; ++t) {
-        p.taps.pos_off[t] = (unsigned short)(((t >> 2) * PY + ((t >> 1) & 1)) * PX + (t & 1));
-        p.taps.slot[t] = (unsigned char)t;
-    }
-    const bool mt2 = p.M > 32;
-    return mt2 ? launch_igemm<2, 2, 2, 8, 16, 2>(s, p, "lnn_convT3d_k2s2_dgrad")
-               : launch_igemm<2, 2, 2, 8, 16, 1>(s, p, "lnn_convT3d_k2s2_dgrad");
+    if (use_down2s(p)) return lnn_launch_down2s(s, p, "lnn_convT3d_k2s2_dgrad(down2s)");
+    return lnn_launch_down2_convT_dgrad(s, p, "lnn_convT3d_k2s2_dgrad(down2)");
 }

@@ -34,10 +34,11 @@ struct WgradParams {
     int tiles_z, tiles_y, tiles_x, tiles_total, tiles_per_block;
     int pad_lo;
     // deterministic mode (lnn_*_wgrad_det): every writer of a block stores its partial sums to its own copy of the panel,
-    // parts[(blockIdx.x * part_writers + writer) * part_stride + panel index]; wg_reduce_parts adds the copies in order
+    // parts[(tile chunk * part_writers + writer) * part_stride + panel index]; wg_reduce_parts adds the copies in order
     float* parts = nullptr;
     long parts_elems = 0, part_stride = 0;
     int part_writers = 1;
+    int xcd_group = 0, xcd_panels = 0;   // xcd_group > 0: 1-D grid in XCD-aware order over (tile chunk, panel), see wg_block()
     int debug = 0;                    // LNN_WGRAD_DEBUG (measurements only): 1 = skip the epilogue atomics, 4 = phase timers
     unsigned long long* dbgbuf = nullptr;   // LNN_WGRAD_PHASEBUF: 6 x u64 {issue, mfma, barrier1, store, barrier2, tiles}
     // first layer with the InstanceNorm / LeakyReLU backward folded in (lnn_conv3d_wgrad_c1_in_bwd): p = y (the conv output, NOT
@@ -62,11 +63,24 @@ __device__ __forceinline__ half4 lds_tr16(const char* addr) {
 }
 
 // panel accumulation: coalesced fp32 atomics (default) or, in deterministic mode, a plain store into this writer's panel copy
-__device__ __forceinline__ void wg_out(const WgradParams& p, int writer, long idx, float v) {
-    if (p.parts) p.parts[((long)blockIdx.x * p.part_writers + writer) * p.part_stride + idx] = v;
+__device__ __forceinline__ void wg_out(const WgradParams& p, int chunk, int writer, long idx, float v) {
+    if (p.parts) p.parts[((long)chunk * p.part_writers + writer) * p.part_stride + idx] = v;
     else atomicAdd(p.dwp + idx, v);
 }
-
+// Block -> (tile chunk, panel).  Default: a (chunks, panels) grid.  XCD-aware order (xcd_group > 0, 1-D grid): the hardware
+// deals consecutive workgroups round-robin to the 8 XCDs, each with its own 4 MB L2.  Blocks that walk the SAME tiles for
+// different panels are "siblings"; groups of xcd_group siblings (consecutive panels of one chunk) get consecutive slots of ONE
+// XCD -- they start together, stream the same operand tiles at the same time and the second to ask finds the lines (and the
+// other half of a 128-byte line of a 64-channel tensor) in that L2.  The groups themselves go round-robin over the XCDs, so
+// every XCD gets the same share whatever the chunk count.  In the (chunks, panels) grid two siblings are `chunks` workgroups
+// apart: on different XCDs unless chunks % 8 == 0.
+struct WgBlock { int chunk, panel; };
+__device__ __forceinline__ WgBlock wg_block(const WgradParams& p) {
+    if (p.xcd_group == 0) return {(int)blockIdx.x, (int)blockIdx.y};
+    const int l = blockIdx.x, s = l >> 3, g = p.xcd_group, gpc = p.xcd_panels / g;   // gpc = groups per chunk
+    const int u = (s / g) * 8 + (l & 7);                                               // group index
+    return {u / gpc, (u % gpc) * g + s % g};                                           // chunk >= chunks: nothing to do
+}
 __global__ __launch_bounds__(256) void wg_reduce_parts_kernel(const float* __restrict__ parts, int nslots, long slot_elems,
                                                               float* __restrict__ panel) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < slot_elems; i += (long)gridDim.x * 256 * 4) {
@@ -74,140 +88,6 @@ __global__ __launch_bounds__(256) void wg_reduce_parts_kernel(const float* __res
         for (int k = 1; k < nslots; ++k) a += *reinterpret_cast<const floatx4*>(parts + (long)k * slot_elems + i);
         floatx4* o = reinterpret_cast<floatx4*>(panel + i);
         *o = *o + a;
-    }
-}
-
-template <int IS, int EXT, int TZ, int TY, int TPW>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
-    constexpr int TX = 8, TV = TZ * TY * TX;
-    constexpr int PZ = IS * (TZ - 1) + EXT, PY = IS * (TY - 1) + EXT, PX = IS * (TX - 1) + EXT, P = PZ * PY * PX;
-    constexpr int ROWB = 80;  // 32 channels * 2 B + 16 B pad
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ql = smem;             // [P][ROWB]
-    char* pl = smem + P * ROWB;  // [TV][ROWB]
-    // LDS copies of the tap tables (dynamic kernarg indexing becomes dependent VMEM loads); carved from the END of
-    // the dynamic region so the dynamic base keeps its 16-byte alignment
-    int* tap_pos = reinterpret_cast<int*>(smem + (P + TV) * ROWB);
-    int* tap_slot = tap_pos + 32;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 27) { tap_pos[tid] = p.taps.pos_off[tid]; tap_slot[tid] = p.taps.slot[tid]; }
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
-
-    // transpose-read lane roles: 16-lane group g -> channel base 16*(g&1); lane s in group supplies the
-    // address of voxel (s>>2) (+4r, +8h) and channel sub-block 4*(s&3); it receives channel (s) of 4 voxels.
-    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
-    const int lane_ch_off = (cb + 4 * sq) * 2;
-    // voxel-in-chunk u = 8*hk + 4*r + sj  -> row hk of the chunk, x = 4r + sj
-    const int p_lane = (8 * hk + sj) * ROWB + lane_ch_off;
-    const int q_lane = ((IS * hk) * PX + IS * sj) * ROWB + lane_ch_off;
-
-    floatx16 acc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-    __syncthreads();
-    int tpos[TPW];
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = wave + 4 * ti;
-        tpos[ti] = tap < 27 ? __builtin_amdgcn_readfirstlane(tap_pos[tap < 27 ? tap : 0]) : 0;
-    }
-    const int t_begin = blockIdx.x * p.tiles_per_block;
-    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        int t = tile;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int tz = t % p.tiles_z; t /= p.tiles_z;
-        const int n = t;
-        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
-        const int iz0 = IS * lz0 - p.pad_lo, iy0 = IS * ly0 - p.pad_lo, ix0 = IS * lx0 - p.pad_lo;
-        __syncthreads();
-        // ---- stage Q tile (gathered operand, 32 channels c0..c0+31) ------------------------------
-        const long qbase = (long)n * p.Qd * p.Qh * p.Qw;
-        for (int base = 0; base < P * 4; base += 1024) {
-            half8 r[4];
-            unsigned ok = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = min(base + i * 256 + tid, P * 4 - 1);
-                const int pos = idx >> 2, c8 = idx & 3;
-                const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-                const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-                const bool v_ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh &&
-                                  (unsigned)ix < (unsigned)p.Qw && c0 + c8 * 8 < p.C;
-                const long off = v_ok ? (qbase + ((long)iz * p.Qh + iy) * p.Qw + ix) * p.ld_q + c0 + c8 * 8 : 0;
-                r[i] = *reinterpret_cast<const half8*>(p.q + off);
-                ok |= (v_ok ? 1u : 0u) << i;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = base + i * 256 + tid;
-                if (idx < P * 4) *reinterpret_cast<half8*>(ql + (idx >> 2) * ROWB + (idx & 3) * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
-            }
-        }
-        // ---- stage P tile (32 channels m0..m0+31 at the loop voxels) ------------------------------
-        const long pbase = (long)n * p.Ld * p.Lh * p.Lw;
-        for (int base = 0; base < TV * 4; base += 1024) {
-            half8 r[4];
-            unsigned ok = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = min(base + i * 256 + tid, TV * 4 - 1);
-                const int vox = idx >> 2, c8 = idx & 3;
-                const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
-                const int lz = lz0 + z, ly = ly0 + y, lx = lx0 + x;
-                const bool v_ok = lz < p.Ld && ly < p.Lh && lx < p.Lw && m0 + c8 * 8 < p.M;
-                const long off = v_ok ? (pbase + ((long)lz * p.Lh + ly) * p.Lw + lx) * p.ld_p + m0 + c8 * 8 : 0;
-                r[i] = *reinterpret_cast<const half8*>(p.p + off);
-                ok |= (v_ok ? 1u : 0u) << i;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = base + i * 256 + tid;
-                if (idx < TV * 4) *reinterpret_cast<half8*>(pl + (idx >> 2) * ROWB + (idx & 3) * 16) = ((ok >> i) & 1u) ? r[i] : zero8;
-            }
-        }
-        __syncthreads();
-        // ---- contraction over the tile's voxels, 16 per MFMA --------------------------------------
-#pragma unroll 2
-        for (int ch = 0; ch < TV / 16; ++ch) {
-            // chunk rows 2ch, 2ch+1 (8 voxels each)
-            const int row = 2 * ch;  // + hk folded into lane offsets
-            const int z = row / TY, y = row % TY;
-            const char* pa = pl + ch * 16 * ROWB + p_lane;
-            half4 a0 = lds_tr16(pa), a1 = lds_tr16(pa + 4 * ROWB);
-            half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            const char* qa = ql + ((IS * z * PY + IS * y) * PX) * ROWB + q_lane;
-#pragma unroll
-            for (int ti = 0; ti < TPW; ++ti) {
-                const int tap = wave + 4 * ti;
-                if (tap < p.taps.ntaps) {
-                    const char* qt = qa + tpos[ti] * ROWB;
-                    half4 b0 = lds_tr16(qt), b1 = lds_tr16(qt + 4 * IS * ROWB);
-                    half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
-                }
-            }
-        }
-    }
-    // ---- epilogue: D rows = m (8*(r>>2) + 4*hk + (r&3)), cols = c (lane&31) ----------------------
-    const int c = c0 + (lane & 31);
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = wave + 4 * ti;
-        if (tap < p.taps.ntaps) {
-            float* panel = p.dwp + (long)tap_slot[tap] * p.Mpad * p.Cpad;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                atomicAdd(panel + (long)m * p.Cpad + c, acc[ti][r]);
-            }
-        }
     }
 }
 
@@ -234,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
     char* const pl = smem + QB;   // [TV][64 B]  transpose reads (4 voxels x 32 B per 16-lane group) are conflict free
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
+    const WgBlock blk = wg_block(p);
+    const int m0 = (blk.panel / (p.Cpad / 32)) * 32, c0 = (blk.panel % (p.Cpad / 32)) * 32;
     // Q = channel concatenation of two tensors (lnn_conv3d_wgrad_cat): this block's 32-channel panel lives in one of them
     const half_t* const qsrc = c0 >= p.csplit ? p.q2 : p.q;
     const int cq = c0 >= p.csplit ? c0 - p.csplit : c0;
@@ -249,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_begin = blk.chunk * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
     if (t_begin >= t_end) return;
 
@@ -447,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                wg_out(p, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
+                wg_out(p, blk.chunk, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
             }
         }
     }
@@ -481,7 +362,8 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_s2_v2_kernel(const WgradPa
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpanels = p.Cpad / 32;
-    const int m0 = (blockIdx.y / cpanels) * 32 * MP, c0 = (blockIdx.y % cpanels) * 32;
+    const WgBlock blk = wg_block(p);
+    const int m0 = (blk.panel / cpanels) * 32 * MP, c0 = (blk.panel % cpanels) * 32;
     const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
     const int chb = (cb + 4 * sq) * 2;
     const int p_addr = (8 * hk + sj) * 64 + chb;
@@ -495,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_s2_v2_kernel(const WgradPa
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][a][j] = 0.f;
 
-    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_begin = blk.chunk * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
     if (t_begin >= t_end) return;
 
@@ -620,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_s2_v2_kernel(const WgradPa
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + mp * 32 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                    wg_out(p, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][mp][r]);
+                    wg_out(p, blk.chunk, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][mp][r]);
                 }
             }
         }
@@ -641,7 +523,8 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) char pl[TV * ROWB];
     __shared__ half_t xl[P];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 32;
+    const WgBlock blk = wg_block(p);
+    const int m0 = blk.panel * 32;
     const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
     const int p_lane = (8 * hk + sj) * ROWB + (cb + 4 * sq) * 2;
     const int tapn = lane & 31;
@@ -649,7 +532,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
     floatx16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_begin = blk.chunk * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
     if (t_begin >= t_end) return;
     // register prefetch of the next tile (round 2): the kernel is a streaming reduction over dy (4 MFMAs per wave and tile), and
@@ -759,7 +642,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-            wg_out(p, wave, (long)m * 32 + tapn, tapn < 27 ? acc[r] : 0.f);
+            wg_out(p, blk.chunk, wave, (long)m * 32 + tapn, tapn < 27 ? acc[r] : 0.f);
         }
     }
 }
@@ -773,6 +656,17 @@ int wg_prepare_parts(WgradParams& p, unsigned gridx, int writers, long slot_elem
     p.part_writers = writers;
     return LNN_OK;
 }
+// grid of a (chunks x panels) launch: XCD-aware 1-D order (wg_block) in sibling groups of 4 (2) when the panel count allows;
+// LNN_WGRAD_XCD=0 keeps the plain (chunks, panels) grid (A/B measurements)
+dim3 wg_grid(WgradParams& p, unsigned chunks, unsigned panels) {
+    static int xcd = -1;
+    if (xcd < 0) { const char* e = getenv("LNN_WGRAD_XCD"); xcd = (e && e[0] == '0') ? 0 : 1; }
+    const int g = panels % 4 == 0 ? 4 : (panels % 2 == 0 ? 2 : 1);
+    if (!xcd || g == 1) { p.xcd_group = 0; return dim3(chunks, panels); }
+    p.xcd_group = g; p.xcd_panels = (int)panels;
+    const unsigned groups = chunks * (panels / g);
+    return dim3((unsigned)lnn_round_up((int)groups, 8) * g);
+}
 int wg_reduce_parts(hipStream_t s, const WgradParams& p, unsigned gridx, long slot_elems, const char* name) {
     if (!p.parts) return LNN_OK;
     const long v4 = slot_elems / 4;
@@ -782,45 +676,23 @@ int wg_reduce_parts(hipStream_t s, const WgradParams& p, unsigned gridx, long sl
     return LNN_OK;
 }
 
-template <int IS, int EXT, int TZ, int TY, int TPW>
-int launch_wgrad(hipStream_t s, WgradParams& p, const char* name) {
-    constexpr int TX = 8, TV = TZ * TY * TX;
-    constexpr int PZ = IS * (TZ - 1) + EXT, PY = IS * (TY - 1) + EXT, PX = IS * (TX - 1) + EXT, P = PZ * PY * PX;
-    p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
-    p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
-    const int panels = (p.Mpad / 32) * (p.Cpad / 32);
-    // enough blocks to fill the chip ~4x over, but at least a few tiles per block to amortise the atomics
-    int tpb = lnn_cdiv((long)p.tiles_total * panels, 1024);
-    if (tpb < 1) tpb = 1;
-    if (tpb > 32) tpb = 32;
-    p.tiles_per_block = tpb;
-    const size_t lds = (size_t)(P + TV) * 80 + 256;   // + tap tables
-    auto kern = igemm_wgrad_kernel<IS, EXT, TZ, TY, TPW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
-    LNN_REQUIRE(!p.parts, "%s: the generic first-version kernel has no deterministic mode", name);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    LNN_CHECK_LAUNCH(name);
-    return LNN_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
-// Stride-1 weight gradient, v4 (round 2).  The phase timers of v2 (tools/kbench.py --wgrad-phases) showed where its time
-// goes per wave and tile: 4.6 k cycles ISSUING the 14 register-prefetch loads (the wave blocks while the CU's L1 absorbs
-// 57 KB at ~18 B/clk), 4.9 k in the MFMA loop, 1.5 k writing the registers to LDS, 0.8 k in two barriers -- the matrix
-// pipe sits at 43 %, and neither HBM (a MALL-resident half-size problem: +5 %) nor LDS latency (pipelined reads: +0 %) nor
-// the epilogue atomics (-2 % without them) is the limit.  v4 removes the issue and store phases instead of hiding them:
+// Stride-1 weight gradient (kernel "v5"; the register-prefetch kernels v1-v4 it grew out of were deleted in round 3).
+// Phase timers on the register-prefetch design showed per wave and tile 4.6 k cycles ISSUING the prefetch loads (the wave
+// blocks while the CU's L1 absorbs 57 KB at ~18 B/clk), 4.9 k in the MFMA loop, 1.5 k writing the registers to LDS, 0.8 k in
+// two barriers: neither HBM nor LDS latency nor the epilogue atomics was the limit, the issue and store phases were.  So:
 //   * tiles arrive by DMA (buffer_load ... lds, 16 B per lane straight into the linear [position][64 B] tile image; lanes
-//     outside the volume / channel range carry an out-of-range offset and the descriptor zero-fills them), 7 instructions
-//     per thread and tile, issued one at a time BETWEEN the MFMA groups of the current tile: no staging registers, no LDS
-//     store phase, the wave never waits for the address pipe;
-//   * two tile images (2 x 56 KB), ONE barrier per tile (vmcnt(0) + s_barrier);
+//     outside the volume / channel range carry an out-of-range offset and the descriptor zero-fills them = the conv's zero
+//     padding), issued one at a time BETWEEN the MFMA groups of the current tile: no staging registers, no LDS store
+//     phase, the wave never waits for the address pipe;
+//   * ONE barrier per tile (vmcnt(0) + s_barrier), dy tile double-buffered;
 //   * one 8-wave block per CU: wave = (tap group 0..3, tile half 0..1), 8 chunks x 7 taps = 56 MFMAs per wave and tile,
-//     operand reads software-pipelined two groups ahead and shared between the three dx taps of a row (see v2).
+//     operand reads software-pipelined two groups ahead and shared between the three dx taps of a row;
+//   * a z-ring of input planes: the 6x10x10 halo of a 4x8x8 tile is 2.34x its voxels and L2 keeps none of it (PMC 2.5x the
+//     algorithmic bytes without the ring).  A block walks a column of tiles in z, so 2 of the 6 input planes of the next
+//     tile are already in LDS: the input tile lives in a ring of 12 plane slots (10x10 positions x 64 B, padded to 7
+//     wave-wide DMA rows = 7 KB), only the 4 NEW planes are fetched per tile (6 when the next tile starts a new column),
+//     bytes per tile 54.4 -> 41.6 KB.  Out-of-volume planes use a zero-length descriptor.
 // ------------------------------------------------------------------------------------------------
 // The DMA is issued through inline asm: hipcc's waitcnt pass treats the transposing LDS read (an intrinsic without a
 // memory operand) like an LDS store and puts `s_waitcnt vmcnt(0)` in front of EVERY such read once an LDS-DMA load it knows
@@ -831,197 +703,7 @@ __device__ __forceinline__ void wg_dma16(uint4v rs, unsigned lds_addr, int voffs
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rs)
                  : "memory");       // m0 is reserved by the backend (it never allocates it), so no clobber entry is needed
 }
-__device__ __forceinline__ uint4v wg_rsrc(const void* base) {
-    const unsigned long long a = (unsigned long long)base;
-    uint4v r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
-    r[0] = __builtin_amdgcn_readfirstlane(r[0]);
-    r[1] = __builtin_amdgcn_readfirstlane(r[1]);
-    return r;
-}
 __device__ __forceinline__ void wg_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-template <int STEP>
-__global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v4_kernel(const WgradParams p) {
-    constexpr int TZ = 4, TY = 8, TX = 8, PZ = 6, PY = 10, PX = 10, P = PZ * PY * PX, TPW = 7;
-    constexpr int NQ = 5, NP = 2, NT = 512;                 // DMA instructions per thread and tile: 5 x 512 >= 4 P, 2 x 512 = 4 TV
-    constexpr int QB = NQ * NT * 16, BUFB = QB + NP * NT * 16;
-    constexpr int OOB = (int)0x80000000;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), tg = wave & 3, hf = wave >> 2;
-    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
-    const half_t* const qsrc = c0 >= p.csplit ? p.q2 : p.q;
-    const int cq = c0 >= p.csplit ? c0 - p.csplit : c0;
-    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
-    const int chb = (cb + 4 * sq) * 2;
-    // this wave's half of the tile = chunks 8 hf .. 8 hf + 7 = tile planes 2 hf, 2 hf + 1
-    const int p_addr = QB + (8 * hk + sj) * 64 + chb + hf * 8 * 1024;
-    const int q_lane = (hk * PX + sj) * 64 + chb + hf * 2 * PY * PX * 64;
-
-    floatx16 acc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-    const int t_begin = blockIdx.x * p.tiles_per_block;
-    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
-    if (t_begin >= t_end) return;
-
-    // per-thread DMA constants: byte offset relative to the tile origin and the packed tile coordinate of each piece
-    int qrel[NQ], qco[NQ], prel[NP], pco[NP];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int idx = i * NT + tid, pos = idx >> 2, c8 = idx & 3;
-        const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-        const bool st = pos < P;
-        qrel[i] = st ? (((pz * p.Qh + py) * p.Qw + px) * p.ld_q + c8 * 8) * 2 : OOB;
-        qco[i] = st ? (pz | (py << 8) | (px << 16) | (c8 << 24)) : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int idx = j * NT + tid, vox = idx >> 2, c8 = idx & 3;
-        const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
-        prel[j] = (((z * p.Lh + y) * p.Lw + x) * p.ld_p + c8 * 8) * 2;
-        pco[j] = z | (y << 8) | (x << 16) | (c8 << 24);
-    }
-
-    // accumulator ti -> tap: rows 2 tg (ti 0..2), 2 tg + 1 (ti 3..5), row 8 dx = tg (ti 6, tg < 3; a dropped duplicate for tg = 3)
-    auto tap_of = [&](int ti) { return ti < 6 ? (2 * tg + ti / 3) * 3 + ti % 3 : (tg < 3 ? 24 + tg : 27); };
-    int tapaddr[TPW];
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = min(tap_of(ti), 26);
-        tapaddr[ti] = q_lane + (((tap / 9) * PY + (tap / 3) % 3) * PX + tap % 3) * 64;
-    }
-
-    uint4v qrs, prs;
-    int qv[NQ], pv[NP];
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-    auto prep = [&](int tile) {            // descriptors + lane offsets of a tile (z runs fastest)
-        int t = tile;
-        const int tz = t % p.tiles_z; t /= p.tiles_z;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int n = t;
-        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
-        const long qbase = ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + cq;
-        const long pbase = ((((long)n * p.Ld + lz0) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
-        qrs = wg_rsrc(qsrc + qbase);
-        prs = wg_rsrc(p.p + pbase);
-        const bool interior = lz0 >= 1 && ly0 >= 1 && lx0 >= 1 && lz0 + TZ + 1 <= p.Qd && ly0 + TY + 1 <= p.Qh &&
-                              lx0 + TX + 1 <= p.Qw && c0 + 32 <= p.C && m0 + 32 <= p.M;
-        if (interior) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) qv[i] = qrel[i];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) pv[j] = prel[j];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int iz = lz0 - 1 + (qco[i] & 255), iy = ly0 - 1 + ((qco[i] >> 8) & 255), ix = lx0 - 1 + ((qco[i] >> 16) & 255);
-                const bool ok = qco[i] >= 0 && (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh &&
-                                (unsigned)ix < (unsigned)p.Qw && c0 + (qco[i] >> 24) * 8 < p.C;
-                qv[i] = ok ? qrel[i] : OOB;
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const bool ok = lz0 + (pco[j] & 255) < p.Ld && ly0 + ((pco[j] >> 8) & 255) < p.Lh && lx0 + ((pco[j] >> 16) & 255) < p.Lw &&
-                                m0 + (pco[j] >> 24) * 8 < p.M;
-                pv[j] = ok ? prel[j] : OOB;
-            }
-        }
-    };
-    auto issue = [&](int k, int nb) {      // k-th DMA instruction of the prepared tile into tile image nb
-        const unsigned base = lds0 + nb * BUFB + wave * 1024;
-        if (k < NQ) wg_dma16(qrs, base + k * (NT * 16), qv[k]);
-        else wg_dma16(prs, base + QB + (k - NQ) * (NT * 16), pv[k - NQ]);
-    };
-
-    prep(t_begin);
-#pragma unroll
-    for (int k = 0; k < NQ + NP; ++k) issue(k, 0);
-    wg_wait_all();
-    __syncthreads();
-
-    int cur = 0;
-#pragma unroll 1
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const bool more = tile + 1 < t_end;
-        if (more) prep(tile + 1);
-        const char* const tb = smem + cur * BUFB;
-        constexpr int NCH = 8;
-        auto qrow = [&](int ch) { return (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64; };
-        half4 al[2], ah[2];
-        auto rdA = [&](int ch) {
-            al[ch & 1] = lds_tr16(tb + ch * 1024 + p_addr);
-            ah[ch & 1] = lds_tr16(tb + ch * 1024 + 256 + p_addr);
-        };
-        uint2v g0[3], g1[3], g2[3];
-        auto rdG = [&](int g) {
-            const int ch = g / 3, k = g % 3, sl = g % 3;
-            const char* qa = tb + qrow(ch) + tapaddr[3 * k];
-            g0[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa));
-            g1[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 256));
-            if (k < 2) g2[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 512));
-        };
-        rdA(0);
-        rdG(0);
-        rdG(1);
-#pragma unroll
-        for (int g = 0; g < 3 * NCH; ++g) {
-            const int ch = g / 3, k = g % 3, sl = g % 3;
-            if (g + 2 < 3 * NCH) rdG(g + 2);
-            if (k == 1 && ch + 1 < NCH) rdA(ch + 1);
-            if (g % STEP == STEP - 1 && g / STEP < NQ + NP) {
-                if (more) issue(g / STEP, cur ^ 1);
-            }
-            const half8 a = {al[ch & 1][0], al[ch & 1][1], al[ch & 1][2], al[ch & 1][3],
-                             ah[ch & 1][0], ah[ch & 1][1], ah[ch & 1][2], ah[ch & 1][3]};
-            const uint2v d01 = g0[sl], d23 = g1[sl], d45 = g2[sl];
-            const uint4v w0 = {d01[0], d01[1], d23[0], d23[1]};
-            if (k < 2) {
-                const uint4v w1 = {__builtin_amdgcn_alignbit(d01[1], d01[0], 16), __builtin_amdgcn_alignbit(d23[0], d01[1], 16),
-                                   __builtin_amdgcn_alignbit(d23[1], d23[0], 16), __builtin_amdgcn_alignbit(d45[0], d23[1], 16)};
-                const uint4v w2 = {d01[1], d23[0], d23[1], d45[0]};
-                acc[3 * k + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[3 * k + 0], 0, 0, 0);
-                acc[3 * k + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w1), acc[3 * k + 1], 0, 0, 0);
-                acc[3 * k + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w2), acc[3 * k + 2], 0, 0, 0);
-            } else {
-                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[6], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        wg_wait_all();                   // the next tile image is complete ...
-        __syncthreads();                 // ... and every wave is done reading this one
-        cur ^= 1;
-    }
-    const int c = c0 + (lane & 31);
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = tap_of(ti);
-        if (tap < 27) {
-            const long pbase_ = (long)tap * p.Mpad * p.Cpad;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                wg_out(p, hf, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stride-1 weight gradient, v5 = v4 + a z-ring of input planes.  With the issue stalls gone v4 moves 3.4-3.8 TB/s through
-// the fabric on the level-0 layers (the 6x10x10 halo of a 4x8x8 tile is 2.34x its voxels and L2 keeps none of it: PMC 2.5x
-// the algorithmic bytes), i.e. it is bandwidth-bound again.  A block walks a column of tiles in z, so 2 of the 6 input
-// planes of the next tile are already in LDS: the input tile lives in a ring of 12 plane slots (10x10 positions x 64 B,
-// padded to 7 wave-wide DMA rows = 7 KB), only the 4 NEW planes are fetched per tile (6 when the next tile starts a new
-// column: the ring has room for them next to the 6 planes in use), the dy tile stays double-buffered.  Bytes per tile
-// 54.4 -> 41.6 KB.  Out-of-volume planes use a zero-length descriptor, out-of-volume rows / columns / channels an
-// out-of-range lane offset: both make the DMA write zeros (= the conv's zero padding).
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4v wg_rsrc_n(const void* base, unsigned num_records) {
     const unsigned long long a = (unsigned long long)base;
     uint4v r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, num_records, 0x00020000u};
@@ -1041,7 +723,8 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), tg = wave & 3, hf = wave >> 2;
-    const int m0 = (blockIdx.y / (p.Cpad / 32)) * 32, c0 = (blockIdx.y % (p.Cpad / 32)) * 32;
+    const WgBlock blk = wg_block(p);
+    const int m0 = (blk.panel / (p.Cpad / 32)) * 32, c0 = (blk.panel % (p.Cpad / 32)) * 32;
     const half_t* const qsrc = c0 >= p.csplit ? p.q2 : p.q;
     const int cq = c0 >= p.csplit ? c0 - p.csplit : c0;
     const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
@@ -1065,7 +748,7 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_begin = blk.chunk * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
     if (t_begin >= t_end) return;
 
@@ -1257,13 +940,13 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                wg_out(p, hf, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
+                wg_out(p, blk.chunk, hf, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
             }
         }
     }
 }
 
-int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
+int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
     constexpr int TZ = 4, TY = 8, TX = 8;
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
     p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
@@ -1273,9 +956,8 @@ int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
         int dev = 0;
         hipDeviceProp_t prop;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     static int dbg4 = -1;
     static unsigned long long* dbgbuf4 = nullptr;
@@ -1285,34 +967,20 @@ int launch_wgrad_s1_v4(hipStream_t s, WgradParams& p) {
     }
     p.debug = dbg4; p.dbgbuf = dbgbuf4;
     static int step = 0;
-    if (!step) { const char* e = getenv("LNN_WGRAD_V4_STEP"); step = e ? atoi(e) : 2; if (step < 1 || step > 3) step = 2; }
+    if (!step) { const char* e = getenv("LNN_WGRAD_V4_STEP"); step = e ? atoi(e) : 2; if (step < 1 || step > 2) step = 2; }
     // one block per CU: spread tiles x panels over ~num_cu blocks, >= 1 tile per block
     int tpb = lnn_cdiv((long)p.tiles_total * panels, num_cu);
     if (tpb < 1) tpb = 1;
     if (tpb > p.tiles_total) tpb = p.tiles_total;
     p.tiles_per_block = tpb;
-    const size_t lds = (size_t)2 * (5 + 2) * 512 * 16;
-    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
-    static int ring = -1;
-    if (ring < 0) {
-        const char* e = getenv("LNN_WGRAD_RING");
-        ring = (e && e[0] == '0') ? 0 : 1;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    const unsigned chunks = (unsigned)lnn_cdiv(p.tiles_total, tpb);
+    const dim3 grid = wg_grid(p, chunks, (unsigned)panels);
     const long slot_elems = 27L * p.Mpad * p.Cpad;
-    if (int e = wg_prepare_parts(p, grid.x, 2, slot_elems, "lnn_conv3d_wgrad(s1)")) return e;       // writers: the two tile halves
-    if (ring) {
-        if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<1>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
-        else hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<2>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
-        LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v5)");
-        return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(s1,v5,reduce)");
-    }
-    if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<1>), grid, dim3(512), lds, s, p);
-    else if (step == 2) hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<2>), grid, dim3(512), lds, s, p);
-    else hipLaunchKernelGGL((igemm_wgrad_s1_v4_kernel<3>), grid, dim3(512), lds, s, p);
-    LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v4)");
-    return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(s1,v4,reduce)");
+    if (int e = wg_prepare_parts(p, chunks, 2, slot_elems, "lnn_conv3d_wgrad(s1)")) return e;       // writers: the two tile halves
+    if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<1>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
+    else hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<2>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
+    LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v5)");
+    return wg_reduce_parts(s, p, chunks, slot_elems, "lnn_conv3d_wgrad(s1,v5,reduce)");
 }
 
 int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
@@ -1370,22 +1038,13 @@ int launch_wgrad_s2_v2(hipStream_t s, WgradParams& p, const char* name) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         attr_set = true;
     }
-    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
+    const unsigned chunks = (unsigned)lnn_cdiv(p.tiles_total, tpb);
+    const dim3 grid = wg_grid(p, chunks, (unsigned)panels);
     const long slot_elems = (long)(EXT * EXT * EXT) * p.Mpad * p.Cpad;
-    if (int e = wg_prepare_parts(p, grid.x, 1, slot_elems, name)) return e;
+    if (int e = wg_prepare_parts(p, chunks, 1, slot_elems, name)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
     LNN_CHECK_LAUNCH(name);
-    return wg_reduce_parts(s, p, grid.x, slot_elems, name);
-}
-
-// LNN_WGRAD_S2_V1=1 selects the generic kernel for the stride-2 / transposed-conv weight gradients (A/B measurements)
-bool use_wgrad_s2_v2() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LNN_WGRAD_S2_V1");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v == 1;
+    return wg_reduce_parts(s, p, chunks, slot_elems, name);
 }
 
 int check_act_w(const void* ptr, int ld, int C, const char* what) {
@@ -1467,24 +1126,14 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
             p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
             p.taps.slot[t] = (unsigned char)t;
         }
-        static int use_v1 = -1;
-        if (use_v1 < 0) { const char* e = getenv("LNN_CONV_V1"); use_v1 = (e && e[0] == '1') ? 1 : 0; }
-        LNN_REQUIRE(!(use_v1 && x2), "lnn_conv3d_wgrad_cat: not supported by the generic first-version kernel (LNN_CONV_V1)");
-        if (use_v1) return launch_wgrad<1, 3, 4, 8, 7>(s, p, "lnn_conv3d_wgrad(s1)");
-        static int use_v2 = -1;          // LNN_WGRAD_V2=1: the register-prefetch kernel of round 1 (A/B measurements, tests)
+        static int use_v2 = -1;          // LNN_WGRAD_V2=1: the register-prefetch kernel (kept: fallback for >2 GB plane sets, A/B measurements, tests)
         if (use_v2 < 0) { const char* e = getenv("LNN_WGRAD_V2"); use_v2 = (e && e[0] == '1') ? 1 : 0; }
         // the DMA descriptors address a tile with 32-bit offsets relative to its origin: 6 input planes must stay below 2 GB
-        const bool v4_ok = 6L * p.Qh * p.Qw * p.ld_q * 2 < 0x7fffffffL && 4L * p.Lh * p.Lw * p.ld_p * 2 < 0x7fffffffL;
-        if (!use_v2 && v4_ok) return launch_wgrad_s1_v4(s, p);
+        const bool dma_ok = 6L * p.Qh * p.Qw * p.ld_q * 2 < 0x7fffffffL && 4L * p.Lh * p.Lw * p.ld_p * 2 < 0x7fffffffL;
+        if (!use_v2 && dma_ok) return launch_wgrad_s1_v5(s, p);
         return launch_wgrad_s1_v2(s, p);
     }
-    if (use_wgrad_s2_v2()) return launch_wgrad_s2_v2<3>(s, p, "lnn_conv3d_wgrad(s2,v2)");
-    constexpr int PY = 2 * 3 + 3, PX = 2 * 7 + 3;  // IS=2, TZ=2, TY=4, TX=8
-    for (int t = 0; t < 27; ++t) {
-        p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
-        p.taps.slot[t] = (unsigned char)t;
-    }
-    return launch_wgrad<2, 3, 2, 4, 7>(s, p, "lnn_conv3d_wgrad(s2)");
+    return launch_wgrad_s2_v2<3>(s, p, "lnn_conv3d_wgrad(s2,v2)");
 }
 }  // namespace
 
@@ -1554,13 +1203,6 @@ int convT3d_k2s2_wgrad_impl(lnn_stream_t s_, const void* x, int ld_x, const void
     p.parts = parts; p.parts_elems = parts_elems;
     p.N = N; p.Ld = D; p.Lh = H; p.Lw = W; p.Qd = 2 * D; p.Qh = 2 * H; p.Qw = 2 * W;
     p.M = C; p.C = K; p.Mpad = lnn_round_up(C, 32); p.Cpad = lnn_round_up(K, 32); p.pad_lo = 0;
-    if (use_wgrad_s2_v2()) return launch_wgrad_s2_v2<2>(s, p, "lnn_convT3d_k2s2_wgrad(v2)");
-    constexpr int PY = 2 * 3 + 2, PX = 2 * 7 + 2;  // IS=2, EXT=2, TZ=2, TY=4
-    p.taps.ntaps = 8;
-    for (int t = 0; t < 8; ++t) {
-        p.taps.pos_off[t] = (unsigned short)(((t >> 2) * PY + ((t >> 1) & 1)) * PX + (t & 1));
-        p.taps.slot[t] = (unsigned char)t;
-    }
-    return launch_wgrad<2, 2, 2, 4, 2>(s, p, "lnn_convT3d_k2s2_wgrad");
+    return launch_wgrad_s2_v2<2>(s, p, "lnn_convT3d_k2s2_wgrad(v2)");
 }
 }  // namespace

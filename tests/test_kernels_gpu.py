@@ -509,7 +509,7 @@ def test_batch_dice_data_parallel_exchange_equals_full_batch():
     assert float((got - dfull).abs().max()) <= 1e-6 * float(dfull.abs().max())
 
 
-@pytest.mark.parametrize("which", [1, 5, 7, 8, 9])
+@pytest.mark.parametrize("which", [5, 7, 8, 9])
 def test_every_stride1_conv_kernel_variant(which):
     """The automatic selection picks v5 / v7 / v8 / v9 by layer shape, so the small parity shapes above only exercise v5:
     pin each shipped stride-1 kernel in turn and run forward + dgrad (with and without accumulation) on all

@@ -16,9 +16,12 @@ LAYERS = {  # name: (N, C, K, D, H, W, stride)
     "enc2.1": (2, 128, 128, 40, 48, 40, 1), "dec2.0d": (2, 128, 256, 40, 48, 40, 1),     # 128 input channels (v9 <8,1,1> since round 3)
     "dec4.0half": (2, 64, 32, 80, 96, 80, 1), "enc0.1half": (2, 32, 32, 80, 96, 80, 1),   # same layers, 1/8 of the voxels (fit the MALL)
     "enc1.0s2": (2, 32, 64, 160, 192, 160, 2), "enc2.0s2": (2, 64, 128, 80, 96, 80, 2),
+    "enc3.0s2": (2, 128, 256, 40, 48, 40, 2), "enc4.0s2": (2, 256, 320, 20, 24, 20, 2),
+    "enc4.1": (2, 320, 320, 10, 12, 10, 1), "dec0.0": (2, 640, 320, 10, 12, 10, 1), "enc5.1": (2, 320, 320, 5, 6, 5, 1),
+    "dec1.0": (2, 512, 256, 20, 24, 20, 1),
 }
 UPS = {  # transposed conv k2s2: name: (N, C, K, D, H, W) (low-res extents)
-    "up4": (2, 64, 32, 80, 96, 80), "up3": (2, 128, 64, 40, 48, 40),
+    "up4": (2, 64, 32, 80, 96, 80), "up3": (2, 128, 64, 40, 48, 40), "up2": (2, 256, 128, 20, 24, 20),
 }
 
 
@@ -54,7 +57,18 @@ def main():
             e1.record(); torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / a.iters * 1e-3
             gb = (x.numel() + y.numel()) * 2 / 1e9
-            print(f"{name:9s} {C:4d}->{K:<4d} convT @{D}x{H}x{W} : fwd {t*1e3:7.3f} ms  {gb/t:6.0f} GB/s algorithmic", flush=True)
+            line = f"{name:9s} {C:4d}->{K:<4d} convT @{D}x{H}x{W} : fwd {t*1e3:7.3f} ms  {gb/t:6.0f} GB/s algorithmic"
+            if "wgrad" in a.which:
+                panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 8, C, K), device=dev)
+                fw = lambda: nat.call("lnn_convT3d_k2s2_wgrad", x, C, y, K, panel, N, D, H, W, C, K)
+                fw(); torch.cuda.synchronize()
+                e0.record()
+                for _ in range(a.iters):
+                    fw()
+                e1.record(); torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) / a.iters * 1e-3
+                line += f" | wgrad {t*1e3:7.3f} ms  {gb/t:6.0f} GB/s"
+            print(line, flush=True)
             del x, y
             continue
         cat = name.endswith("cat")            # e.g. dec4.0cat: the input as two separate 32-channel tensors
