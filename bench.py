@@ -503,6 +503,14 @@ def main():
             traffic, traffic_note = tj["kernels"][dom_key]["hbm_bytes_per_launch_corrected"], "profiles/r03_pmc_traffic.json: " + tj["note"]
         except Exception:
             pass
+        clock = None
+        try:      # shader clock and matrix-pipe busy cycles of the same launches (committed PMC pass, tools/pmc_mfma_clock.py)
+            cj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_mfma_clock.json")))
+            clock = {k: {"clock_ghz": v["clock_ghz"], "mfma_busy_frac_in_cycles": v["mfma_busy_frac_in_cycles"]}
+                     for k, v in cj["families"].items() if v}
+            clock["source"] = "profiles/r03_pmc_mfma_clock.json (GRBM_GUI_ACTIVE / duration; SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles)"
+        except Exception:
+            pass
         ach = dom["achieved_in_step"] or dom["achieved_isolated"]
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"] + " on " + kr["layer"], "achieved": ach,
                            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
@@ -515,7 +523,7 @@ def main():
                                   "launch repeated back to back on an idle chip (the forward call includes its 2 tiny statistics "
                                   "launches)",
                            "algorithmic_gflop_per_launch": kr["kernels"][dom_key]["gflop"],
-                           "families": fams, "slowest_family": dom_key}
+                           "families": fams, "slowest_family": dom_key, "pmc_clock_and_matrix_pipe": clock}
         try:
             out["regulariser_kernels"] = regulariser_rooflines(tr, plans)
         except Exception as e:
