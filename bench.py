@@ -143,6 +143,24 @@ def kernel_rooflines(trainer):
             "kernels": {k: {"tflops": f / t / 1e12, "ms": t * 1e3, "gflop": f / 1e9} for k, (f, t) in res.items()}}
 
 
+def library_gemm_reference(n=8192, iters=20):
+    """Calibration, not product: the vendor library's plain fp16 GEMM (torch.matmul -> hipBLASLt) on this box in this run, as a
+    measured reference for what fraction of the 2.5 PFLOP/s datasheet peak dense fp16 MFMA code sustains here (the part lowers its
+    clock under dense MFMA: profiles/r03_library_gemm_roof.txt)."""
+    import torch
+    a = torch.randn((n, n), device="cuda", dtype=torch.float16)
+    b = torch.randn((n, n), device="cuda", dtype=torch.float16)
+    for _ in range(3):
+        torch.matmul(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.matmul(a, b)
+    e1.record(); torch.cuda.synchronize()
+    tf = 2.0 * n ** 3 / (e0.elapsed_time(e1) / iters * 1e-3) / 1e12
+    return {"what": "torch.matmul fp16 %d^3 (hipBLASLt), same box, same run" % n, "tflops": tf, "frac_of_peak": tf / PEAK_MFMA_F16_TFLOPS}
+
+
 def regulariser_rooflines(trainer, plans):
     """HIP-event timing of the HBM-bound regulariser / optimiser kernels at this workload's sizes (P = flat arena size;
     logits of the full-resolution level), algorithmic bytes as SURVEY.md 8(d) counts them, against the 8 TB/s HBM peak."""
@@ -524,6 +542,12 @@ def main():
                                   "launches)",
                            "algorithmic_gflop_per_launch": kr["kernels"][dom_key]["gflop"],
                            "families": fams, "slowest_family": dom_key, "pmc_clock_and_matrix_pipe": clock}
+        try:
+            ref = library_gemm_reference()
+            out["roofline"]["library_gemm_fp16_reference"] = ref
+            out["roofline"]["achieved_vs_library_gemm"] = ach / ref["tflops"]
+        except Exception as e:
+            out["roofline"]["library_gemm_fp16_reference"] = {"error": repr(e)}
         try:
             out["regulariser_kernels"] = regulariser_rooflines(tr, plans)
         except Exception as e:
