@@ -120,79 +120,76 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const half_t* __restrict__
     });
 }
 
-// Finalize kernels: 256 threads = 16 (n,c) entries x 16 slices of the block partials; returns the fp64 total of
-// entry i = blockIdx.x * 16 + (threadIdx.x & 15) for accumulator a (valid in the threads with slice 0).
-__device__ __forceinline__ double sum_partials_at(const float* pws, int a, int nblk, int NC, double* red, int i) {
-    const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    double s = 0;
-    if (i < NC) {
-        const float* p = pws + (long)a * nblk * NC + i;
-        int b = sl;
-        for (; b + 48 < nblk; b += 64) {          // four independent loads in flight (the dependent chain was latency-bound)
-            const float a0 = p[(long)b * NC], a1 = p[(long)(b + 16) * NC], a2 = p[(long)(b + 32) * NC], a3 = p[(long)(b + 48) * NC];
-            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-        }
-        for (; b < nblk; b += 16) s += (double)p[(long)b * NC];
+// Finalize kernels: 256 threads = EB entries x SL slices of the block partials (EB = 256 / SL).  They are a handful of blocks
+// of pure load latency, so the loads of a thread are all independent and issued together: with 16 slices and 4 loads in flight a
+// 1024-partial entry was 16 dependent round trips (15 us for the sums kernel of a 32-channel layer, 18 such launches per step);
+// 64 slices x 16 loads in flight make it one.
+constexpr int FSL = 64, FEB = 256 / FSL;
+// fp64 sum of partials sl, sl + SL, ... of one entry (p = address of partial 0 of the entry, stride in floats)
+template <int SL>
+__device__ __forceinline__ double slice_sum(const float* p, long stride, int nparts, int sl) {
+    double acc = 0;
+    int b = sl;
+    for (; b + 15 * SL < nparts; b += 16 * SL) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = p[(long)(b + k * SL) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) acc += ((double)v[k] + (double)v[k + 1]) + ((double)v[k + 2] + (double)v[k + 3]);
     }
+    for (; b + 3 * SL < nparts; b += 4 * SL) {
+        const float a0 = p[(long)b * stride], a1 = p[(long)(b + SL) * stride], a2 = p[(long)(b + 2 * SL) * stride],
+                    a3 = p[(long)(b + 3 * SL) * stride];
+        acc += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; b < nparts; b += SL) acc += (double)p[(long)b * stride];
+    return acc;
+}
+// Sum of J values per thread over the SL slices of its entry (thread = slice * EB + entry); totals valid in the threads of
+// slice 0.  Fixed order: bit-reproducible.  red: J * 256 doubles.
+template <int SL, int J>
+__device__ __forceinline__ void reduce_slices(double (&s)[J], double* red) {
+    constexpr int EB = 256 / SL;
+    const int ii = threadIdx.x % EB, sl = threadIdx.x / EB;
     __syncthreads();
-    red[threadIdx.x] = s;
+#pragma unroll
+    for (int j = 0; j < J; ++j) red[j * 256 + threadIdx.x] = s[j];
     __syncthreads();
+    if constexpr (SL > 16) {              // stage 1: slices 0..15 take slices sl + 16, sl + 32, ...
+        if (sl < 16) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                for (int k = sl + 16; k < SL; k += 16) s[j] += red[j * 256 + k * EB + ii];
+        }
+        __syncthreads();
+        if (sl < 16) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) red[j * 256 + threadIdx.x] = s[j];
+        }
+        __syncthreads();
+    }
     if (sl == 0) {
 #pragma unroll
-        for (int k = 1; k < 16; ++k) s += red[k * 16 + ii];
-    }
-    return s;
-}
-
-// Both accumulators (a = 0, 1) of TWO entries i0, i1 (pass NC for "none") with one pair of barriers: red4 holds 4 x 256 doubles.
-// Results valid in the threads with slice 0: out[2 * e + a].
-__device__ __forceinline__ void sum_partials_pair(const float* pws, int nblk, int NC, double* red4, int i0, int i1, double (&out)[4]) {
-    const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    double s[4] = {0, 0, 0, 0};
+        for (int j = 0; j < J; ++j)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int i = e ? i1 : i0;
-        if (i < NC) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const float* p = pws + (long)a * nblk * NC + i;
-                double acc = 0;
-                int b = sl;
-                for (; b + 48 < nblk; b += 64) {
-                    const float a0 = p[(long)b * NC], a1 = p[(long)(b + 16) * NC], a2 = p[(long)(b + 32) * NC], a3 = p[(long)(b + 48) * NC];
-                    acc += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-                }
-                for (; b < nblk; b += 16) acc += (double)p[(long)b * NC];
-                s[2 * e + a] = acc;
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red4[j * 256 + threadIdx.x] = s[j];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        double t = s[j];
-        if (sl == 0) {
-#pragma unroll
-            for (int k = 1; k < 16; ++k) t += red4[j * 256 + k * 16 + ii];
-        }
-        out[j] = t;
+            for (int k = 1; k < 16; ++k) s[j] += red[j * 256 + k * EB + ii];
     }
 }
 
-__device__ __forceinline__ double sum_partials(const float* pws, int a, int nblk, int NC, double* red) {
-    return sum_partials_at(pws, a, nblk, NC, red, blockIdx.x * 16 + (threadIdx.x & 15));
-}
-
+// grid = ceil(NC / FEB)
 __global__ void in_stats_finalize_kernel(const float* pws, int nblk, int NC, long V, float eps, float* mean, float* rstd) {
-    __shared__ double red[256];
-    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s0 = sum_partials(pws, 0, nblk, NC, red), s1 = sum_partials(pws, 1, nblk, NC, red);
-    if (i >= NC || (threadIdx.x >> 4) != 0) return;
-    const double m = s0 / (double)V;
-    double var = s1 / (double)V - m * m;
+    __shared__ double red[2 * 256];
+    const int ii = threadIdx.x % FEB, sl = threadIdx.x / FEB;
+    const int i = blockIdx.x * FEB + ii;
+    double t[2] = {0, 0};
+    if (i < NC) {
+        t[0] = slice_sum<FSL>(pws + i, NC, nblk, sl);
+        t[1] = slice_sum<FSL>(pws + (long)nblk * NC + i, NC, nblk, sl);
+    }
+    reduce_slices<FSL, 2>(t, red);
+    if (i >= NC || sl != 0) return;
+    const double m = t[0] / (double)V;
+    double var = t[1] / (double)V - m * m;
     if (var < 0) var = 0;
     mean[i] = (float)m;
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
@@ -388,28 +385,43 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
 // One thread group per CHANNEL, samples walked in order: the affine gradients are one ordered fp64 sum over n and ONE add per
 // call and channel (bit-reproducible for any batch size; the atomic only serves two sample lanes adding from two streams,
 // and two operands commute).  NC = N * C, grid = ceil(C / 16).
-__global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, int C, double* ws, float* dgamma, float* dbeta,
-                                         float unscale) {
-    __shared__ double red[4 * 256];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int N = NC / C;
+// (n, c) totals of pass 1 and the affine gradients of FEB channels per block: shared by the plain and the seg-head variant
+__device__ __forceinline__ void in_bwd_sums_block(const float* pws, int nblk, int N, int C, int blk, double* red, double* ws,
+                                                  float* dgamma, float* dbeta, float unscale) {
+    const int ii = threadIdx.x % FEB, sl = threadIdx.x / FEB;
+    const int c = blk * FEB + ii, NC = N * C;
     double g0 = 0, g1 = 0;
-    for (int n = 0; n < N; n += 2) {                   // two samples per barrier pair
-        const int i0 = c < C ? n * C + c : NC, i1 = (c < C && n + 1 < N) ? (n + 1) * C + c : NC;
-        double o[4];
-        sum_partials_pair(pws, nblk, NC, red, i0, i1, o);
-        if (c < C && (threadIdx.x >> 4) == 0) {
-            ws[(long)i0 * 3 + 0] = o[0]; ws[(long)i0 * 3 + 1] = o[1];
+    for (int n = 0; n < N; n += 2) {                   // two samples per reduction
+        const bool two = n + 1 < N;
+        double o[4] = {0, 0, 0, 0};
+        if (c < C) {
+            const float* p0 = pws + n * C + c;
+            o[0] = slice_sum<FSL>(p0, NC, nblk, sl);
+            o[1] = slice_sum<FSL>(p0 + (long)nblk * NC, NC, nblk, sl);
+            if (two) {
+                o[2] = slice_sum<FSL>(p0 + C, NC, nblk, sl);
+                o[3] = slice_sum<FSL>(p0 + C + (long)nblk * NC, NC, nblk, sl);
+            }
+        }
+        reduce_slices<FSL, 4>(o, red);
+        if (c < C && sl == 0) {
+            const long i0 = (long)n * C + c;
+            ws[i0 * 3 + 0] = o[0]; ws[i0 * 3 + 1] = o[1];
             g0 += o[0]; g1 += o[1];
-            if (i1 < NC) {
-                ws[(long)i1 * 3 + 0] = o[2]; ws[(long)i1 * 3 + 1] = o[3];
+            if (two) {
+                ws[(i0 + C) * 3 + 0] = o[2]; ws[(i0 + C) * 3 + 1] = o[3];
                 g0 += o[2]; g1 += o[3];
             }
         }
     }
-    if (c >= C || (threadIdx.x >> 4) != 0) return;
+    if (c >= C || sl != 0) return;
     if (dgamma) atomicAdd(dgamma + c, (float)(g1 * unscale));
     if (dbeta) atomicAdd(dbeta + c, (float)(g0 * unscale));
+}
+__global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, int C, double* ws, float* dgamma, float* dbeta,
+                                         float unscale) {
+    __shared__ double red[4 * 256];
+    in_bwd_sums_block(pws, nblk, NC / C, C, blockIdx.x, red, ws, dgamma, dbeta, unscale);
 }
 
 // pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V), in place over y; DBIAS: db partial = sum dy (the conv-bias gradient; it is
@@ -479,9 +491,12 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_apply_kernel(half_t* __restri
 __global__ void in_lrelu_bwd_finalize_kernel(const double* ws, const float* pws, int nblk, int N, int C, float* dgamma,
                                              float* dbeta, float* dbias, float unscale) {
     __shared__ double red[256];
-    const int i = blockIdx.x * 16 + (threadIdx.x & 15);          // (n, c) entry
-    const double db = sum_partials(pws, 0, nblk, N * C, red);
-    if (i >= N * C || (threadIdx.x >> 4) != 0) return;
+    const int ii = threadIdx.x % FEB, sl = threadIdx.x / FEB;
+    const int i = blockIdx.x * FEB + ii;                          // (n, c) entry
+    double t[1] = {i < N * C ? slice_sum<FSL>(pws + i, N * C, nblk, sl) : 0.0};
+    reduce_slices<FSL, 1>(t, red);
+    const double db = t[0];
+    if (i >= N * C || sl != 0) return;
     const int c = i % C;
     // atomics: N samples (and, with sample lanes, two HIP streams) add into the same channel
     (void)ws; (void)dgamma; (void)dbeta;        // the affine gradients are added by the sums kernel
@@ -655,53 +670,18 @@ __global__ __launch_bounds__(NT, (KT <= 3 && !PRIOR && QUAD) ? 3 : 2) void in_lr
 __global__ void in_lrelu_seg_bwd_sums_kernel(const float* pws, int nblk, int N, int C, int K, int nb_in, double* ws, float* dgamma,
                                              float* dbeta, float* dsegw, float unscale) {
     __shared__ double red[4 * 256];
-    const int ii = threadIdx.x & 15, sl = threadIdx.x >> 4;
     if ((int)blockIdx.x < nb_in) {                     // as in_lrelu_bwd_sums_kernel: per channel, samples in order
-        const int NC = N * C;
-        const int c = blockIdx.x * 16 + ii;
-        double g0 = 0, g1 = 0;
-        for (int n = 0; n < N; n += 2) {
-            const int i0 = c < C ? n * C + c : NC, i1 = (c < C && n + 1 < N) ? (n + 1) * C + c : NC;
-            double o[4];
-            sum_partials_pair(pws, nblk, NC, red, i0, i1, o);
-            if (c < C && sl == 0) {
-                ws[(long)i0 * 3 + 0] = o[0]; ws[(long)i0 * 3 + 1] = o[1];
-                g0 += o[0]; g1 += o[1];
-                if (i1 < NC) {
-                    ws[(long)i1 * 3 + 0] = o[2]; ws[(long)i1 * 3 + 1] = o[3];
-                    g0 += o[2]; g1 += o[3];
-                }
-            }
-        }
-        if (c >= C || sl != 0) return;
-        if (dgamma) atomicAdd(dgamma + c, (float)(g1 * unscale));
-        if (dbeta) atomicAdd(dbeta + c, (float)(g0 * unscale));
+        in_bwd_sums_block(pws, nblk, N, C, blockIdx.x, red, ws, dgamma, dbeta, unscale);
         return;
     }
-    // d seg_w: 16 consecutive entries (k * C + c) x 16 slices of the N * nblk block partials (partial b of entry i sits at
-    // pseg[b * K * C + i]); 4 independent loads in flight per thread -- with one the 128 dependent round trips of a slice took 30 us
+    // d seg_w: FEB consecutive entries (k * C + c) x FSL slices of the N * nblk block partials (partial b of entry i sits at
+    // pseg[b * K * C + i])
     const float* pseg = pws + 2l * nblk * N * C;
-    const int i = (blockIdx.x - nb_in) * 16 + ii;
-    const int nparts = nblk * N;
-    double s = 0;
-    if (i < K * C) {
-        const float* pp = pseg + i;
-        const long stride = (long)K * C;
-        int b = sl;
-        for (; b + 48 < nparts; b += 64) {
-            const float a0 = pp[(long)b * stride], a1 = pp[(long)(b + 16) * stride], a2 = pp[(long)(b + 32) * stride],
-                        a3 = pp[(long)(b + 48) * stride];
-            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-        }
-        for (; b < nparts; b += 16) s += (double)pp[(long)b * stride];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (sl == 0 && i < K * C) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) s += red[k * 16 + ii];
-        dsegw[i] += (float)(s * unscale);
-    }
+    const int ii = threadIdx.x % FEB, sl = threadIdx.x / FEB;
+    const int i = (blockIdx.x - nb_in) * FEB + ii;
+    double t[1] = {i < K * C ? slice_sum<FSL>(pseg + i, (long)K * C, nblk * N, sl) : 0.0};
+    reduce_slices<FSL, 1>(t, red);
+    if (sl == 0 && i < K * C) dsegw[i] += (float)(t[0] * unscale);
 }
 
 // pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V) over y, dz rebuilt as in pass 1
@@ -795,7 +775,7 @@ int check_common(const void* y, int N, long V, int C, const char* what) {
 }  // namespace
 
 int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd) {
-    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nslots, N * C, V, eps, mean, rstd);
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, FEB)), dim3(256), 0, s, pws, nslots, N * C, V, eps, mean, rstd);
     LNN_CHECK_LAUNCH("lnn_instnorm_stats(finalize, fused partials)");
     return LNN_OK;
 }
@@ -812,7 +792,7 @@ extern "C" int lnn_instnorm_stats(lnn_stream_t s_, const void* y, int N, long V,
     const int nblk = blocks_for(V, C);
     hipLaunchKernelGGL(in_stats_kernel, dim3(nblk, N), dim3(NT), 0, s, (const half_t*)y, V, C, pws);
     LNN_CHECK_LAUNCH("lnn_instnorm_stats");
-    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, pws, nblk, N * C, V, eps, mean, rstd);
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, FEB)), dim3(256), 0, s, pws, nblk, N * C, V, eps, mean, rstd);
     LNN_CHECK_LAUNCH("lnn_instnorm_stats(finalize)");
     return LNN_OK;
 }
@@ -869,14 +849,14 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
     hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, grid, dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
                        mean, rstd, gamma, beta, slope, pws, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(reduce)");
-    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, FEB)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
                        grad_unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(sums)");
     if (dbias) {
         hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<true>), grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
                            rstd, gamma, beta, slope, ws, pws, in_nt_flag());
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(apply)");
-        hipLaunchKernelGGL(in_lrelu_bwd_finalize_kernel, dim3(lnn_cdiv(N * C, 16)), dim3(256), 0, s, ws, pws, nblk, N, C, dgamma,
+        hipLaunchKernelGGL(in_lrelu_bwd_finalize_kernel, dim3(lnn_cdiv(N * C, FEB)), dim3(256), 0, s, ws, pws, nblk, N, C, dgamma,
                            dbeta, dbias, grad_unscale);
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(finalize)");
     } else {
@@ -904,14 +884,14 @@ extern "C" int lnn_instnorm_lrelu_seg_bwd(lnn_stream_t s_, void* y, const void* 
     const int nblk = blocks_for(V, C);
     const dim3 grid(nblk, N);
     const half_t* pr = (const half_t*)dz_prior;
-    const int nb_in = lnn_cdiv(C, 16);
+    const int nb_in = lnn_cdiv(C, FEB);
 #define LNN_SB(KT, PRIOR) do { if (C % 32 == 0) LNN_SBQ(KT, PRIOR, true); else LNN_SBQ(KT, PRIOR, false); } while (0)
 #define LNN_SBQ(KT, PRIOR, QUAD)                                                                                                     \
     do {                                                                                                                             \
         hipLaunchKernelGGL((in_lrelu_seg_bwd_reduce_kernel<KT, PRIOR, QUAD>), grid, dim3(NT), 0, s, (const half_t*)y, pr, ld_dz, V, C, \
                            mean, rstd, gamma, beta, slope, seg_w, dlogits, pws);                                                     \
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_bwd(reduce)");                                                                      \
-        hipLaunchKernelGGL(in_lrelu_seg_bwd_sums_kernel, dim3(nb_in + lnn_cdiv(K * C, 16)), dim3(256), 0, s, pws, nblk, N, C, K,     \
+        hipLaunchKernelGGL(in_lrelu_seg_bwd_sums_kernel, dim3(nb_in + lnn_cdiv(K * C, FEB)), dim3(256), 0, s, pws, nblk, N, C, K,     \
                            nb_in, ws, dgamma, dbeta, seg_dw, grad_unscale);                                                          \
         LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_bwd(sums)");                                                                        \
         hipLaunchKernelGGL((in_lrelu_seg_bwd_apply_kernel<KT, PRIOR, QUAD>), grid, dim3(NT), 0, s, (half_t*)y, pr, ld_dz, V, C, mean, \
@@ -942,7 +922,7 @@ extern "C" int lnn_instnorm_lrelu_bwd_sums(lnn_stream_t s_, const void* y, const
     hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, dim3(nblk, N), dim3(NT), 0, s, (const half_t*)y, (const half_t*)dz, ld_dz, V, C,
                        mean, rstd, gamma, beta, slope, pws, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(reduce)");
-    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, 16)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, FEB)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
                        grad_unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(sums)");
     return LNN_OK;

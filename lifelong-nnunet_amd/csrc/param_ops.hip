@@ -112,6 +112,25 @@ template <int NTAPS>
 __device__ __forceinline__ void pack_unit_load(const float* __restrict__ sp, half_t* tile, int TS, int mb, int ck, int M, int KC, long sm,
                                                long skc, long st, bool kc_inner) {
     constexpr int E = 512 * NTAPS;
+    // full units of tap-contiguous tensors: the unit is 32 (16) source runs of 16 (32) x NTAPS consecutive floats -> 16-byte loads
+    // (a quarter of the load instructions; the scalar loop below remains for ragged units and the first layer)
+    const bool full = mb * 32 + 32 <= M && ck * 16 + 16 <= KC && st == 1 && (kc_inner ? skc : sm) == NTAPS &&
+                      ((sm | skc) & 3) == 0 && (reinterpret_cast<unsigned long long>(sp) & 15) == 0;
+    if (NTAPS > 1 && full) {
+        const int RL4 = (kc_inner ? 4 : 8) * NTAPS;          // float4 per run
+        const float* base = sp + (long)mb * 32 * sm + (long)ck * 16 * skc;
+        for (int q = threadIdx.x; q < 128 * NTAPS; q += NT) {
+            const int o = q / RL4, j = q - o * RL4;
+            const floatx4 v = *reinterpret_cast<const floatx4*>(base + o * (kc_inner ? sm : skc) + 4 * j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = 4 * j + k, ir = x / NTAPS, t = x - ir * NTAPS;
+                const int kcl = kc_inner ? ir : o, ml = kc_inner ? o : ir;
+                tile[t * TS + ml * 16 + kcl] = (half_t)v[k];
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < E; e += NT) {
         const int t = e % NTAPS, r = e / NTAPS;
         const int kcl = kc_inner ? r % 16 : r / 32, ml = kc_inner ? r / 16 : r % 32;
@@ -441,6 +460,20 @@ template <int NTAPS>
 __device__ __forceinline__ void unpack_unit_store(float* __restrict__ op, const float* tile, int m0, int kc0, int M, int KC, long sm,
                                                   long skc, long st, bool kc_inner, float scale, int accumulate) {
     constexpr int E = 8 * 32 * NTAPS;
+    // full units of [m][kc][tap] tensors: a row's 32 x NTAPS destination floats are one contiguous run with the tile's own
+    // layout -> 16-byte LDS reads and 16-byte read-modify-writes
+    const bool full = kc_inner && m0 + 8 <= M && kc0 + 32 <= KC && st == 1 && skc == NTAPS && (sm & 3) == 0 &&
+                      (reinterpret_cast<unsigned long long>(op) & 15) == 0;
+    if (NTAPS > 1 && full) {
+        constexpr int RL4 = 8 * NTAPS;                       // float4 per row run
+        for (int q = threadIdx.x; q < 8 * RL4; q += NT) {
+            const int ml = q / RL4, j = q - ml * RL4;
+            floatx4* o = reinterpret_cast<floatx4*>(op + (long)(m0 + ml) * sm + (long)kc0 * NTAPS + 4 * j);
+            const floatx4 v = *reinterpret_cast<const floatx4*>(tile + ml * 32 * NTAPS + 4 * j) * scale;
+            *o = accumulate ? *o + v : v;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < E; e += NT) {
         const int t = e % NTAPS, r = e / NTAPS;
         const int kcl = kc_inner ? r % 32 : r / 8, ml = kc_inner ? r / 32 : r % 8;
@@ -456,7 +489,7 @@ __device__ __forceinline__ void unpack_unit_store(float* __restrict__ op, const 
 __global__ __launch_bounds__(NT) void unpack_wgrad_tiled_kernel(const float* __restrict__ dwp, float* __restrict__ dst,
                                                                 const long* __restrict__ desc, int n, float scale, int accumulate) {
     __shared__ long ufirst[DESC_MAX + 1];
-    __shared__ float tile[8 * 32 * 27];
+    __shared__ __attribute__((aligned(16))) float tile[8 * 32 * 27];
     if (threadIdx.x == 0) {
         long acc = 0;
         for (int j = 0; j < n; ++j) {
@@ -477,10 +510,19 @@ __global__ __launch_bounds__(NT) void unpack_wgrad_tiled_kernel(const float* __r
         const int m0 = (int)(lu / nck) * 8, kc0 = (int)(lu % nck) * 32;
         const int E = 8 * 32 * ntaps;
         const float* pp = dwp + d[0];
-        for (int e = threadIdx.x; e < E; e += NT) {
-            const int kcl = e & 31, ml = (e >> 5) & 7, t = e >> 8;
-            const int m = m0 + ml, kc = kc0 + kcl;
-            tile[(ml * 32 + kcl) * ntaps + t] = (m < M && kc < KC) ? pp[((long)t * Mpad + m) * KCpad + kc] : 0.f;
+        if (m0 + 8 <= M && (reinterpret_cast<unsigned long long>(pp) & 15) == 0) {       // panel rows are padded to 32 channels
+            for (int e4 = threadIdx.x; e4 < E / 4; e4 += NT) {
+                const int kcl = (e4 & 7) * 4, ml = (e4 >> 3) & 7, t = e4 >> 6;
+                const floatx4 v = *reinterpret_cast<const floatx4*>(pp + ((long)t * Mpad + m0 + ml) * KCpad + kc0 + kcl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tile[(ml * 32 + kcl + k) * ntaps + t] = v[k];
+            }
+        } else {
+            for (int e = threadIdx.x; e < E; e += NT) {
+                const int kcl = e & 31, ml = (e >> 5) & 7, t = e >> 8;
+                const int m = m0 + ml, kc = kc0 + kcl;
+                tile[(ml * 32 + kcl) * ntaps + t] = (m < M && kc < KC) ? pp[((long)t * Mpad + m) * KCpad + kc] : 0.f;
+            }
         }
         __syncthreads();
         const long sm = d[2], skc = d[3], st = d[4];
