@@ -215,8 +215,27 @@ __global__ __launch_bounds__(NT, 2) void igemm_up2_kernel(const ConvParams p, in
     char* const stg = smem;
     const int qz = qz0 + wz, qy = qy0 + wy;
     const int skey = (vx >> 1) & 3;
+    // accumulate mode (the encoder's strided dgrad adds to the skip gradient the decoder wrote): the 8 old rows of a pass are
+    // loaded BEFORE its staging writes and barrier, all in flight together -- inside the store loop each read-modify-write was a
+    // dependent global round trip (16 per block; the kernel ran at 0.12 busy matrix pipes and 3.2 TB/s)
+    const int eox = (lane >> 2) & 15, ec = lane & 3;
+    const int egx = 2 * qx0 + eox, em = m0 + ec * 8;
+    auto out_ptr = [&](int pz, int rr) -> half8* {
+        const int row = wave * 8 + rr, zl = row >> 4, oyl = row & 15;
+        const int oz = 2 * (qz0 + zl) + pz, oy = 2 * qy0 + oyl;
+        const bool ok = oz < p.Do && oy < p.Ho && egx < p.Wo && em < p.M;
+        return ok ? reinterpret_cast<half8*>(p.y + ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + egx) * p.ld_y + em) : nullptr;
+    };
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
+        half8 olds[8];
+        if (p.accumulate) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const half8* d = out_ptr(pz, rr);
+                olds[rr] = *(d ? d : reinterpret_cast<const half8*>(p.y));
+            }
+        }
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             const int cls = pz * 4 + c4, py = c4 >> 1, px = c4 & 1;
@@ -230,21 +249,17 @@ __global__ __launch_bounds__(NT, 2) void igemm_up2_kernel(const ConvParams p, in
         }
         __syncthreads();
         {
-            const int ox = (lane >> 2) & 15, c = lane & 3;
-            const int rkey = (ox >> 2) & 3;                              // = skey of the low-res voxel ox >> 1
-            const int gx = 2 * qx0 + ox, m = m0 + c * 8;
+            const int rkey = (eox >> 2) & 3;                             // = skey of the low-res voxel ox >> 1
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
-                const int row = wave * 8 + rr, zl = row >> 4, oyl = row & 15;
-                const int oz = 2 * (qz0 + zl) + pz, oy = 2 * qy0 + oyl;
-                half8 v = *reinterpret_cast<const half8*>(stg + row * RS + ox * 64 + ((c ^ (rkey >> 1)) << 4));
+                const int row = wave * 8 + rr;
+                half8 v = *reinterpret_cast<const half8*>(stg + row * RS + eox * 64 + ((ec ^ (rkey >> 1)) << 4));
                 if (rkey & 1) v = half8{v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-                if (oz < p.Do && oy < p.Ho && gx < p.Wo && m < p.M) {
-                    half8* dst = reinterpret_cast<half8*>(p.y + ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + gx) * p.ld_y + m);
+                half8* dst = out_ptr(pz, rr);
+                if (dst) {
                     if (p.accumulate) {
-                        const half8 old = *dst;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)olds[rr][e]);
                     }
                     *dst = v;
                 }

@@ -948,6 +948,227 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stride-2 gathers on the v5 recipe (round 3, "s2s"): same operand layout and MFMA loop as igemm_wgrad_s2_v2_kernel above (eight
+// parity sub-tiles, two 32-row P panels x one 32-column Q panel per block, taps wave, wave + 8, ...), but
+//   * a block walks a z COLUMN of tiles (1 loop plane x 8 x 8 loop voxels each); the Q planes live in an LDS ring of 2 EXT slots:
+//     with EXT = 3 plane 2 lz + 1 serves tile lz (tap dz = 2) and tile lz + 1 (dz = 0), so a step fetches 2 planes instead of 3;
+//   * tiles arrive by LDS-DMA (buffer_load ... lds), one tile ahead, issued one instruction at a time between the MFMA groups: no
+//     staging registers, no LDS store phase, ONE barrier per tile.  The (y, x)-parity de-interleave happens in the DMA: a lane's
+//     GLOBAL offset is chosen so that the wave's linear 1 KB run in LDS is already [parity][qy][qx][64 B].  Out-of-volume rows /
+//     columns / channels carry an out-of-range offset, out-of-volume planes a zero-length descriptor -> zeros (= the padding);
+//   * the register-prefetch kernel spent a global round trip per tile (27 MFMAs per wave = 0.8 us of matrix work against ~3.8 us
+//     per tile measured): it was paced by load latency, not by HBM or the matrix pipe.
+// ------------------------------------------------------------------------------------------------
+template <int EXT>
+__global__ __launch_bounds__(512, 2) void igemm_wgrad_s2s_kernel(const WgradParams p) {
+    constexpr int TY = 8, TX = 8, TV = 64, MP = 2, NT = 512;
+    constexpr int QY = TY + (EXT == 3), QX = TX + (EXT == 3), PY = 2 * (TY - 1) + EXT, PX = 2 * (TX - 1) + EXT;
+    constexpr int SUB = QY * QX * 64;                    // bytes of one (y, x)-parity sub-plane
+    constexpr int NPI = (4 * SUB + 1023) / 1024;         // DMA instructions (1 KB wave runs) per plane
+    constexpr int SLOTB = NPI * 1024, KPW = (NPI + 7) / 8, NSLOT = 2 * EXT;
+    constexpr int QB = NSLOT * SLOTB, PB = MP * TV * 64;
+    constexpr int NTAP = EXT * EXT * EXT, TPW = (NTAP + 7) / 8;
+    constexpr int NIP = 4 * TPW;                         // DMA issue points per tile (one per MFMA group)
+    constexpr int DPP = (EXT * KPW + 1 + NIP - 1) / NIP; // DMA instructions per issue point
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WgBlock blk = wg_block(p);
+    const int cpanels = p.Cpad / 32;
+    const int m0 = (blk.panel / cpanels) * 32 * MP, c0 = (blk.panel % cpanels) * 32;
+    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
+    const int chb = (cb + 4 * sq) * 2;
+    const int p_addr = (8 * hk + sj) * 64 + chb;
+    const int q_lane = (hk * QX + sj) * 64 + chb;
+
+    floatx16 acc[TPW][MP];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int a = 0; a < MP; ++a)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][a][j] = 0.f;
+
+    const int t_begin = blk.chunk * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
+    if (t_begin >= t_end) return;
+
+    // DMA lane constants.  Q plane: instruction j = k * 8 + wave covers slab pieces [64 j, 64 j + 64); piece = (position, 16-byte part)
+    int qrel[KPW], qpk[KPW];
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+        const int sidx = (k * 8 + wave) * 64 + lane, pos = sidx >> 2, c8 = sidx & 3;
+        const int par = pos / (QY * QX), rem = pos % (QY * QX), qy = rem / QX, qx = rem % QX;
+        const int py = 2 * qy + (par >> 1), px = 2 * qx + (par & 1);
+        const bool st = k * 8 + wave < NPI && par < 4 && py < PY && px < PX;
+        qrel[k] = st ? ((py * p.Qw + px) * p.ld_q + c8 * 8) * 2 : OOB;
+        qpk[k] = st ? (py | (px << 8) | (c8 << 16)) : -1;
+    }
+    int prel, ppk;
+    {
+        const int sidx = wave * 64 + lane, c8 = sidx & 3, vox = (sidx >> 2) & 63, mp = sidx >> 8;
+        prel = (((vox / TX) * p.Lw + vox % TX) * p.ld_p + mp * 32 + c8 * 8) * 2;
+        ppk = (vox / TX) | ((vox % TX) << 8) | ((mp * 32 + c8 * 8) << 16);
+    }
+    const long qplane = (long)p.Qh * p.Qw * p.ld_q, pplane = (long)p.Lh * p.Lw * p.ld_p;
+
+    struct Tile {
+        const half_t* qorg;    // Q position (2 lz - pad, 2 ly0 - pad, 2 lx0 - pad) of sample n, channel c0
+        const half_t* porg;    // P position (lz, ly0, lx0), channel m0
+        int lz, qv[KPW], pv;
+    };
+    auto prep = [&](int tile) {                                // full decode: first tile of the block / of a column (z runs fastest)
+        Tile t;
+        int r = tile;
+        t.lz = r % p.Ld; r /= p.Ld;
+        const int tx = r % p.tiles_x; r /= p.tiles_x;
+        const int ty = r % p.tiles_y; r /= p.tiles_y;
+        const int n = r;
+        const int ly0 = ty * TY, lx0 = tx * TX;
+        const int iy0 = 2 * ly0 - p.pad_lo, ix0 = 2 * lx0 - p.pad_lo, iz0 = 2 * t.lz - p.pad_lo;
+        t.qorg = p.q + ((((long)n * p.Qd + iz0) * p.Qh + iy0) * p.Qw + ix0) * p.ld_q + c0;
+        t.porg = p.p + ((((long)n * p.Ld + t.lz) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
+        const bool inner = iy0 >= 0 && ix0 >= 0 && iy0 + PY <= p.Qh && ix0 + PX <= p.Qw && c0 + 32 <= p.C;
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+            if (inner) {
+                t.qv[k] = qrel[k];
+            } else {
+                const int iy = iy0 + (qpk[k] & 255), ix = ix0 + ((qpk[k] >> 8) & 255);
+                const bool ok = qpk[k] >= 0 && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw && c0 + (qpk[k] >> 16) * 8 < p.C;
+                t.qv[k] = ok ? qrel[k] : OOB;
+            }
+        }
+        const bool pin = ly0 + TY <= p.Lh && lx0 + TX <= p.Lw && m0 + 32 * MP <= p.M;
+        const bool pok = pin || (ly0 + (ppk & 255) < p.Lh && lx0 + ((ppk >> 8) & 255) < p.Lw && m0 + (ppk >> 16) < p.M);
+        t.pv = pok ? prel : OOB;
+        return t;
+    };
+    auto advance = [&](const Tile& c, int tile_next) {         // next tile: same column -> a few adds (no divisions)
+        if (c.lz + 1 < p.Ld) {
+            Tile t = c;
+            t.lz = c.lz + 1;
+            t.qorg = c.qorg + 2 * qplane;
+            t.porg = c.porg + pplane;
+            return t;
+        }
+        return prep(tile_next);
+    };
+    auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
+    auto dma_q = [&](const Tile& t, int rel, int slot, int k) {    // piece run k of Q plane `rel` (0 .. EXT-1) of tile t -> ring slot
+        if (k * 8 + wave >= NPI) return;
+        const int iz = 2 * t.lz - p.pad_lo + rel;
+        const uint4v rs = wg_rsrc_n(t.qorg + rel * qplane, (unsigned)iz < (unsigned)p.Qd ? 0x7fffffffu : 0u);
+        wg_dma16(rs, lds0 + slot * SLOTB + (k * 8 + wave) * 1024, t.qv[k]);
+    };
+    auto dma_p = [&](const Tile& t, int img) { wg_dma16(wg_rsrc_n(t.porg, 0x7fffffffu), lds0 + QB + img * PB + wave * 1024, t.pv); };
+
+    Tile cur = prep(t_begin);
+    int base = 0, img = 0;
+#pragma unroll
+    for (int rel = 0; rel < EXT; ++rel)
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) dma_q(cur, rel, rel, k);
+    dma_p(cur, 0);
+    wg_wait_all();
+    __syncthreads();
+
+    // per-wave tap constants: tap = wave + 8 ti -> (dz, byte offset inside a plane slab)
+    int tapz[TPW], tapc[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = min(wave + 8 * ti, NTAP - 1);
+        const int dz = EXT == 3 ? tap / 9 : tap >> 2, dy = EXT == 3 ? (tap / 3) % 3 : (tap >> 1) & 1, dx = EXT == 3 ? tap % 3 : tap & 1;
+        tapz[ti] = dz;
+        tapc[ti] = q_lane + ((dy & 1) * 2 + (dx & 1)) * SUB + ((dy >> 1) * QX + (dx >> 1)) * 64;
+    }
+
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool more = tile + 1 < t_end;
+        Tile nxt = cur;
+        if (more) nxt = advance(cur, tile + 1);
+        const bool same_col = more && nxt.lz != 0;          // z runs fastest: the next tile continues this column
+        const int rel0 = same_col ? EXT - 2 : 0;
+        const int nq = more ? (EXT - rel0) * KPW : -1;      // plane DMA instructions of this wave, then one for the P tile
+        const int nbase = wrap(base + (same_col ? 2 : EXT));
+        int tapaddr[TPW];
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) tapaddr[ti] = wrap(base + tapz[ti]) * SLOTB + tapc[ti];
+        const char* const pl = smem + QB + img * PB;
+        // MFMA groups g = (16-voxel chunk, tap slot); the operands of group g + 1 are read from LDS before the MFMAs of group g
+        // are issued (register double buffer), the next tile's DMA instructions go between the groups (spread: issuing them in
+        // one burst at the start of the tile measured 3-8 % slower)
+        constexpr int NG = (TV / 16) * TPW;
+        half8 a[2][MP];
+        half4 bq[2][2];
+        auto rdA = [&](int ch, int buf) {
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp) {
+                const half4 a0 = lds_tr16(pl + mp * TV * 64 + ch * 1024 + p_addr), a1 = lds_tr16(pl + mp * TV * 64 + ch * 1024 + 256 + p_addr);
+                a[buf][mp] = half8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            }
+        };
+        auto rdB = [&](int g, int buf) {
+            const int ch = g / TPW, ti = g % TPW;
+            if (wave + 8 * ti < NTAP) {
+                const char* qa = smem + 2 * ch * QX * 64 + tapaddr[ti];      // chunk rows 2ch, 2ch+1 (+hk in the lane address)
+                bq[buf][0] = lds_tr16(qa);
+                bq[buf][1] = lds_tr16(qa + 256);
+            }
+        };
+        rdA(0, 0);
+        rdB(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int ch = g / TPW, ti = g % TPW;
+            if (g + 1 < NG) {
+                rdB(g + 1, (g + 1) & 1);
+                if ((g + 1) % TPW == 0) rdA((g + 1) / TPW, ((g + 1) / TPW) & 1);
+            }
+            if (wave + 8 * ti < NTAP) {
+                const half4 b0 = bq[g & 1][0], b1 = bq[g & 1][1];
+                const half8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                for (int mp = 0; mp < MP; ++mp) acc[ti][mp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ch & 1][mp], b, acc[ti][mp], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < DPP; ++e) {
+                const int d = g * DPP + e;
+                if (d < nq) dma_q(nxt, rel0 + d / KPW, wrap(nbase + rel0 + d / KPW), d % KPW);
+                else if (d == nq) dma_p(nxt, img ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wg_wait_all();                   // the next tile's planes / P tile are complete ...
+        __syncthreads();                 // ... and every wave is done reading this tile
+        base = nbase;
+        img ^= 1;
+        cur = nxt;
+    }
+    const int c = c0 + (lane & 31);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = wave + 8 * ti;
+        if (tap < NTAP) {
+            const long pbase_ = (long)tap * p.Mpad * p.Cpad;
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp) {
+                if (m0 + mp * 32 >= p.Mpad) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + mp * 32 + 8 * (r >> 2) + 4 * hk + (r & 3);
+                    wg_out(p, blk.chunk, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][mp][r]);
+                }
+            }
+        }
+    }
+}
+
 int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
     constexpr int TZ = 4, TY = 8, TX = 8;
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
@@ -1049,6 +1270,48 @@ int launch_wgrad_s2_v2(hipStream_t s, WgradParams& p, const char* name) {
     return wg_reduce_parts(s, p, chunks, slot_elems, name);
 }
 
+// z-streaming stride-2 gathers (igemm_wgrad_s2s_kernel); LNN_WGRAD_S2S=0 keeps the register-prefetch kernel (A/B measurements)
+template <int EXT>
+int launch_wgrad_s2(hipStream_t s, WgradParams& p, const char* name) {
+    static int s2s = -1;
+    if (s2s < 0) { const char* e = getenv("LNN_WGRAD_S2S"); s2s = (e && e[0] == '0') ? 0 : 1; }
+    constexpr int TY = 8, TX = 8, PY = 2 * (TY - 1) + EXT;
+    // the DMA descriptors address a plane / a P tile with 32-bit byte offsets relative to the tile origin
+    const bool dma_ok = (long)PY * p.Qw * p.ld_q * 2 < 0x7fffffffL && (long)TY * p.Lw * p.ld_p * 2 < 0x7fffffffL;
+    // the level-0 transposed conv (one panel, no plane reuse with EXT = 2) already streams at 4.9 TB/s in the register-prefetch kernel
+    const bool one_panel_ext2 = EXT == 2 && lnn_cdiv(p.Mpad, 64) * (p.Cpad / 32) < 2;
+    if (!s2s || !dma_ok || one_panel_ext2) return launch_wgrad_s2_v2<EXT>(s, p, name);
+    constexpr int QY = TY + (EXT == 3), QX = TX + (EXT == 3), NPI = (4 * QY * QX * 64 + 1023) / 1024;
+    p.tiles_z = p.Ld; p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
+    p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
+    const int panels = lnn_cdiv(p.Mpad, 64) * (p.Cpad / 32);
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    // one 8-wave block per CU: tiles x panels over ~num_cu blocks, whole tiles per block
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, num_cu);
+    if (tpb < 1) tpb = 1;
+    if (tpb > p.tiles_total) tpb = p.tiles_total;
+    p.tiles_per_block = tpb;
+    const size_t lds = (size_t)2 * EXT * NPI * 1024 + (size_t)2 * 2 * 64 * 64;
+    auto kern = igemm_wgrad_s2s_kernel<EXT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const unsigned chunks = (unsigned)lnn_cdiv(p.tiles_total, tpb);
+    const dim3 grid = wg_grid(p, chunks, (unsigned)panels);
+    const long slot_elems = (long)(EXT * EXT * EXT) * p.Mpad * p.Cpad;
+    if (int e = wg_prepare_parts(p, chunks, 1, slot_elems, name)) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+    LNN_CHECK_LAUNCH(name);
+    return wg_reduce_parts(s, p, chunks, slot_elems, name);
+}
+
 int check_act_w(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -1135,7 +1398,7 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
         if (!use_v2 && dma_ok) return launch_wgrad_s1_v5(s, p);
         return launch_wgrad_s1_v2(s, p);
     }
-    return launch_wgrad_s2_v2<3>(s, p, "lnn_conv3d_wgrad(s2,v2)");
+    return launch_wgrad_s2<3>(s, p, "lnn_conv3d_wgrad(s2)");
 }
 }  // namespace
 
@@ -1205,6 +1468,6 @@ int convT3d_k2s2_wgrad_impl(lnn_stream_t s_, const void* x, int ld_x, const void
     p.parts = parts; p.parts_elems = parts_elems;
     p.N = N; p.Ld = D; p.Lh = H; p.Lw = W; p.Qd = 2 * D; p.Qh = 2 * H; p.Qw = 2 * W;
     p.M = C; p.C = K; p.Mpad = lnn_round_up(C, 32); p.Cpad = lnn_round_up(K, 32); p.pad_lo = 0;
-    return launch_wgrad_s2_v2<2>(s, p, "lnn_convT3d_k2s2_wgrad(v2)");
+    return launch_wgrad_s2<2>(s, p, "lnn_convT3d_k2s2_wgrad");
 }
 }  // namespace

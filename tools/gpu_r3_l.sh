@@ -8,4 +8,4 @@ timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-rooflin
 d2=/tmp/prof2_$TAG; rm -rf $d2
 (cd /tmp && LNN_NO_WGRAD_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace -d $d2 -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --other-workloads none > $OUT/prof2_bench.json 2> $OUT/prof2.err)
 python tools/rocpd_stats.py $(find $d2 -name "*.db" | head -1) > $OUT/kernel_stats_serialized.txt 2>&1
-grep -E "sums_kernel|finalize|in_stats_kernel|gradnorm|pack" $OUT/kernel_stats_serialized.txt | cut -c1-170
+grep -E "sums_kernel|finalize|in_stats_kernel|gradnorm|pack|up2|c1_" $OUT/kernel_stats_serialized.txt | cut -c1-170
