@@ -518,7 +518,8 @@ def main():
         traffic, traffic_note = None, None
         try:      # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 runs)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
-            traffic, traffic_note = tj["kernels"][dom_key]["hbm_bytes_per_launch_corrected"], "profiles/r03_pmc_traffic.json: " + tj["note"]
+            short = {"igemm_conv_fwd": "fwd", "igemm_conv_dgrad": "dgrad", "igemm_wgrad": "wgrad"}.get(dom_key, dom_key)
+            traffic, traffic_note = tj["kernels"][short]["hbm_bytes_per_launch_corrected"], "profiles/r03_pmc_traffic.json: " + tj["note"]
         except Exception:
             pass
         clock = None
