@@ -713,7 +713,6 @@ __device__ __forceinline__ uint4v wg_rsrc_n(const void* base, unsigned num_recor
     return r;
 }
 
-template <int STEP>
 __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradParams p) {
     constexpr int TZ = 4, TY = 8, TX = 8, PY = 10, PX = 10, PP = PY * PX, TPW = 7, NT = 512;
     constexpr int SLOTB = 7 * 1024, NSLOT = 12, QB = NSLOT * SLOTB, PB = 2 * NT * 16;
@@ -855,6 +854,8 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
         const bool more = tile + 1 < t_end;
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (timed) t0 = __builtin_readcyclecounter();
+        // (moving this decode behind the first MFMA group -- round 3 -- moved its 320 cycles into the MFMA phase and changed nothing:
+        // the loop is bound by the wave's own instruction stream, not by the shared matrix pipe)
         Tile nxt = cur;
         if (more) nxt = advance(cur, tile + 1);
         const bool same_col = nxt.tz != 0;                  // z runs fastest: the next tile continues this column
@@ -886,8 +887,8 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
             if (g + 2 < 3 * NCH) rdG(g + 2);
             if (k == 1 && ch + 1 < NCH) rdA(ch + 1);
             if (g == 12) addr_for(nbase, img ^ 1, qaddr_n, pa_n);     // next tile's addresses, off the critical path
-            if (g % STEP == STEP - 1 && g / STEP < 8) {     // 8 DMA issue points, every STEP-th group
-                const int i = g / STEP;
+            if (g % 2 == 1 && g / 2 < 8) {                  // 8 DMA issue points, every second group (every group: +-0, round 2)
+                const int i = g / 2;
                 if (i < 6) {
                     if (i < nin) dma_q(nxt, rel0 + i, wrap(wrap(base + 6 + i)));
                 } else if (more) {
@@ -1179,8 +1180,7 @@ int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
         int dev = 0;
         hipDeviceProp_t prop;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     static int dbg4 = -1;
     static unsigned long long* dbgbuf4 = nullptr;
@@ -1189,8 +1189,6 @@ int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
         const char* b = getenv("LNN_WGRAD_PHASEBUF"); if ((dbg4 & 4) && b) dbgbuf4 = (unsigned long long*)strtoull(b, nullptr, 0);
     }
     p.debug = dbg4; p.dbgbuf = dbgbuf4;
-    static int step = 0;
-    if (!step) { const char* e = getenv("LNN_WGRAD_V4_STEP"); step = e ? atoi(e) : 2; if (step < 1 || step > 2) step = 2; }
     // one block per CU: spread tiles x panels over ~num_cu blocks, >= 1 tile per block
     int tpb = lnn_cdiv((long)p.tiles_total * panels, num_cu);
     if (tpb < 1) tpb = 1;
@@ -1200,8 +1198,7 @@ int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
     const dim3 grid = wg_grid(p, chunks, (unsigned)panels);
     const long slot_elems = 27L * p.Mpad * p.Cpad;
     if (int e = wg_prepare_parts(p, chunks, 2, slot_elems, "lnn_conv3d_wgrad(s1)")) return e;       // writers: the two tile halves
-    if (step == 1) hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<1>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
-    else hipLaunchKernelGGL((igemm_wgrad_s1_v5_kernel<2>), grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
+    hipLaunchKernelGGL(igemm_wgrad_s1_v5_kernel, grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
     LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v5)");
     return wg_reduce_parts(s, p, chunks, slot_elems, "lnn_conv3d_wgrad(s1,v5,reduce)");
 }
