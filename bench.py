@@ -439,7 +439,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.probe = None
     probe_ser = None
-    if probe is not None:
+    if probe is not None and world == 1:      # extra steps on ONE rank would issue gradient all-reduces nobody answers
         # the same bracketing with the weight gradients on the MAIN stream (the default plan runs them on a side stream next
         # to the data gradients: two MFMA-bound kernels then share the chip and each one's own duration says little)
         probe_ser = {"layer": probe["layer"]}
@@ -503,7 +503,7 @@ def main():
                  "igemm_wgrad": "igemm_wgrad_s1_v5_kernel (stride-1 weight gradient; the rocprof top row of the step)"}
         fams = {}
         for kind, key in fam.items():
-            evs, evs2 = probe_ser.get(kind, []), probe.get(kind, [])
+            evs, evs2 = (probe_ser or {}).get(kind, []), probe.get(kind, [])
             iso = kr["kernels"][key]
             ms_in = sum(a_.elapsed_time(b_) for a_, b_ in evs) / len(evs) if evs else None
             ms_two = sum(a_.elapsed_time(b_) for a_, b_ in evs2) / len(evs2) if evs2 else None
