@@ -44,6 +44,8 @@ CONV_CASES = [
     (2, 32, 64, 8, 16, 8, 2),
     (1, 16, 32, 7, 9, 11, 2),
     (1, 64, 128, 6, 6, 6, 2),
+    (1, 32, 64, 2, 12, 20, 2),      # one output plane: every tile of the z-streaming stride-2 kernels starts a new column
+    (2, 64, 64, 9, 17, 5, 2),       # odd extents, two channel panels, ragged tiles in every dimension
 ]
 
 
@@ -120,7 +122,7 @@ def test_conv3d_first_layer(N, K, D, H, W):
     assert rel_err(dw.cpu(), w.grad) < 1e-3
 
 
-CONVT_CASES = [(2, 64, 32, 4, 8, 4), (1, 16, 8, 3, 5, 6), (1, 320, 320, 2, 3, 2), (1, 32, 64, 4, 8, 8)]
+CONVT_CASES = [(2, 64, 32, 4, 8, 4), (1, 16, 8, 3, 5, 6), (1, 320, 320, 2, 3, 2), (1, 32, 64, 4, 8, 8), (1, 64, 64, 1, 5, 9), (2, 128, 64, 5, 3, 11)]
 
 
 @pytest.mark.parametrize("N,C,K,D,H,W", CONVT_CASES)
