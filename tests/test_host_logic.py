@@ -342,6 +342,36 @@ def test_preprocessed_data_loader(tmp_path):
     assert set(next(prov("Task900_Toy", "val", plans))["keys"]) <= set(val)
 
 
+def test_evaluator_matches_the_reference_function_executed_on_recorded_volumes(golden_dir):
+    """tests/golden/evaluator_reference.*: ``compute_scores_and_build_dict`` of nnunet_ext/evaluation/evaluator2.py:60-109 EXECUTED
+    (oracle/make_goldens_evaluator.py) on seeded volumes -- random errors, a class absent from both volumes (None), a class that
+    is only predicted (0.0), a perfect case, validation-only and validation + training case lists.  Both the oracle restatement and
+    the product module must reproduce every number."""
+    import json
+    from oracle import evaluation as oev
+    from lifelong_nnunet_amd.evaluation import compute_scores_and_build_dict
+    arr = np.load(golden_dir + "/evaluator_reference.npz")
+    meta = json.load(open(golden_dir + "/evaluator_reference.json"))
+    K = meta["num_classes"]
+    for key, names in (("validation_only", meta["splits"]["val"]), ("include_training_data", meta["splits"]["val"] + meta["splits"]["train"])):
+        ref = meta["results"][key]
+        assert list(ref) == names                                           # the reference's case order: val first, then train
+        cases = {n: (arr["out::" + n], arr["tgt::" + n]) for n in names}
+        got = compute_scores_and_build_dict(cases, K)
+        assert list(got) == names
+        for n in names:
+            orc = oev.case_scores(*cases[n], K)
+            assert list(got[n]) == list(ref[n]) == list(orc) == [f"mask_{c}" for c in range(1, K + 1)]
+            for m in ref[n]:
+                for metric in ("IoU", "Dice"):
+                    r = ref[n][m][metric]
+                    for val in (got[n][m][metric], orc[m][metric]):
+                        assert (r is None and val is None) or (r is not None and val is not None and abs(val - r) <= 1e-12), (n, m, metric, r, val)
+    assert meta["results"]["validation_only"]["case_b"]["mask_3"] == {"IoU": None, "Dice": None}
+    assert meta["results"]["validation_only"]["case_c"]["mask_2"] == {"IoU": 0.0, "Dice": 0.0}
+    assert meta["results"]["validation_only"]["case_d"]["mask_1"] == {"IoU": 1.0, "Dice": 1.0}
+
+
 def test_evaluator_summary_matches_the_reference_arithmetic():
     """lifelong-nnunet_amd/evaluation.py against the reference's own scikit-learn call (evaluator2.py:88-107, restated in
     oracle/evaluation.py): random label volumes, a class absent from both volumes (-> None), a class only predicted."""
