@@ -46,16 +46,29 @@ class MultiHead_Module(nn.Module):
         assert isinstance(split_at, str), "The provided split needs to be a string.."
         self.split = [x.strip() for x in split_at.split('.')]
         names = [n for n, _ in self.model.named_parameters()]
-        self._check_and_simplify_split(names)
+        self._check_and_simplify_split()
         self.heads = nn.ModuleDict()
         assert isinstance(task, (str, int)), "The provided task needs to be an integer (ID) or string, not {}..".format(type(task))
         self.active_task = task
 
-        # everything at or after the split point in registration (pre-order) order is the head
-        prefix = '.'.join(self.split) + '.'
-        first = next(i for i, n in enumerate(names) if n.startswith(prefix))
+        # everything at or after the split MODULE in registration (pre-order) order is the head; the position is taken from the
+        # module tree, so a split at a parameter-less module (``td`` with convolutional pooling: the reference accepts it) works
+        path, first, seen = '.'.join(self.split), None, 0
+        for mod_name, mod in self.model.named_modules():
+            if mod_name == path:
+                first = seen
+                break
+            seen += len(mod._parameters)
+        assert first is not None, "The provided split path '{}' does not exist..".format(path)
         assert first > 0, "You tried to split before the first layer, so the body would be empty --> body can never be empty.."
-        self._body_names, self._head_names = names[:first], names[first:]
+        self._head_names = names[first:]
+        # Reference behaviour, reproduced (tests/golden/multihead_splits_reference.json, produced by the reference class): for a
+        # NESTED split ('tu.1', 'conv_blocks_context.2', ...) the body keeps the WHOLE top-level container the split lies in --
+        # the container object is shared with the running model, so MHM.py:254-262 cannot take the head-side members out of it.
+        # They are then both body (shared tensors, ``body.*`` state-dict keys, frozen by ``freeze_body``) and head (per-task
+        # copies that ``assemble_model`` writes back).  Top-level splits ('seg_outputs', 'tu') have no such overlap.
+        top = self.split[0] + '.'
+        self._body_names = [n for i, n in enumerate(names) if i < first or (len(self.split) > 1 and n.startswith(top))]
         params = dict(self.model.named_parameters())
         self.body = nn.Module()
         for n in self._body_names:
@@ -68,19 +81,28 @@ class MultiHead_Module(nn.Module):
         self.body_freezed = False
 
     # ------------------------------------------------------------------------------------------ split
-    def _check_and_simplify_split(self, names):
-        def exists(path):
-            pre = '.'.join(path) + '.'
-            return any(n.startswith(pre) for n in names)
-        assert exists(self.split), "The provided split path '{}' does not exist..".format('.'.join(self.split))
+    def _check_and_simplify_split(self):
+        from operator import attrgetter
+
+        def module_at(path):
+            try:
+                m = attrgetter('.'.join(path))(self.model)
+            except AttributeError:
+                return None
+            return m if isinstance(m, nn.Module) else None
+        assert len(self.split) > 0 and self.split != [''] and module_at(self.split) is not None, \
+            "The provided split path '{}' does not exist..".format('.'.join(self.split))
         # MHM.py:73-92: drop trailing components that name the FIRST child of their parent
+        full = self.split[:]
         while len(self.split) > 1:
-            parent = '.'.join(self.split[:-1]) + '.'
-            first_child = next(n for n in names if n.startswith(parent))[len(parent):].split('.')[0]
+            first_child = next(module_at(self.split[:-1]).named_children())[0]
             if self.split[-1] == first_child:
                 self.split = self.split[:-1]
             else:
                 break
+        first_top = next(self.model.named_children())[0]
+        assert not (len(self.split) == 1 and self.split[0] == first_top), \
+            "The provided split '{}' is empty after simplification and would split before the first layer..".format('.'.join(full))
 
     def get_split_path(self):
         return '.'.join(self.split)

@@ -128,6 +128,38 @@ def test_multihead_module_matches_reference_naming_and_semantics(golden_dir):
     assert [n for n, _ in mh3.heads["t"].named_parameters()] == ["tu.0.weight", "tu.1.weight", "seg_outputs.0.weight", "seg_outputs.1.weight"]
 
 
+def test_multihead_splits_match_the_reference(golden_dir):
+    """tests/golden/multihead_splits_reference.json: the reference's ``MultiHead_Module`` CONSTRUCTED (oracle/make_goldens_splits.py)
+    with 24 ``split_at`` strings -- top-level and nested paths, paths that simplify (``tu.0`` -> ``tu``), a parameter-less module
+    (``td``), whitespace, paths before the first layer and paths that do not exist.  The product must agree on: refusal
+    (AssertionError), the normalised split, the ``state_dict()`` key list in order, body and head parameter names.  That includes the
+    reference's behaviour for NESTED splits: the body keeps the whole top-level container of the split, so its head-side members
+    are body AND head."""
+    g = json.load(open(f"{golden_dir}/multihead_splits_reference.json"))
+    assert len(g["splits"]) == 24
+    for sp, r in g["splits"].items():
+        if "raises" in r:
+            assert r["raises"] == "AssertionError", (sp, r)
+            with pytest.raises(AssertionError):
+                MultiHead_Module(Generic_UNet, sp, "taskA", None, *g["ctor"], device="cpu")
+            continue
+        mh = MultiHead_Module(Generic_UNet, sp, "taskA", None, *g["ctor"], device="cpu")
+        mh.add_new_task("taskB", use_init=True)
+        assert mh.get_split_path() == r["split"], sp
+        assert list(mh.state_dict().keys()) == r["state_dict_keys"], sp
+        assert [n for n, _ in mh.body.named_parameters()] == r["body_param_names"], sp
+        assert [n for n, _ in mh.heads["taskA"].named_parameters()] == r["head_param_names"], sp
+        assert [n for n, _ in mh.model.named_parameters()] == r["model_param_names"], sp
+        # body tensors are the running model's own, head tensors are copies -- also where a nested split makes a tensor both
+        body, model = dict(mh.body.named_parameters()), dict(mh.model.named_parameters())
+        assert all(body[n] is model[n] for n in body), sp
+        assert all(p is not model[n] for n, p in mh.heads["taskA"].named_parameters()), sp
+        mh.assemble_model("taskB", freeze_body=True)         # MHM.py:379-395: every body NAME is frozen in the running model
+        assert all(model[n].requires_grad == (n not in body) for n in model), sp
+    nested = g["splits"]["tu.1"]
+    assert "tu.1.weight" in nested["body_param_names"] and "tu.1.weight" in nested["head_param_names"]
+
+
 def test_trainer_plugin_surface():
     for ext, cls_name, hp in (("sequential", "nnUNetTrainerSequential", {}), ("ewc", "nnUNetTrainerEWC", {"ewc_lambda": float}),
                               ("lwf", "nnUNetTrainerLWF", {"lwf_temperature": float}),
