@@ -3,7 +3,7 @@
 Mirrors nnunet_ext/network_architecture/MultiHead_Module.py:
   constructor / split path handling :16-125, ``forward`` :127-137, ``update_after_iteration`` :139-157,
   ``assemble_model`` :326-377, ``_set_requires_grad`` :379-395, ``add_new_task`` :435-458,
-  ``add_n_tasks_and_activate`` :460-485.
+  ``add_n_tasks_and_activate`` :460-485, getters / setters / ``replace_layers`` :488-572.
 Semantics kept: body parameters are SHARED tensors with the running model, head parameters are
 per-task copies; the head of the active task is refreshed from the running model after every training
 iteration.  What is dropped is the cost: the reference re-splits the module tree and ``deepcopy``s the
@@ -13,6 +13,7 @@ tensors (2 400 floats for the 5-level U-Net).
 """
 from __future__ import annotations
 
+import copy
 from collections import OrderedDict
 from typing import Type
 
@@ -69,10 +70,7 @@ class MultiHead_Module(nn.Module):
         # copies that ``assemble_model`` writes back).  Top-level splits ('seg_outputs', 'tu') have no such overlap.
         top = self.split[0] + '.'
         self._body_names = [n for i, n in enumerate(names) if i < first or (len(self.split) > 1 and n.startswith(top))]
-        params = dict(self.model.named_parameters())
-        self.body = nn.Module()
-        for n in self._body_names:
-            _set_nested(self.body, n, params[n])          # the SAME Parameter objects as the running model
+        self._share_body()
         init_module = self._head_from_model()
         self.state_init = OrderedDict((k, v.clone()) for k, v in init_module.state_dict().items())
         self.heads[str(task)] = init_module
@@ -107,6 +105,15 @@ class MultiHead_Module(nn.Module):
     def get_split_path(self):
         return '.'.join(self.split)
 
+    def _share_body(self):
+        """``self.body`` = the body parameters of the running model: the SAME Parameter objects (MHM.py:108: the split hands the
+        model's own modules to the body)."""
+        params = dict(self.model.named_parameters())
+        self.body = nn.Module()
+        for n in self._body_names:
+            _set_nested(self.body, n, params[n])
+        self._body_detached = False
+
     def _head_from_model(self):
         params = dict(self.model.named_parameters())
         head = nn.Module()
@@ -121,6 +128,8 @@ class MultiHead_Module(nn.Module):
     def update_after_iteration(self, model=None, update_body=True):
         """Refresh the active task's head from the running model (body tensors are shared already)."""
         model = self.model if model is None else model
+        if update_body and self._body_detached:
+            self._share_body()          # MHM.py:152-153: the body is re-split from the running model, a body given to set_body is dropped
         src = dict(model.named_parameters())
         with torch.no_grad():
             for n, p in self.heads[str(self.active_task)].named_parameters():
@@ -134,6 +143,11 @@ class MultiHead_Module(nn.Module):
                 task, list(self.heads.keys()))
         dst = dict(self.model.named_parameters())
         with torch.no_grad():
+            if self._body_detached:     # a body given to set_body reaches the running model here (MHM.py:343-359), then is shared again
+                for n, p in self.body.named_parameters():
+                    if n in dst:
+                        dst[n].copy_(p)
+                self._share_body()
             for n, p in self.heads[str(task)].named_parameters():
                 dst[n].copy_(p)
         if hasattr(self.model, "mark_params_changed"):
@@ -177,6 +191,47 @@ class MultiHead_Module(nn.Module):
                 if task not in [str(t) for t in list_of_tasks]:
                     del self.heads[task]
         self.assemble_model(activate_with)
+
+    # ------------------------------------------------------------------------------------------ getters / setters (MHM.py:488-572)
+    def get_heads(self):
+        """A deep copy of the ModuleDict of heads (MHM.py:488-493)."""
+        return copy.deepcopy(self.heads)
+
+    def get_body(self):
+        """A deep copy of the body (MHM.py:495-500): independent tensors, not the running model's."""
+        return copy.deepcopy(self.body)
+
+    def set_heads(self, heads, reset=True):
+        """Replace (``reset=True``) or update the ModuleDict of heads (MHM.py:502-517); the running model is untouched until the next
+        ``assemble_model``."""
+        assert isinstance(heads, nn.ModuleDict), "Provided heads are not a nn.ModuleDict."
+        if reset:
+            del self.heads
+            self.heads = heads
+        else:
+            self.heads.update(heads)
+
+    def set_body(self, body):
+        """Replace the body by a COPY of ``body`` (MHM.py:519-528).  As in the reference the running model only takes these values at
+        the next ``assemble_model`` that does not return early; ``update_after_iteration(update_body=True)`` re-derives the body from
+        the running model and drops them."""
+        assert isinstance(body, nn.Module), "Provided body is not a nn.Module.."
+        del self.body
+        self.body = copy.deepcopy(body)
+        self._body_detached = True
+
+    def replace_layers(self, model, old, new):
+        """Every child of ``model`` (recursively) that is an instance of ``old`` is replaced by ``new`` (MHM.py:544-572).  The heads
+        and the body of THIS class hold bare parameters (the convolutions run in the HIP engine, not in ``nn.Conv3d`` modules), so the
+        method is only meaningful for modules the caller brings."""
+        assert model is not None and new is not None and old is not None, \
+            "To replace a Module, the layers need to be Modules as well as the model.."
+        for name, module in model.named_children():
+            if len(list(module.children())) > 0:
+                self.replace_layers(module, old, new)
+            if isinstance(module, old):
+                setattr(model, name, new)
+        return model
 
     def head_weights(self, task):
         """seg-head tensors of ``task`` in engine order (used for multi-head evaluation on one body pass).  Only valid when

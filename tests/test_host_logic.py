@@ -160,6 +160,34 @@ def test_multihead_splits_match_the_reference(golden_dir):
     assert "tu.1.weight" in nested["body_param_names"] and "tu.1.weight" in nested["head_param_names"]
 
 
+def test_multihead_flow_matches_the_reference(golden_dir):
+    """tests/golden/multihead_flow_reference.json: a 12-step script -- deterministic parameters, update_after_iteration (with and without
+    the body), add_new_task, assemble_model incl. its early return and body freezing, get_body / set_body (the running model only sees a
+    new body at the next assemble_model that does not return early; update_after_iteration drops it), get_heads / set_heads (update and
+    reset) -- EXECUTED on the reference's ``MultiHead_Module`` (oracle/make_goldens_mh_flow.py) for the two top-level splits
+    ``seg_outputs`` and ``tu``; the same script through the product must leave the same tensors in the running model, the body and every
+    head, the same ``requires_grad`` flags, active task and ``body_freezed`` after every step."""
+    from oracle.make_goldens_mh_flow import script
+    g = json.load(open(f"{golden_dir}/multihead_flow_reference.json"))
+    close = lambda a, b: abs(a - b) <= 1e-6 * max(1.0, abs(b))
+    for sp, steps in g["flows"].items():
+        mh = MultiHead_Module(Generic_UNet, sp, "A", None, *g["ctor"], device="cpu")
+        seen = []
+        for name, snap in script(mh):
+            ref = steps[name]
+            seen.append(name)
+            for part in ("model", "body"):
+                assert list(snap[part]) == list(ref[part]), (sp, name, part)
+                assert all(close(snap[part][n], ref[part][n]) for n in ref[part]), (sp, name, part)
+            assert list(snap["heads"]) == list(ref["heads"]), (sp, name)
+            for t in ref["heads"]:
+                assert list(snap["heads"][t]) == list(ref["heads"][t]), (sp, name, t)
+                assert all(close(snap["heads"][t][n], ref["heads"][t][n]) for n in ref["heads"][t]), (sp, name, t)
+            assert snap["requires_grad"] == ref["requires_grad"], (sp, name)
+            assert snap["active_task"] == ref["active_task"] and snap["body_freezed"] == ref["body_freezed"], (sp, name)
+        assert seen == list(steps) and len(seen) == 12
+
+
 def test_trainer_plugin_surface():
     for ext, cls_name, hp in (("sequential", "nnUNetTrainerSequential", {}), ("ewc", "nnUNetTrainerEWC", {"ewc_lambda": float}),
                               ("lwf", "nnUNetTrainerLWF", {"lwf_temperature": float}),
