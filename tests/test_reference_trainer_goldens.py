@@ -308,3 +308,27 @@ def test_oracle_lwf_flow_equals_reference(ref):
     assert gB.n == f["batches_consumed_B"] == 12
     assert np.allclose(lB, f["lossesB"], rtol=1e-5), (lB, f["lossesB"])
     _check(arr, "lwf::final_theta", dict(net.named_parameters()), names, 7, 1e-6)
+
+
+def test_oracle_forward_wiring_matches_the_reference_forward_lines(golden_dir):
+    """tests/golden/forward_wiring_reference.npz: ``Generic_ViT_UNet.forward`` of the reference (generic_ViT_UNet.py:216-284 -- upstream's
+    U-Net forward "copied from original implementation" around the transformer) called unbound on the oracle network with the
+    transformer stood in by the identity (oracle/make_goldens_forward.py).  The oracle's own ``forward`` must return the same tensors
+    bit for bit: skip indexing, ``cat((x, skip), 1)`` order, decoder level -> segmentation layer, order of the deep-supervision tuple,
+    and the single-output mode."""
+    d = np.load(golden_dir + "/forward_wiring_reference.npz")
+    net = OracleGenericUNet(*[int(v) for v in d["ctor"]])
+    net.load_state_dict({k[4:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd::")})
+    net.eval()
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        out = net(x)
+        net.do_ds = False
+        single = net(x)
+    n_levels = int(d["ctor"][3])
+    assert isinstance(out, tuple) and len(out) == n_levels
+    for i in range(n_levels):
+        ref = torch.from_numpy(d[f"ref_ds_{i}"])
+        assert out[i].shape == ref.shape and float((out[i] - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), i
+    assert float((single - torch.from_numpy(d["ref_single"])).abs().max()) <= 1e-6 * float(single.abs().max())
+    assert [tuple(o.shape[2:]) for o in out] == [(8, 16, 8), (4, 8, 4), (2, 4, 2)]      # full resolution first
