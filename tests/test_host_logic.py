@@ -188,6 +188,42 @@ def test_multihead_flow_matches_the_reference(golden_dir):
         assert seen == list(steps) and len(seen) == 12
 
 
+def test_network_configuration_matches_the_reference(golden_dir):
+    """tests/golden/network_config_reference.json: the constructor arguments the reference's ``initialize_network``
+    (nnViTUNetTrainer.py:97-122) EXECUTED with a recording network class produces.  The oracle network and the product's constants must
+    be that configuration: Conv3d / InstanceNorm3d(eps 1e-5, affine) / no dropout / LeakyReLU(1e-2), deep supervision, identity final
+    nonlinearity, He initialisation with a = 1e-2, convolutional pooling and upsampling, no logits upscaling, feature doubling capped at
+    320, two convs per stage."""
+    from torch import nn
+    from oracle.unet import OracleGenericUNet
+    from lifelong_nnunet_amd import engine
+    c = json.load(open(f"{golden_dir}/network_config_reference.json"))
+    assert c["conv_op"].endswith("Conv3d") and c["norm_op"].endswith("InstanceNorm3d") and c["nonlin"].endswith("LeakyReLU")
+    assert c["norm_op_kwargs"] == {"eps": 1e-5, "affine": True} and c["dropout_op_kwargs"]["p"] == 0
+    assert c["nonlin_kwargs"]["negative_slope"] == 1e-2 and c["he_init_neg_slope"] == 1e-2
+    assert c["deep_supervision"] is True and c["dropout_in_localization"] is False and c["upscale_logits"] is False
+    assert c["convolutional_pooling"] is True and c["convolutional_upsampling"] is True
+    assert c["final_nonlin_of_probe"] == [-2.0, 0.5] and c["num_conv_per_stage"] == 2 and c["feat_map_mul_on_downscale"] == 2
+    # product constants
+    assert engine.LRELU_SLOPE == c["nonlin_kwargs"]["negative_slope"] and engine.IN_EPS == c["norm_op_kwargs"]["eps"]
+    # oracle network built with the same arguments
+    net = OracleGenericUNet(c["input_channels"], 4, c["num_classes"], 3, conv_per_stage=c["num_conv_per_stage"])
+    norms = [m for m in net.modules() if isinstance(m, nn.InstanceNorm3d)]
+    acts = [m for m in net.modules() if isinstance(m, nn.LeakyReLU)]
+    assert norms and all(m.eps == 1e-5 and m.affine for m in norms) and acts and all(m.negative_slope == 1e-2 for m in acts)
+    assert not any(isinstance(m, (nn.Dropout3d, nn.Dropout, nn.MaxPool3d, nn.Upsample)) for m in net.modules())
+    convs = [m for m in net.modules() if isinstance(m, nn.Conv3d) and m.kernel_size == (3, 3, 3)]
+    assert all(m.padding == (1, 1, 1) for m in convs) and {m.stride for m in convs} == {(1, 1, 1), (2, 2, 2)}      # convolutional pooling
+    assert len(net.td) == 0 and all(isinstance(m, nn.ConvTranspose3d) and m.kernel_size == (2, 2, 2) and m.stride == (2, 2, 2)
+                                    and m.bias is None for m in net.tu)                                           # convolutional upsampling
+    assert net._deep_supervision and net.do_ds and len(net.seg_outputs) == 3
+    assert all(m.kernel_size == (1, 1, 1) and m.bias is None for m in net.seg_outputs)
+    # the product network has the same parameters (names, shapes) as the oracle network built from that configuration
+    prod = Generic_UNet(c["input_channels"], 4, c["num_classes"], 3, device="cpu")
+    assert [(n, tuple(p.shape)) for n, p in prod.named_parameters()] == [(n, tuple(p.shape)) for n, p in net.named_parameters()]
+    assert [ch for ch in (c["base_num_features"] * 2 ** d for d in range(6))][:3] == [32, 64, 128] and OracleGenericUNet.MAX_FEATURES_3D == 320
+
+
 def test_trainer_plugin_surface():
     for ext, cls_name, hp in (("sequential", "nnUNetTrainerSequential", {}), ("ewc", "nnUNetTrainerEWC", {"ewc_lambda": float}),
                               ("lwf", "nnUNetTrainerLWF", {"lwf_temperature": float}),
