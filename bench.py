@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 PEAK_MFMA_F16_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level table)
 
 _C2 = {"patch_size": (160, 192, 160), "batch_size": 2, "num_pool": 5, "base_num_features": 32,
-       "num_classes": 3, "num_input_channels": 1, "synthetic_period": 1}
+       "num_classes": 3, "num_input_channels": 1, "synthetic_period": 2}
 WORKLOADS = {       # BASELINE.json configs[...]: (plans, trainer extension, description)
     "c2": (_C2, "sequential", "BASELINE configs[1]: nnUNetTrainerSequential.run_iteration"),
     "c1": ({**_C2, "patch_size": (40, 56, 40), "num_pool": 3}, "sequential", "BASELINE configs[0] shapes on the GPU (plumbing size)"),
@@ -161,6 +161,25 @@ def library_gemm_reference(n=8192, iters=20):
     return {"what": "torch.matmul fp16 %d^3 (hipBLASLt), same box, same run" % n, "tflops": tf, "frac_of_peak": tf / PEAK_MFMA_F16_TFLOPS}
 
 
+def so_sha256():
+    import hashlib
+    from lifelong_nnunet_amd import native as nat
+    return hashlib.sha256(open(nat.LIB_PATH, "rb").read()).hexdigest()
+
+
+def committed_pmc(suffix, so_sha):
+    """(file name, content) of the newest profiles/rNN_<suffix> collected with the library that is loaded now, else None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        if j.get("so_sha256") == so_sha:
+            return os.path.basename(path), j
+    return None
+
+
 def regulariser_rooflines(trainer, plans):
     """HIP-event timing of the HBM-bound regulariser / optimiser kernels at this workload's sizes (P = flat arena size;
     logits of the full-resolution level), algorithmic bytes as SURVEY.md 8(d) counts them, against the 8 TB/s HBM peak."""
@@ -216,7 +235,8 @@ def cpu_baseline_and_parity(tr, plans, flops_full, batch, sample="full"):
     from oracle import losses as olosses, train as otrain
     from oracle.unet import OracleGenericUNet
     from lifelong_nnunet_amd.synthetic import make_patch_batch
-    cores = min(os.cpu_count() or 1, 32)     # oneDNN conv3d stops scaling (and thrashes) far below 256 threads
+    cores_present = os.cpu_count() or 1
+    cores = min(cores_present, 32)           # oneDNN conv3d stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(cores)
     K, npool = plans["num_classes"], plans["num_pool"]
     data = batch["data"][:1].float().cpu()
@@ -279,11 +299,57 @@ def cpu_baseline_and_parity(tr, plans, flops_full, batch, sample="full"):
                 break
     except OSError:
         pass
-    base = {"value": ratio / dt, "unit": "patches/s", "cores": cores, "kind": "port", "extrapolated": sample != "full", "cpu": cpu_name,
+    base = {"value": ratio / dt, "unit": "patches/s", "cores": cores, "cores_used": cores, "cores_present": cores_present,
+            "kind": "port", "extrapolated": sample != "full", "cpu": cpu_name,
             "sample": f"oracle.train.run_iteration (forward, Dice+CE, backward, clip, SGD), same {npool}-level U-Net, ONE "
                       f"{'x'.join(map(str, shape))} patch (B=1) in {dt:.1f} s" + ("" if sample == "full" else f", scaled by the voxel ratio {ratio:.4f}"),
             "gflops": flops_full * ratio / dt / 1e9}
     return base, parity
+
+
+def regulariser_parity(tr, ext):
+    """Bench-size parity gate of the continual-learning term of c3 / c4 / c5 (relative loss error <= 1e-4
+    beside the timing): the HIP value on the trainer's OWN state against the oracle's CPU restatement on the same numbers.
+      ewc / rehearsal_ewc: penalty lambda/2 sum F (theta - theta*)^2 over all P parameters and the norm of its gradient
+                           (deep_supervision.py:58-83) -- lnn_ewc_penalty_fwd / _bwd vs oracle.losses.ewc_penalty + autograd;
+      lwf:                 batchmean KL at temperature T of one full-size logits pair (deep_supervision.py:194-196) --
+                           lnn_kl_logits vs oracle.losses.lwf_distillation."""
+    import torch
+    from oracle import losses as ol
+    if ext in ("ewc", "rehearsal_ewc"):
+        named = list(tr.network.named_parameters())
+        arena = tr.network.arena
+        keep = arena.grad.clone()
+        arena.grad.zero_()
+        tr.loss.update_network_params(iter(named))
+        pen = tr.loss._regulariser(tr.loss.ewc_lambda)
+        pen.backward()
+        torch.cuda.synchronize()
+        v_hip, g_hip = float(pen), float(arena.grad.double().norm())
+        arena.grad.copy_(keep)
+        tr.loss.update_network_params(tr.network.named_parameters())
+        cpu = [(n, p.detach().cpu().clone().requires_grad_(True)) for n, p in named]
+        fisher = {t: {n: v.detach().float().cpu() for n, v in d.items()} for t, d in tr.fisher.items()}
+        stars = {t: {n: v.detach().float().cpu() for n, v in d.items()} for t, d in tr.params.items()}
+        ref = ol.ewc_penalty(cpu, fisher, stars, tr.loss.ewc_lambda, first_task_only=True)
+        ref.backward()
+        v_ref = float(ref)
+        g_ref = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in cpu)))
+        rv, rg = abs(v_hip - v_ref) / max(abs(v_ref), 1e-30), abs(g_hip - g_ref) / max(abs(g_ref), 1e-30)
+        return {"what": "EWC penalty and its gradient norm over P = %d parameters, HIP vs oracle.losses.ewc_penalty (CPU fp32)" % arena.size,
+                "penalty_hip": v_hip, "penalty_oracle": v_ref, "penalty_rel_err": rv, "grad_norm_hip": g_hip,
+                "grad_norm_oracle": g_ref, "grad_norm_rel_err": rg, "gates": {"rel_err<=1e-4": rv <= 1e-4 and rg <= 1e-4}}
+    if ext == "lwf":
+        from lifelong_nnunet_amd.losses import kl_logits
+        pred, teach = tr.LwFloss.pred_logits[0], tr.LwFloss.target_logits[0]
+        T = tr.LwFloss.lwf_temperature
+        v_hip = float(kl_logits(pred, teach, T))
+        v_ref = float(ol.lwf_distillation(pred.detach().float().cpu(), teach.detach().float().cpu(), T))
+        rv = abs(v_hip - v_ref) / max(abs(v_ref), 1e-30)
+        return {"what": "LwF distillation KL (T = %g) of the last iteration's full-size logits pair %s, lnn_kl_logits vs "
+                        "oracle.losses.lwf_distillation (CPU fp32)" % (T, "x".join(map(str, pred.shape))),
+                "kl_hip": v_hip, "kl_oracle": v_ref, "rel_err": rv, "gates": {"rel_err<=1e-4": rv <= 1e-4}}
+    return None
 
 
 def build_trainer(workload, device, rank):
@@ -296,7 +362,8 @@ def build_trainer(workload, device, rank):
 
     def provider(task, split, p):
         from lifelong_nnunet_amd.training.network_training.multihead.nnUNetTrainerMultiHead import default_data_provider
-        return ResidentBatches(default_data_provider(task, split, p, seed=12345 + 7919 * rank), device)
+        # TWO distinct resident batches, alternated: no step sees the patch of the step before it
+        return ResidentBatches(default_data_provider(task, split, p, seed=12345 + 7919 * rank), device, n=2)
 
     kw = {"cases_per_task": 8} if ext == "rehearsal_ewc" else {}
     tr = Trainer("seg_outputs", "synthetic_task_A", plans=plans, data_provider=provider, device=device, fold=0, **kw)
@@ -353,6 +420,11 @@ def other_workload(workload, args, device, rank):
     res = {"workload": f"{wl_desc}, {'x'.join(map(str, plans['patch_size']))} patches, batch {B}", "value": B * args.steps / dt,
            "unit": "patches/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "loss": float(loss)}
     res.update(extra_cfg)
+    if not args.no_cpu_baseline:
+        try:
+            res["parity"] = regulariser_parity(tr, ext)
+        except Exception as e:
+            res["parity"] = {"error": repr(e)}
     if ext == "lwf":          # the fix behind a flag: every head evaluated on the training batch (one batch, one body pass)
         tr.same_batch_predictions = True
         for _ in range(2):
@@ -379,16 +451,44 @@ def main():
                     help="CPU baseline / parity patch: one full-size patch (~15 s of CPU work) or a 128^3 sub-patch")
     ap.add_argument("--other-workloads", default=None,
                     help="comma list of further BASELINE configurations reported as extra keys (default: c3,c4,c5 with --workload c2 at N=1; 'none')")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the gradient exchange: nccl (= RCCL over xGMI, one GPU per rank) or gloo "
+                         "(stages device tensors through host memory; what lets N ranks share one GPU in the tests)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="ranks beyond torch.cuda.device_count() reuse the visible GPUs round-robin (gloo only: a plumbing check "
+                         "of the N-rank path on a 1-GPU box, never a measurement)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run, same arguments
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or call "
+                 f"`python bench.py --gpus {args.gpus}` without WORLD_SIZE in the environment (it launches the ranks itself)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not (args.share_gpu and args.backend == "gloo"):
+            sys.exit(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible, {world} ranks): one GPU per rank is the "
+                     f"measurement contract (--share-gpu --backend gloo is the plumbing check)")
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("LNN_FORCE_DP", "0") == "1"
     # stdout must carry exactly ONE line (the JSON): libraries that print to the C-level stdout (RCCL writes a version
     # banner there at communicator creation) are sent to stderr; the JSON goes to the saved descriptor at the end
@@ -402,7 +502,7 @@ def main():
         # NO device_id: with it the RCCL communicator is created eagerly, BEFORE the engine allocates its buffers, and every
         # step then runs 6-7 % slower on this stack (ROCm 7.0 / RCCL 2.26.6; tools/dp_ab.py: 27.6 vs 25.9 ms, plain 25.9).
         # Created lazily by the first collective (the first warm-up step's gradient all-reduce) it costs nothing.
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from lifelong_nnunet_amd import native as nat
     tr, plans, ext, wl_desc, extra_cfg = build_trainer(args.workload, device, rank)
@@ -449,23 +549,33 @@ def main():
             step()
         torch.cuda.synchronize()
         eng.probe, eng.overlap_wgrad = None, keep_ov
+    ranks_seen, devices_seen = 1, 1
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                   # every rank adds 1: what the collective library itself saw
+        ranks_seen = int(ones.item())
+        uu = [None] * world
+        dist.all_gather_object(uu, str(torch.cuda.get_device_properties(device).uuid) if hasattr(
+            torch.cuda.get_device_properties(device), "uuid") else f"index{dev_index}")
+        devices_seen = len(set(uu))
 
     flops_patch, mac_fwd = eng.flops_per_patch()
     B = plans["batch_size"]
     patches_per_s = world * B * args.steps / dt
     out = {
         "metric": "3D patches/sec (whole node) + mean Dice vs ref, 5-level 3D Generic_UNet training step", "value": patches_per_s,
-        "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "patches/s", "n_gpus": world, "ranks_seen": ranks_seen, "distinct_devices": devices_seen,
+        "backend": (args.backend if use_dist else None), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
         "config": {"workload": f"{wl_desc}, "
                                f"{'x'.join(map(str, plans['patch_size']))} patches, batch {B}/GPU, num_pool {plans['num_pool']}, "
                                f"base {plans['base_num_features']}, {plans['num_classes']} logits",
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss),
+                   "distinct_resident_batches": len(tr.tr_gen.items) if isinstance(tr.tr_gen, ResidentBatches) else None,
                    "conv_gflop_per_patch": flops_patch / 1e9,
                    "conv_stack_tflops": patches_per_s / world * flops_patch / 1e12,
                    "conv_stack_frac_of_mfma_peak": patches_per_s / world * flops_patch / 1e12 / PEAK_MFMA_F16_TFLOPS},
@@ -515,21 +625,23 @@ def main():
         # the headline is the family that bounds the stack: the slowest of the three IN the step
         dom_key = min(fams, key=lambda k: fams[k]["achieved_in_step"] or fams[k]["achieved_isolated"])
         dom = fams[dom_key]
-        traffic, traffic_note = None, None
-        try:      # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 runs)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        # HBM bytes per launch / shader clock / matrix-pipe busy cycles come from committed PMC passes over this same command
+        # (separate rocprofv3 runs, tools/gpu_r4_pmc.sh).  They describe ONE binary: each file carries the sha256 of the
+        # liblnn_hip.so it was collected with and is quoted only when that is the library loaded now.
+        traffic, traffic_note, clock = None, None, None
+        so_sha = so_sha256()
+        tj = committed_pmc("pmc_traffic.json", so_sha)
+        if tj is not None:
             short = {"igemm_conv_fwd": "fwd", "igemm_conv_dgrad": "dgrad", "igemm_wgrad": "wgrad"}.get(dom_key, dom_key)
-            traffic, traffic_note = tj["kernels"][short]["hbm_bytes_per_launch_corrected"], "profiles/r03_pmc_traffic.json: " + tj["note"]
-        except Exception:
-            pass
-        clock = None
-        try:      # shader clock and matrix-pipe busy cycles of the same launches (committed PMC pass, tools/pmc_mfma_clock.py)
-            cj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_mfma_clock.json")))
+            traffic = tj[1]["kernels"][short]["hbm_bytes_per_launch_corrected"]
+            traffic_note = f"profiles/{tj[0]} (so_sha256 matches the loaded library): " + tj[1]["note"]
+        else:
+            traffic_note = "no committed PMC pass for this liblnn_hip.so (sha256 %s...): traffic not quoted" % so_sha[:12]
+        cj = committed_pmc("pmc_mfma_clock.json", so_sha)
+        if cj is not None:
             clock = {k: {"clock_ghz": v["clock_ghz"], "mfma_busy_frac_in_cycles": v["mfma_busy_frac_in_cycles"]}
-                     for k, v in cj["families"].items() if v}
-            clock["source"] = "profiles/r03_pmc_mfma_clock.json (GRBM_GUI_ACTIVE / duration; SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles)"
-        except Exception:
-            pass
+                     for k, v in cj[1]["families"].items() if v}
+            clock["source"] = f"profiles/{cj[0]} (GRBM_GUI_ACTIVE / duration; SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles)"
         ach = dom["achieved_in_step"] or dom["achieved_isolated"]
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"] + " on " + kr["layer"], "achieved": ach,
                            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,

@@ -217,6 +217,7 @@ size_t lnn_seg1x1_bwd_ws_floats(int N, int C);
  *   fwd : stats[n][k][3] = soft tp/fp/fn (double), ce_sum (double) -> loss = CE + Dice (fp32, *out_loss)
  *   bwd : dlogits = gscale * d(loss)/d(logits)   (gscale = ds weight * upstream grad * loss scale)
  * labels: (N,1,V) float holding integers (nnUNetTrainerMultiHead.py:606-608).  ws >= lnn_dice_ce_ws_doubles.
+ * Limits (error code, not a fallback): 2 <= K <= 8 logit channels, 1 <= N <= 4096 samples per call (the per-rank batch).
  * ---------------------------------------------------------------------------------------------- */
 int lnn_dice_ce_fwd(lnn_stream_t s, const float* logits, const float* labels, int N, int K, long V,
                     int batch_dice, float smooth, float* out_loss, double* ws);
@@ -341,11 +342,6 @@ long lnn_flat_reduce_ws_doubles(void);
 int lnn_sgd_nesterov_step(lnn_stream_t s, float* theta, float* momentum_buf, const float* grad, long n,
                           float lr, float momentum, float weight_decay, float grad_scale, int first_step);
 
-/* debug: every lane of one wave issues ds_read_b64_tr_b16 at LDS byte address lane*8 over an LDS image
- * holding its own half-index; out[lane*4+j] (float) = value received.  Used by tests to pin the
- * hardware transpose-read lane mapping the wgrad kernels rely on. */
-int lnn_debug_tr16_probe(lnn_stream_t s, float* out256);
-
 /* as above with the unscale / clip coefficient / inf-skip decision taken ON DEVICE from ctrl = out2 of
  * lnn_gradnorm_sumsq: coef = min(1, max_norm/(sqrt(ctrl[0])+1e-6)); ctrl[1] > 0 skips the step
  * (GradScaler.step + clip_grad_norm_, nnUNetTrainerMultiHead.py:627-631).  momentum_buf must start zeroed. */
@@ -381,19 +377,6 @@ int lnn_f32_instnorm_lrelu_bwd(lnn_stream_t s, float* y, int ld_y, const float* 
 int lnn_f32_seg1x1_fwd(lnn_stream_t s, const float* z, int ld_z, const float* w, float* logits, int N, long V, int C, int K);
 int lnn_f32_seg1x1_bwd(lnn_stream_t s, const float* z, int ld_z, const float* w, const float* dlogits, float* gz, int ld_gz,
                        float* dw, int N, long V, int C, int K, int accumulate);
-
-/* debug: when set to a zeroed device buffer of 6 uint64, the stride-1 conv kernel accumulates shader-clock cycles
- * per phase {issue loads, MFMA, barrier, LDS stores, barrier} and the step count; pass NULL to disable. */
-int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64);
-/* Parity tests only: pin the stride-1 conv forward / dgrad kernel (-1 automatic, 5 = v5, 7 = v7, 8 = v8 where
- * the layer has >= 64 output channels, 9 = v9 where the layer has 32 / 64 / 128 input channels and no accumulation,
- * v5 otherwise; any other value is an error -- the generic first-version kernel was deleted in round 3).  Process-wide, not thread-safe: a debug hook, not part of the production surface. */
-int lnn_debug_force_conv_kernel(int which);
-/* Parity tests only: pin the stride-2 conv forward kernel (-1 automatic, 0 the tile kernel, 1 the z-streaming kernel wherever
- * it supports the layer: 32 / 64 input channels, output channels a multiple of 64, even extents).  Process-wide. */
-int lnn_debug_force_down2_kernel(int which);
-/* Parity tests only: number of z segments the v9 kernel cuts a column into (0 = automatic).  Process-wide. */
-int lnn_debug_set_v9_zseg(int segments);
 
 /* fp32 <-> fp16 helpers for the image input (N,1,D,H,W f32 -> fp16, same memory order when C == 1) */
 int lnn_cast_f32_to_h(lnn_stream_t s, const float* src, void* dst_h, long n);

@@ -265,10 +265,6 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         floatx4 pv[(NCK - 1) * QN];
         auto fin_load = [&](int tprev) {
             if (!fin) return;
-#ifdef LNN_V9_EXPERIMENT_NO_EXCHANGE
-            for (int s = 0; s < (NCK - 1) * QN; ++s) pv[s] = floatx4{0.f, 0.f, 0.f, 0.f};
-            return;
-#endif
             const char* eb = exch + (tprev & 1) * EXB + rbase;
 #pragma unroll
             for (int s = 0; s < (NCK - 1) * QN; ++s) pv[s] = *reinterpret_cast<const floatx4*>(eb + s * 1024);
@@ -362,16 +358,11 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 if (a < QN && fin) continue;                 // own quads stay in registers
-#ifdef LNN_V9_EXPERIMENT_NO_EXCHANGE       // timing experiment only: partial sums are dropped
-                continue;
-#endif
                 const floatx4 w = {acc[c][4 * a], acc[c][4 * a + 1], acc[c][4 * a + 2], acc[c][4 * a + 3]};
                 *reinterpret_cast<floatx4*>(eb + wb[a]) = w;
             }
             wait_vm<(D - 2) * DPW, true>();
-#ifndef LNN_V9_EXPERIMENT_NO_BARRIER      // timing experiment only (tools/gpu_r3_k.sh): results are wrong without it
             __builtin_amdgcn_s_barrier();
-#endif
         };
 
         // T plane steps + one more that stores the last output plane, rounded up to the 3-step accumulator rotation

@@ -914,9 +914,7 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
         if (timed) t2 = __builtin_readcyclecounter();
         wg_wait_all();                   // the next tile's planes / dy tile are complete ...
         if (timed) t3 = __builtin_readcyclecounter();
-#ifndef LNN_WG_EXPERIMENT_NO_BARRIER     // timing experiment only (tools/gpu_r3_k.sh): results are wrong without it
         __syncthreads();                 // ... and every wave is done reading this tile
-#endif
         if (timed) {
             const unsigned long long t4 = __builtin_readcyclecounter();
             ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include "../../include/lnn_hip.h"
+#include "lnn_debug.h"
 
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

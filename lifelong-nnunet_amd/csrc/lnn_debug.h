@@ -1,0 +1,31 @@
+/* Debug / test hooks of liblnn_hip.so -- NOT part of the drop-in surface (include/lnn_hip.h).  The parity tests use them to pin
+ * one kernel variant at a time, the profiling tools to read per-phase cycle counters.  Process-wide, not thread-safe. */
+#ifndef LNN_DEBUG_H
+#define LNN_DEBUG_H
+#include "../../include/lnn_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* debug: every lane of one wave issues ds_read_b64_tr_b16 at LDS byte address lane*8 over an LDS image
+ * holding its own half-index; out[lane*4+j] (float) = value received.  Used by tests to pin the
+ * hardware transpose-read lane mapping the wgrad kernels rely on. */
+int lnn_debug_tr16_probe(lnn_stream_t s, float* out256);
+
+/* debug: when set to a zeroed device buffer of 6 uint64, the stride-1 conv kernel accumulates shader-clock cycles
+ * per phase {issue loads, MFMA, barrier, LDS stores, barrier} and the step count; pass NULL to disable. */
+int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64);
+/* Parity tests only: pin the stride-1 conv forward / dgrad kernel (-1 automatic, 5 = v5, 7 = v7, 8 = v8 where
+ * the layer has >= 64 output channels, 9 = v9 where the layer has 32 / 64 / 128 input channels and no accumulation,
+ * v5 otherwise; any other value is an error -- the generic first-version kernel was deleted in round 3).  Process-wide, not thread-safe: a debug hook, not part of the production surface. */
+int lnn_debug_force_conv_kernel(int which);
+/* Parity tests only: pin the stride-2 conv forward kernel (-1 automatic, 0 the tile kernel, 1 the z-streaming kernel wherever
+ * it supports the layer: 32 / 64 input channels, output channels a multiple of 64, even extents).  Process-wide. */
+int lnn_debug_force_down2_kernel(int which);
+/* Parity tests only: number of z segments the v9 kernel cuts a column into (0 = automatic).  Process-wide. */
+int lnn_debug_set_v9_zseg(int segments);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LNN_DEBUG_H */

@@ -115,7 +115,9 @@ __device__ __forceinline__ void pack_unit_load(const float* __restrict__ sp, hal
     // full units of tap-contiguous tensors: the unit is 32 (16) source runs of 16 (32) x NTAPS consecutive floats -> 16-byte loads
     // (a quarter of the load instructions; the scalar loop below remains for ragged units and the first layer)
     const bool full = mb * 32 + 32 <= M && ck * 16 + 16 <= KC && st == 1 && (kc_inner ? skc : sm) == NTAPS &&
-                      ((sm | skc) & 3) == 0 && (reinterpret_cast<unsigned long long>(sp) & 15) == 0;
+                      ((kc_inner ? sm : skc) & 3) == 0 && (reinterpret_cast<unsigned long long>(sp) & 15) == 0;
+    // (only the OUTER stride has to keep the run starts 16-byte aligned: the inner one is NTAPS itself -- 27 for every 3x3x3
+    // layer -- and a unit starts at a multiple of 16 * NTAPS or 32 * NTAPS floats, a multiple of 4 either way)
     if (NTAPS > 1 && full) {
         const int RL4 = (kc_inner ? 4 : 8) * NTAPS;          // float4 per run
         const float* base = sp + (long)mb * 32 * sm + (long)ck * 16 * skc;

@@ -7,6 +7,7 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int KMAX = 8;  // logit channels held in registers
+constexpr int LNN_DICE_CE_MAX_BATCH = 4096;   // per-sample CE partials of the finalize kernel live in (dynamic) LDS: 32 KB
 
 // ---------------------------------------------------------------------------------------- seg 1x1x1
 __global__ __launch_bounds__(NT) void seg_fwd_kernel(const half_t* __restrict__ z, int ld_z, const float* __restrict__ w,
@@ -269,7 +270,7 @@ __device__ void dice_ce_loss_from_totals(const double* ws, int N, int K, long V,
 // with a block-wide tree per total: 20 x 8 barriers = 28 us per deep-supervision level.
 __global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nblk, int N, int K, long V, int batch_dice,
                                                               float smooth, float* out, float weight, float* total, int accumulate) {
-    __shared__ double ce_part[KMAX * 8];
+    extern __shared__ double ce_part[];               // N doubles (dynamic: any batch size up to LNN_DICE_CE_MAX_BATCH)
     constexpr int W = 3 * KMAX + 1;
     const float* pws = reinterpret_cast<const float*>(ws + (long)N * K * 3 + 2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nb
         s = wave_sum_d(s);
         if (lane == 0) {
             if (i < 3 * KMAX) ws[((long)n * K + i / 3) * 3 + i % 3] = s;
-            else ce_part[n] = s;                      // N <= KMAX * 8 is checked by the host
+            else ce_part[n] = s;
         }
     }
     __syncthreads();
@@ -648,7 +649,7 @@ static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* l
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(logits && labels && out_loss && ws, "lnn_dice_ce_fwd: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
-    LNN_REQUIRE(N >= 1 && N <= KMAX * 8, "lnn_dice_ce_fwd: batch %d unsupported (1..%d)", N, KMAX * 8);
+    LNN_REQUIRE(N >= 1 && N <= LNN_DICE_CE_MAX_BATCH, "lnn_dice_ce_fwd: batch %d unsupported (1..%d)", N, LNN_DICE_CE_MAX_BATCH);
     const int nblk = vox_blocks(V);
     const bool vec = (V & 3) == 0 && lnn_aligned16(logits) && lnn_aligned16(labels);
 #define LNN_DCE_FWD(KT, VEC) hipLaunchKernelGGL((dice_ce_fwd_kernel<KT, VEC>), dim3(nblk, N), dim3(NT), 0, s, logits, labels, K, V, ws, N)
@@ -656,7 +657,7 @@ static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* l
     else { if (K == 3) LNN_DCE_FWD(3, 1); else if (K == 2) LNN_DCE_FWD(2, 1); else if (K == 4) LNN_DCE_FWD(4, 1); else LNN_DCE_FWD(0, 1); }
 #undef LNN_DCE_FWD
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd");
-    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(NT), 0, s, ws, nblk, N, K, V, batch_dice, smooth, out_loss, weight,
+    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(NT), N * sizeof(double), s, ws, nblk, N, K, V, batch_dice, smooth, out_loss, weight,
                        total, accumulate);
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd(finalize)");
     return LNN_OK;

@@ -360,7 +360,6 @@ class UNetEngine:
         self.packed_version = -1
         self.unused_heads: List[str] = []
         self._side = None
-        self._lstreams, self._lws, self._lsplitk = [], [], []
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
@@ -374,9 +373,6 @@ class UNetEngine:
         self.fuse_seg_bwd = os.environ.get("LNN_NO_FUSED_SEG_BWD", "0") != "1"
         # first block: pass 2 of its InstanceNorm backward rebuilt inside its weight gradient (dy never written): A/B switch
         self.fuse_first_bwd = os.environ.get("LNN_NO_FUSED_FIRST_BWD", "0") != "1"
-        # opt-in: measured 1.5 % SLOWER than the single-lane plan on C2 (the 8-wave conv blocks leave the co-scheduler
-        # little room), kept because it is the natural hook for per-sample pipelining across GPUs / larger batches
-        self.sample_lanes = os.environ.get("LNN_SAMPLE_LANES", "0") == "1"
         # measurement hook (bench.py): {"layer": <block prefix>} -> the forward conv / data-gradient / weight-gradient calls of
         # that block are bracketed with timing events ON THE STREAM THEY LAUNCH ON, appended to probe["fwd" | "dgrad" | "wgrad"]
         self.probe = None
@@ -420,24 +416,6 @@ class UNetEngine:
         nat.call("lnn_unpack_wgrad_batched", self.gpanels, self.grad, self._unpack_desc, self._unpack_desc.shape[0],
                  self._unpack_total, 1.0, 1)
 
-    # ------------------------------------------------------------------------------------------ sample lanes
-    # Patches are independent through the whole network (InstanceNorm is per sample), so a batch is processed as up to
-    # two "lanes" of samples on separate HIP streams: while one lane runs an MFMA-bound convolution (one 8-wave block
-    # per CU) the other lane's HBM-bound InstanceNorm / seg / loss-side kernels find free wave slots and LDS.
-    def _lanes(self):
-        if not self.sample_lanes or self.N < 2:
-            return [(0, self.N)]
-        h = self.N // 2
-        return [(0, h), (h, self.N - h)]
-
-    def _lane_streams(self, n):
-        while len(self._lstreams) < n:
-            self._lstreams.append(torch.cuda.Stream(device=self.device))
-            self._lws.append(torch.zeros_like(self.ws))
-            # every lane runs on its own stream: the split-K scratch of the small deep layers must not be shared either
-            self._lsplitk.append(self.splitk_ws if not self._lsplitk else torch.zeros_like(self.splitk_ws))
-        return self._lstreams[:n]
-
     @staticmethod
     def _at(obj, n0):
         """Pointer to sample n0 of an activation (Act) or batch-major tensor."""
@@ -446,21 +424,10 @@ class UNetEngine:
         return obj[n0:]
 
     def _fork(self, fn):
-        """Run fn(n0, nn, ws, splitk_ws) for every lane (workspaces are per lane); lanes beyond the first on their own stream, joined before returning."""
-        lanes = self._lanes()
-        if len(lanes) == 1:
-            fn(0, self.N, self.ws, self.splitk_ws)
-            return
-        main = torch.cuda.current_stream()
-        streams = self._lane_streams(len(lanes))
-        ev = torch.cuda.Event()
-        ev.record(main)
-        for (n0, nn), st, ws, sk in zip(lanes, streams, self._lws, self._lsplitk):
-            st.wait_event(ev)
-            with torch.cuda.stream(st):
-                fn(n0, nn, ws, sk)
-        for st in streams:
-            main.wait_stream(st)
+        """Run fn(n0, nn, ws, splitk_ws) over the whole batch.  (A two-lane variant -- half the samples per HIP stream, so that one
+        lane's HBM-bound normalisation passes would run under the other lane's MFMA-bound convolutions -- measured 1.5 % SLOWER
+        on C2 in round 1: the 8-wave convolution blocks own their CU's register file, nothing co-schedules; removed in round 4.)"""
+        fn(0, self.N, self.ws, self.splitk_ws)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, seg_weights: Optional[List[torch.Tensor]] = None, body: bool = True):
@@ -567,18 +534,13 @@ class UNetEngine:
         self.unused_heads = [seg.w.name for seg, dl in zip(self.segs, dlogits) if dl is None]
         dls = [None if dl is None else dl.contiguous() for dl in dlogits]
         at = self._at
-        multi = len(self._lanes()) > 1
-        assert not (multi and self.deterministic_wgrad), \
-            "deterministic_wgrad keeps ONE ordered-reduction scratch: not available with LNN_SAMPLE_LANES=1 (two streams)"
         # Weight gradients are off the critical path of backward (they only have to be final before the optimiser /
-        # the all-reduce).  Single lane: they go to a SIDE HIP stream right after the layer's dL/dy exists; two lanes:
-        # each lane already overlaps the other, both accumulate into the same fp32 panels (atomics) and the panels
-        # are folded into the gradient arena once, after the lanes have joined.
+        # the all-reduce): they go to a SIDE HIP stream right after the layer's dL/dy exists.
         main = torch.cuda.current_stream()
         # data parallel (progress given): the weight gradients stay on the side stream; a layer's panel is folded into the
         # gradient arena there too, and the all-reduce of every bucket that became final is launched FROM the side stream
         # (parallel.GradAllReducer.progress): two streams share the chip, as in the single-GPU plan
-        side = self._side_stream() if (self.overlap_wgrad and not multi) else None
+        side = self._side_stream() if self.overlap_wgrad else None
 
         def on_side(fn):
             if side is None:
@@ -592,7 +554,7 @@ class UNetEngine:
 
         # the DP all-reduce overlaps with backward and needs every layer's gradient final as soon as its wgrad is:
         # per-layer unpack there; otherwise one batched unpack after the last wgrad
-        per_layer_unpack = progress is not None and not multi
+        per_layer_unpack = progress is not None
 
         def unpack(item):
             if isinstance(item, ConvBlock):
@@ -612,7 +574,7 @@ class UNetEngine:
             seg_u = len(self.segs)
             pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
             for item in reversed(self.order):
-                if progress is not None and not multi and item is not self.order[-1]:
+                if progress is not None and item is not self.order[-1]:
                     # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
                     # (weight gradients + their unpack) have run what is enqueued so far; a head that was deferred into
                     # this block's call is not final yet: only what lies behind the head is
@@ -720,8 +682,6 @@ class UNetEngine:
             main.wait_stream(side)      # every weight gradient is final before anything downstream (norm, step)
         if not per_layer_unpack and not skip_body:
             self.unpack_wgrads()
-        if progress is not None and multi:
-            progress(0)
 
     def _side_stream(self):
         if self._side is None:

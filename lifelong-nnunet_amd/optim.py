@@ -108,6 +108,7 @@ class FusedSGD:
         self.ctrl = self._ctrl_buf[:2]
         self._ctrl_valid = False
         self._ever_stepped = set()       # names the optimiser has stepped at least once (torch creates their momentum_buffer then)
+        self._pending_stepped = None     # names of the last enqueued step, counted once its found-inf flag is known to be 0
 
     def zero_grad(self, set_to_none=False):
         self.net.arena.grad.zero_()
@@ -118,6 +119,7 @@ class FusedSGD:
         """sum of squares of the UNSCALED gradient + non-finite count -> self.ctrl (device)."""
         a = self.net.arena
         first = 1
+        self._resolve_pending()          # (a host sync only if nobody fetched the previous step's control block)
         for lo, hi in _ranges(self.net):
             nat.call("lnn_gradnorm_sumsq", _Off(a.grad, lo), hi - lo, float(inv_scale), self._ctrl_buf, first)
             first = 0
@@ -128,6 +130,7 @@ class FusedSGD:
         the device if a non-finite gradient was counted."""
         a, g = self.net.arena, self.param_groups[0]
         if not self._ctrl_valid:
+            self._resolve_pending()
             self.ctrl.zero_()
             max_norm = 0.0
         for lo, hi in _ranges(self.net):
@@ -136,18 +139,32 @@ class FusedSGD:
                      self.ctrl)
         self._ctrl_valid = False
         skip = set(getattr(self.net, "params_without_grad", ())) - set(getattr(self.net, "penalty_grad_names", ()))
-        self._ever_stepped.update(n for n, p in self.net._named if p.requires_grad and n not in skip)
+        # GradScaler.step does not call optimizer.step() on overflow, so torch creates no momentum_buffer then: the names count
+        # as stepped only once the device-side found-inf flag of THIS step has reached the host (fetch_with_loss / read_ctrl)
+        self._pending_stepped = [n for n, p in self.net._named if p.requires_grad and n not in skip]
         self.net.mark_params_changed()
+
+    def _resolve_pending(self, found_inf=None):
+        if self._pending_stepped is None:
+            return
+        if found_inf is None:
+            found_inf = bool(self.ctrl[1].item() > 0)
+        if not found_inf:
+            self._ever_stepped.update(self._pending_stepped)
+        self._pending_stepped = None
 
     def fetch_with_loss(self, loss):
         """numpy [sum g^2, #non-finite, loss]: the loss is parked next to the control block (slot 2 is scratch of the norm
         reduction, free once the step has been enqueued) so that ONE device-to-host copy carries all three."""
         self._ctrl_buf[2:3].copy_(loss.detach().reshape(1))
-        return self._ctrl_buf[:3].cpu().numpy()
+        arr = self._ctrl_buf[:3].cpu().numpy()
+        self._resolve_pending(bool(arr[1] > 0))
+        return arr
 
     def read_ctrl(self):
         """(total_norm, found_inf) -- ONE host sync; call after the loss has been fetched anyway."""
         c = self.ctrl.cpu()
+        self._resolve_pending(bool(c[1] > 0))
         return float(c[0]) ** 0.5, bool(c[1] > 0)
 
     def _trainable(self):
@@ -161,6 +178,7 @@ class FusedSGD:
         head as long as no penalty term gave it a gradient) has no state entry, as in torch."""
         g = self.param_groups[0]
         named = self._trainable()
+        self._resolve_pending()
         state = {}
         for i, (n, p) in enumerate(named):
             s = p._lnn_slot

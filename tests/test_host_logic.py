@@ -16,8 +16,16 @@ from lifelong_nnunet_amd.network import Generic_UNet
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _headers():
+    """The public C-ABI (include/lnn_hip.h) followed by the debug / test hooks (csrc/lnn_debug.h, not part of the drop-in surface)."""
+    return (open(os.path.join(ROOT, "include", "lnn_hip.h")).read(),
+            open(os.path.join(ROOT, "lifelong-nnunet_amd", "csrc", "lnn_debug.h")).read())
+
+
 def test_cabi_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "lnn_hip.h")).read()
+    pub, dbg = _headers()
+    assert "lnn_debug_" not in pub, "debug hooks belong in csrc/lnn_debug.h, not in the public header"
+    hdr = pub + dbg
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(lnn_[a-zA-Z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 30
@@ -33,7 +41,7 @@ def test_ctypes_signatures_match_the_header():
     """Every declaration of include/lnn_hip.h against the ctypes table: same number of parameters, and per parameter the same
     class (pointer / int / long / float / size_t) -- a wrong table entry would corrupt a call silently."""
     import ctypes as C
-    hdr = open(os.path.join(ROOT, "include", "lnn_hip.h")).read()
+    hdr = "".join(_headers())
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     hdr = re.sub(r"//[^\n]*", "", hdr)
     decls = re.findall(r"\b([a-zA-Z_][a-zA-Z0-9_ \*]*?)\s*\b(lnn_[a-zA-Z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)

@@ -35,6 +35,15 @@ def parse(src):
     return rows
 
 
+
+def so_sha256():
+    """sha256 of the liblnn_hip.so these counters were collected with: bench.py quotes the file only for the same binary."""
+    import hashlib
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lifelong-nnunet_amd", "csrc", "liblnn_hip.so")
+    return hashlib.sha256(open(so, "rb").read()).hexdigest()
+
+
 def main(src, src_clock, dst):
     rows, clk = parse(src), parse(src_clock)
     out = []
@@ -56,7 +65,8 @@ def main(src, src_clock, dst):
     pick = lambda k, g: max((r for r in out if r["kernel"] == k and r["grid_x"] == g), key=lambda r: r["mean_us"], default=None)
     fam = {"fwd": pick("conv_s1_v9<4,1,2,stats=1>", 131072), "dgrad": pick("conv_s1_v9<2,2,2,stats=0>", 131072),
            "wgrad": pick("wgrad_s1_v5", 131072)}     # the launches of conv_blocks_localization.4.0 (bench.py's roofline block)
-    json.dump({"note": __doc__.split("usage")[0].strip(), "families": fam, "kernels": out}, open(dst, "w"), indent=1)
+    json.dump({"note": __doc__.split("usage")[0].strip(), "so_sha256": so_sha256(), "families": fam, "kernels": out},
+              open(dst, "w"), indent=1)
     for r in out[:24]:
         print(f"{r['kernel']:36s} g={r['grid_x']:8d} {r['mean_us']:8.1f} us  {r['clock_ghz']:.2f} GHz  busy {r['mfma_busy_frac_in_cycles']:.2f}"
               f"  ({r['busy_cycles_per_mfma_inst']} cyc/inst)  -> {r['frac_of_2p5_pflops']:.2f} of 2.5 PF")

@@ -44,6 +44,15 @@ def short(name):
     return name[:48]
 
 
+
+def so_sha256():
+    """sha256 of the liblnn_hip.so these counters were collected with: bench.py quotes the file only for the same binary."""
+    import hashlib
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lifelong-nnunet_amd", "csrc", "liblnn_hip.so")
+    return hashlib.sha256(open(so, "rb").read()).hexdigest()
+
+
 def main(src, dst):
     f = parse(src + "/pmc_fetch.txt", "FETCH_SIZE")
     w = parse(src + "/pmc_write.txt", "WRITE_SIZE")
@@ -69,6 +78,7 @@ def main(src, dst):
            "kernels": {"fwd": pick("conv_s1_v9<4,1,2,stats=1>", 131072), "dgrad": pick("conv_s1_v9<2,2,2,stats=0>", 131072),
                        "wgrad": pick("wgrad_s1_v5", 131072)},
            "all_kernels_over_40us": rows}
+    out["so_sha256"] = so_sha256()
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, v["kernel"], v["mean_us"], v["hbm_bytes_per_launch_corrected"] / 1e9, v["ratio_to_algorithmic"], v["hbm_tb_per_s"])
