@@ -384,14 +384,17 @@ class UNetEngine:
 
     def _probed(self, kind, item, fn):
         pr = self.probe
-        if pr is None or pr.get("layer") != item.prefix:
+        if pr is None or (pr.get("layer") != item.prefix and pr.get("layer") != "*"):
             fn()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        pr.setdefault(kind, []).append((e0, e1))
+        if pr.get("layer") == "*":          # tools/layer_table.py: every call of every layer
+            pr.setdefault("all", []).append((item.prefix, kind, e0, e1))
+        else:
+            pr.setdefault(kind, []).append((e0, e1))
 
     # ------------------------------------------------------------------------------------------ views
     def pview(self, slot: ParamSlot, arena=None):
@@ -476,19 +479,22 @@ class UNetEngine:
                     seg = self._seg_after.get(id(item))
                     if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
                         # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y
-                        nat.call("lnn_instnorm_lrelu_seg_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
-                                 self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, self.pview(seg.w),
-                                 logits[self.segs.index(seg)][n0:], self.K)
+                        self._probed("in_fwd", item, lambda: nat.call(
+                            "lnn_instnorm_lrelu_seg_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
+                            self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, self.pview(seg.w),
+                            logits[self.segs.index(seg)][n0:], self.K))
                         fused_segs.add(id(seg))
                     else:
-                        nat.call("lnn_instnorm_lrelu_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
-                                 self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE)
+                        self._probed("in_fwd", item, lambda: nat.call(
+                            "lnn_instnorm_lrelu_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
+                            self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE))
                 elif isinstance(item, UpBlock):
                     if not body:
                         continue
                     D, H, W = item.x.dims
-                    nat.call("lnn_convT3d_k2s2_fwd", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
-                             item.y.ld, nn, D, H, W, item.cin, item.cout)
+                    self._probed("fwd", item, lambda: nat.call(
+                        "lnn_convT3d_k2s2_fwd", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
+                        item.y.ld, nn, D, H, W, item.cin, item.cout))
                 else:
                     if id(item) not in fused_segs:
                         w = self.pview(item.w) if sw is None else sw[u]
@@ -599,16 +605,18 @@ class UNetEngine:
                     V, K, C = item.z.V, item.cout, item.cin
                     if id(item) in pending:
                         seg, dl = pending.pop(id(item))
-                        nat.call("lnn_instnorm_lrelu_seg_bwd", at(item.y, n0), at(item.gz, n0) if seg.gx_has_prior else None,
-                                 item.gz.ld, self.pview(seg.w), dl[n0:], self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
-                                 nn, V, K, item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta),
-                                 LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws)
+                        self._probed("in_bwd", item, lambda: nat.call(
+                            "lnn_instnorm_lrelu_seg_bwd", at(item.y, n0), at(item.gz, n0) if seg.gx_has_prior else None,
+                            item.gz.ld, self.pview(seg.w), dl[n0:], self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
+                            nn, V, K, item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta),
+                            LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
                     elif item.x is None and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
                         # the first block has no data gradient: only the sums of its normalisation backward are taken here,
                         # dy is rebuilt tile by tile inside the weight gradient below (lnn_conv3d_wgrad_c1_in_bwd)
-                        nat.call("lnn_instnorm_lrelu_bwd_sums", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                                 item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
-                                 self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws)
+                        self._probed("in_bwd", item, lambda: nat.call(
+                            "lnn_instnorm_lrelu_bwd_sums", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
+                            item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                            self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
                         D, H, W = item.in_dims
 
                         def first_wgrad(item=item, K=K, D=D, H=H, W=W):
@@ -622,10 +630,11 @@ class UNetEngine:
                         on_side(lambda: self._probed("wgrad", item, first_wgrad))
                         continue
                     else:
-                        nat.call("lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                                 item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
-                                 self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
-                                 self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws)
+                        self._probed("in_bwd", item, lambda: nat.call(
+                            "lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
+                            item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                            self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
+                            self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws))
                     D, H, W = item.in_dims
                     xin = at(self.image, n0) if item.x is None else at(item.x, n0)
                     ldx = 1 if item.x is None else item.x.ld
@@ -664,6 +673,11 @@ class UNetEngine:
                     C, K = item.cin, item.cout
 
                     def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
+                        self._probed("wgrad", item, lambda: up_wgrad_call(item, C, K, D, H, W))
+                        if per_layer_unpack:
+                            unpack(item)
+
+                    def up_wgrad_call(item, C, K, D, H, W):
                         det = self._det_scratch()
                         if det is not None:
                             nat.call("lnn_convT3d_k2s2_wgrad_det", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
@@ -671,11 +685,10 @@ class UNetEngine:
                         else:
                             nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
                                      self._pn(item.panel), nn, D, H, W, C, K)
-                        if per_layer_unpack:
-                            unpack(item)
                     on_side(up_wgrad)
-                    nat.call("lnn_convT3d_k2s2_dgrad", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
-                             item.gx.ld, nn, D, H, W, C, K, 0)
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_convT3d_k2s2_dgrad", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
+                        item.gx.ld, nn, D, H, W, C, K, 0))
 
         self._fork(lane)
         if side is not None:

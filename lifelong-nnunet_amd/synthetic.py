@@ -29,10 +29,12 @@ def make_patch_batch(batch, patch, num_pool, in_channels=1, num_labels=3, seed=1
         f = _smooth_field(patch, gen, k=max(3, int(5 * blob_scale) | 1))[0, 0]
         lab = torch.zeros_like(f)
         # nested blobs: class 1 where the field is high, class 2 in its core
-        qs = torch.quantile(f.flatten()[:: max(1, f.numel() // 65536)], torch.tensor([0.70, 0.90]))
+        # (more than three labels: further nested shells; the thresholds of the first two are unchanged)
+        levels = [0.70, 0.90] + [0.90 + 0.09 * (j + 1) / (num_labels - 3) for j in range(max(0, num_labels - 3))]
+        qs = torch.quantile(f.flatten()[:: max(1, f.numel() // 65536)], torch.tensor(levels))
         lab[f > qs[0]] = 1
-        if num_labels > 2:
-            lab[f > qs[1]] = 2
+        for c in range(2, num_labels):
+            lab[f > qs[c - 1]] = c
         full[b, 0] = lab
         # make the image weakly informative about the label so training has signal
         data[b] += 0.75 * lab[None]
