@@ -378,6 +378,37 @@ int lnn_f32_seg1x1_fwd(lnn_stream_t s, const float* z, int ld_z, const float* w,
 int lnn_f32_seg1x1_bwd(lnn_stream_t s, const float* z, int ld_z, const float* w, const float* dlogits, float* gz, int ld_gz,
                        float* dw, int N, long V, int C, int K, int accumulate);
 
+/* ------------------------------------------------------------------------------------------------
+ * Generic geometry (round 4).  nnU-Net builds Generic_UNet from the plans' `conv_kernel_sizes` / `pool_op_kernel_sizes`
+ * (nnUNetTrainerMultiHead.py:348-369): per axis a kernel extent of 1 or 3 (padding k / 2) and a stride of 1 or 2; the
+ * transposed convolution of a level has kernel == stride == that level's pooling.  Same layouts as above (activations NDHWC
+ * fp16 with a channel stride, weights as blocked panels from lnn_pack_weights with ntaps = kz*ky*kx taps in (z, y, x) order,
+ * fp32 gradient panels of lnn_wgrad_panel_elems(ntaps, ...)).  Replaces torch.nn.functional.conv3d / conv_transpose3d and
+ * their autograd for those shapes.  Di/Hi/Wi = the convolution's INPUT extents, output extents (D - 1) / s + 1;
+ * D/H/W of the transposed entries = ITS input extents, output D * s.  splitk_ws (optional, may be NULL): fp32 scratch that lets
+ * small volumes split the contraction over more waves; parts (optional): scratch of the deterministic weight gradient.
+ * The tensors a call gathers from must be smaller than 2 GB (error otherwise, not a fallback).
+ * ---------------------------------------------------------------------------------------------- */
+int lnn_conv3d_fwd_g(lnn_stream_t s, const void* x, int ld_x, const void* wp, const float* bias, void* y, int ld_y, int N,
+                     int Di, int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx, float* splitk_ws,
+                     long splitk_elems);
+int lnn_conv3d_dgrad_g(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int Di, int Hi,
+                       int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx, int accumulate, float* splitk_ws,
+                       long splitk_elems);
+int lnn_conv3d_wgrad_g(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int Di, int Hi,
+                       int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx, float* parts, long parts_elems);
+int lnn_convT3d_fwd_g(lnn_stream_t s, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N, int D, int H, int W,
+                      int C, int K, int sz, int sy, int sx, float* splitk_ws, long splitk_elems);
+int lnn_convT3d_dgrad_g(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int D, int H,
+                        int W, int C, int K, int sz, int sy, int sx, int accumulate, float* splitk_ws, long splitk_elems);
+int lnn_convT3d_wgrad_g(lnn_stream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int D, int H,
+                        int W, int C, int K, int sz, int sy, int sx, float* parts, long parts_elems);
+/* lnn_convT3d_k2s2_fwd / _dgrad with the optional split-K scratch (as lnn_conv3d_dgrad_ws) */
+int lnn_convT3d_k2s2_fwd_ws(lnn_stream_t s, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N, int D, int H,
+                            int W, int C, int K, float* splitk_ws, long splitk_elems);
+int lnn_convT3d_k2s2_dgrad_ws(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int D,
+                              int H, int W, int C, int K, int accumulate, float* splitk_ws, long splitk_elems);
+
 /* fp32 <-> fp16 helpers for the image input (N,1,D,H,W f32 -> fp16, same memory order when C == 1) */
 int lnn_cast_f32_to_h(lnn_stream_t s, const float* src, void* dst_h, long n);
 

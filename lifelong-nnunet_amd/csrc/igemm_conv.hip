@@ -15,6 +15,7 @@
 // consecutive output channels of one voxel per accumulator quad -> 8-byte channels-last stores.
 #include "lnn_common.h"
 #include "igemm_common.h"
+#include "igemm_gen.h"
 #include <cstdlib>
 
 namespace {
@@ -253,6 +254,28 @@ int launch_v7_maybe_splitk(hipStream_t s, ConvParams& p, float* ws, long ws_elem
     return lnn_launch_splitk_finalize(s, p, name);
 }
 
+}  // namespace
+
+// Small volumes go to the flattened-voxel split-K kernels of igemm_gen.hip (see there): default = at most 4096 output voxels
+// (levels 4 and 5 of the 160x192x160 plan).
+static int g_gen_mode = -1;      // lnn_debug_set_gen_mode: -1 automatic, 0 never, 1 wherever supported
+extern "C" int lnn_debug_set_gen_mode(int mode) {
+    LNN_REQUIRE(mode >= -1 && mode <= 1, "lnn_debug_set_gen_mode: %d is not one of -1, 0, 1", mode);
+    g_gen_mode = mode;
+    return LNN_OK;
+}
+bool lnn_gen_prefers(long loop_voxels) {
+    if (g_gen_mode >= 0) return g_gen_mode == 1;
+    if (g_force_conv >= 0) return false;          // a specialised kernel is pinned by a parity test
+    static long maxvox = -1;
+    if (maxvox < 0) {
+        const char* e = getenv("LNN_GEN_MAXVOX");
+        maxvox = e ? atol(e) : 4096;
+    }
+    return loop_voxels <= maxvox;
+}
+
+namespace {
 int check_act(const void* ptr, int ld, int C, const char* what) {
     LNN_REQUIRE(ptr != nullptr, "%s: null pointer", what);
     LNN_REQUIRE(lnn_aligned16(ptr), "%s: pointer not 16-byte aligned", what);
@@ -314,6 +337,10 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         return LNN_OK;
     }
     if (int e = check_act(x, ld_x, x2 ? c_a : C, "lnn_conv3d_fwd(x)")) return e;
+    if (!x2 && lnn_gen_prefers((long)N * p.Do * p.Ho * p.Wo)) {
+        const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
+        return lnn_gen_conv3d_fwd(s, x, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, k3, st3, splitk_ws, splitk_elems);
+    }
     p.KCpad = lnn_round_up(C, 16);
     p.taps.ntaps = 27;
     if (stride == 1) {
@@ -395,6 +422,10 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
     if (int e = check_act(dy, ld_dy, K, "lnn_conv3d_dgrad(dy)")) return e;
     if (int e = check_act(dx, ld_dx, dx2 ? c_a : C, "lnn_conv3d_dgrad(dx)")) return e;
     const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    if (!dx2 && lnn_gen_prefers((long)N * Di * Hi * Wi)) {
+        const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
+        return lnn_gen_conv3d_dgrad(s, dy, ld_dy, wp, dx, ld_dx, N, Di, Hi, Wi, C, K, k3, st3, accumulate, splitk_ws, splitk_elems);
+    }
     ConvParams p{};
     if (dx2) { p.y2 = (half_t*)dx2; p.msplit = c_a; }
     // roles: gathered input = dy (K channels), output = dx (C channels); panel wp[slot][C][K]
@@ -441,12 +472,17 @@ extern "C" int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy, int ld_dy, c
     return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx_a, dx_b, c_a, ld_dx, N, Di, Hi, Wi, C, K, 1, accumulate);
 }
 
-extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s_, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N,
-                                    int D, int H, int W, int C, int K) {
+namespace {
+int convT3d_k2s2_fwd_impl(lnn_stream_t s_, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N, int D, int H, int W, int C,
+                          int K, float* ws, long ws_elems) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_convT3d_k2s2_fwd: weight panel null/misaligned");
     if (int e = check_act(x, ld_x, C, "lnn_convT3d_k2s2_fwd(x)")) return e;
     if (int e = check_act(y, ld_y, K, "lnn_convT3d_k2s2_fwd(y)")) return e;
+    if (lnn_gen_prefers((long)N * D * H * W * 8)) {
+        const int st3[3] = {2, 2, 2};
+        return lnn_gen_convT3d_fwd(s, x, ld_x, wp, y, ld_y, N, D, H, W, C, K, st3, ws, ws_elems);
+    }
     ConvParams p{};
     p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.y = (half_t*)y; p.ld_x = ld_x; p.ld_y = ld_y;
     p.N = N; p.Di = D; p.Hi = H; p.Wi = W; p.Do = 2 * D; p.Ho = 2 * H; p.Wo = 2 * W;
@@ -454,13 +490,28 @@ extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s_, const void* x, int ld_x, co
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 2; p.pad_lo = 0;
     return lnn_launch_up2_convT(s, p, "lnn_convT3d_k2s2_fwd(up2)");
 }
+}  // namespace
 
-extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx,
-                                      int N, int D, int H, int W, int C, int K, int accumulate) {
+extern "C" int lnn_convT3d_k2s2_fwd(lnn_stream_t s, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N,
+                                    int D, int H, int W, int C, int K) {
+    return convT3d_k2s2_fwd_impl(s, x, ld_x, wp, y, ld_y, N, D, H, W, C, K, nullptr, 0);
+}
+extern "C" int lnn_convT3d_k2s2_fwd_ws(lnn_stream_t s, const void* x, int ld_x, const void* wp, void* y, int ld_y, int N,
+                                       int D, int H, int W, int C, int K, float* splitk_ws, long splitk_elems) {
+    return convT3d_k2s2_fwd_impl(s, x, ld_x, wp, y, ld_y, N, D, H, W, C, K, splitk_ws, splitk_elems);
+}
+
+namespace {
+int convT3d_k2s2_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int D, int H, int W,
+                            int C, int K, int accumulate, float* ws, long ws_elems) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_convT3d_k2s2_dgrad: weight panel null/misaligned");
     if (int e = check_act(dy, ld_dy, K, "lnn_convT3d_k2s2_dgrad(dy)")) return e;
     if (int e = check_act(dx, ld_dx, C, "lnn_convT3d_k2s2_dgrad(dx)")) return e;
+    if (lnn_gen_prefers((long)N * D * H * W)) {
+        const int st3[3] = {2, 2, 2};
+        return lnn_gen_convT3d_dgrad(s, dy, ld_dy, wp, dx, ld_dx, N, D, H, W, C, K, st3, accumulate, ws, ws_elems);
+    }
     ConvParams p{};
     // dx[l, c] = sum_d sum_k dy[2l + d, k] W[c, k, d]: gathered input = dy with stride 2, 8 taps
     p.x = (const half_t*)dy; p.wp = (const half_t*)wp; p.y = (half_t*)dx; p.ld_x = ld_dy; p.ld_y = ld_dx;
@@ -469,4 +520,14 @@ extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s_, const void* dy, int ld_dy
     p.Ld = D; p.Lh = H; p.Lw = W; p.os = 1; p.pad_lo = 0; p.accumulate = accumulate;
     if (use_down2s(p)) return lnn_launch_down2s(s, p, "lnn_convT3d_k2s2_dgrad(down2s)");
     return lnn_launch_down2_convT_dgrad(s, p, "lnn_convT3d_k2s2_dgrad(down2)");
+}
+}  // namespace
+
+extern "C" int lnn_convT3d_k2s2_dgrad(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx,
+                                      int N, int D, int H, int W, int C, int K, int accumulate) {
+    return convT3d_k2s2_dgrad_impl(s, dy, ld_dy, wp, dx, ld_dx, N, D, H, W, C, K, accumulate, nullptr, 0);
+}
+extern "C" int lnn_convT3d_k2s2_dgrad_ws(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx,
+                                         int N, int D, int H, int W, int C, int K, int accumulate, float* splitk_ws, long splitk_elems) {
+    return convT3d_k2s2_dgrad_impl(s, dy, ld_dy, wp, dx, ld_dx, N, D, H, W, C, K, accumulate, splitk_ws, splitk_elems);
 }

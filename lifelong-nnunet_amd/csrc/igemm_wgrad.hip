@@ -12,6 +12,7 @@
 // of TZ x TY x 8 loop voxels, accumulating in registers, and finishes with fp32 atomics into the
 // packed panel (coalesced: c is the fastest index).
 #include "lnn_common.h"
+#include "igemm_gen.h"
 #include <cstdlib>
 
 namespace {
@@ -1379,6 +1380,10 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
         return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(C=1,reduce)");
     }
     if (int e = check_act_w(x, ld_x, x2 ? c_a : C, "lnn_conv3d_wgrad(x)")) return e;
+    if (!x2 && lnn_gen_prefers((long)N * p.Ld * p.Lh * p.Lw)) {
+        const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
+        return lnn_gen_conv3d_wgrad(s, x, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, k3, st3, parts, parts_elems);
+    }
     p.taps.ntaps = 27;
     if (stride == 1) {
         constexpr int PY = 10, PX = 10;
@@ -1457,6 +1462,10 @@ int convT3d_k2s2_wgrad_impl(lnn_stream_t s_, const void* x, int ld_x, const void
     LNN_REQUIRE(dwp != nullptr, "lnn_convT3d_k2s2_wgrad: null panel");
     if (int e = check_act_w(x, ld_x, C, "lnn_convT3d_k2s2_wgrad(x)")) return e;
     if (int e = check_act_w(dy, ld_dy, K, "lnn_convT3d_k2s2_wgrad(dy)")) return e;
+    if (lnn_gen_prefers((long)N * D * H * W)) {
+        const int st3[3] = {2, 2, 2};
+        return lnn_gen_convT3d_wgrad(s, x, ld_x, dy, ld_dy, dwp, N, D, H, W, C, K, st3, parts, parts_elems);
+    }
     WgradParams p{};
     // dW[c,k,d] = sum_l x[l,c] dy[2l+d,k]:  P = x (rows c), Q = dy gathered with stride 2 (cols k)
     p.p = (const half_t*)x; p.q = (const half_t*)dy; p.dwp = dwp; p.ld_p = ld_x; p.ld_q = ld_dy;

@@ -25,6 +25,11 @@ int lnn_debug_force_down2_kernel(int which);
 /* Parity tests only: number of z segments the v9 kernel cuts a column into (0 = automatic).  Process-wide. */
 int lnn_debug_set_v9_zseg(int segments);
 
+/* Parity tests only: the isotropic entry points hand small volumes (<= 4096 output voxels) to the generic flattened-voxel
+ * kernels of igemm_gen.hip; -1 = that automatic rule, 0 = never (pins the specialised kernels on the tests' small shapes),
+ * 1 = every layer the generic kernels support.  Process-wide. */
+int lnn_debug_set_gen_mode(int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -345,7 +345,9 @@ class UNetEngine:
                          nat.query("lnn_instnorm_lrelu_seg_bwd_ws_doubles", N, max(seg.cin for seg in self.segs)), 64)
         self.ws = torch.zeros(ws_doubles, dtype=torch.float64, device=dev)
         # fp32 split-K scratch of the small deep layers (see lnn_conv3d_dgrad_ws): 8 slices of the largest
-        # [N][voxels][roundup32(channels)] among the stride-1 layers with fewer than 512 (8x8x8 x 32-channel) units
+        # [N][voxels][roundup32(channels)] among the stride-1 layers with fewer than 512 (8x8x8 x 32-channel) units; the
+        # flattened-voxel kernels that take the volumes of <= 4096 output voxels (csrc/igemm_gen.hip) split the contraction up to
+        # 64 ways: room for min(64, 2048 waves / their unsplit wave count) slices of every such output
         need = 1
         for blk in self.blocks:
             if blk.stride != 1 or blk.cin == 1:
@@ -356,6 +358,23 @@ class UNetEngine:
             for ch in (blk.cout, blk.cin):
                 if tiles * -(-ch // 32) < 512:
                     need = max(need, 8 * vox * (-(-ch // 32) * 32))
+
+        def gen_need(vox, ch):
+            if vox > 4096:
+                return 1
+            mp = -(-ch // 32) * 32
+            waves = -(-vox // 64) * -(-mp // 64)
+            ks = 1
+            while waves * ks * 2 <= 2048 and ks < 64:
+                ks *= 2
+            return ks * vox * mp
+        for blk in self.blocks:
+            if blk.cin == 1:
+                continue
+            need = max(need, gen_need(N * blk.z.V, blk.cout))                                     # forward
+            need = max(need, gen_need(N * blk.in_dims[0] * blk.in_dims[1] * blk.in_dims[2], blk.cin))   # data gradient
+        for up in self.ups:
+            need = max(need, gen_need(N * up.y.V, up.cout), gen_need(N * up.x.V, up.cin))
         self.splitk_ws = torch.zeros(need, dtype=torch.float32, device=dev)
         self.packed_version = -1
         self.unused_heads: List[str] = []
@@ -493,8 +512,8 @@ class UNetEngine:
                         continue
                     D, H, W = item.x.dims
                     self._probed("fwd", item, lambda: nat.call(
-                        "lnn_convT3d_k2s2_fwd", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
-                        item.y.ld, nn, D, H, W, item.cin, item.cout))
+                        "lnn_convT3d_k2s2_fwd_ws", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
+                        item.y.ld, nn, D, H, W, item.cin, item.cout, splitk_ws, splitk_ws.numel()))
                 else:
                     if id(item) not in fused_segs:
                         w = self.pview(item.w) if sw is None else sw[u]
@@ -687,8 +706,8 @@ class UNetEngine:
                                      self._pn(item.panel), nn, D, H, W, C, K)
                     on_side(up_wgrad)
                     self._probed("dgrad", item, lambda: nat.call(
-                        "lnn_convT3d_k2s2_dgrad", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
-                        item.gx.ld, nn, D, H, W, C, K, 0))
+                        "lnn_convT3d_k2s2_dgrad_ws", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
+                        item.gx.ld, nn, D, H, W, C, K, 0, splitk_ws, splitk_ws.numel()))
 
         self._fork(lane)
         if side is not None:

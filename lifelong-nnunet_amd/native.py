@@ -96,6 +96,16 @@ SIGNATURES = {
     "lnn_debug_force_conv_kernel": (_i, [_i]),
     "lnn_debug_force_down2_kernel": (_i, [_i]),
     "lnn_debug_set_v9_zseg": (_i, [_i]),
+    "lnn_debug_set_gen_mode": (_i, [_i]),
+    # generic geometry (kernel extent 1 / 3 and stride 1 / 2 per axis; transposed convolutions with kernel == stride)
+    "lnn_conv3d_fwd_g": (_i, [_p, _p, _i, _p, _p, _p, _i] + [_i] * 12 + [_p, _l]),
+    "lnn_conv3d_dgrad_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 13 + [_p, _l]),
+    "lnn_conv3d_wgrad_g": (_i, [_p, _p, _i, _p, _i, _p] + [_i] * 12 + [_p, _l]),
+    "lnn_convT3d_fwd_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 9 + [_p, _l]),
+    "lnn_convT3d_dgrad_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 10 + [_p, _l]),
+    "lnn_convT3d_wgrad_g": (_i, [_p, _p, _i, _p, _i, _p] + [_i] * 9 + [_p, _l]),
+    "lnn_convT3d_k2s2_fwd_ws": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _l]),
+    "lnn_convT3d_k2s2_dgrad_ws": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l]),
 }
 
 _lib = None

@@ -19,6 +19,16 @@ def _rand(shape, seed, scale=1.0):
     return q16(torch.randn(shape, generator=g) * scale)
 
 
+@pytest.fixture(autouse=True)
+def _specialised_kernels_only():
+    """The shapes of this file are small volumes, which the isotropic entry points hand to the generic flattened-voxel kernels
+    by default (csrc/igemm_gen.hip: at most 4096 output voxels).  These tests pin the SPECIALISED kernels (tile / z-streaming /
+    LDS-DMA families); the generic ones have their own file, tests/test_gen_gpu.py."""
+    assert nat.lib().lnn_debug_set_gen_mode(0) == 0
+    yield
+    nat.lib().lnn_debug_set_gen_mode(-1)
+
+
 def test_tr16_lane_mapping():
     """ds_read_b64_tr_b16 with lane-linear addresses: within each 16-lane group the 16x4 block is
     transposed: lane i receives elements {i + 16 j} of the group's 64-half block (j = 0..3)."""

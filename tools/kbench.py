@@ -19,9 +19,11 @@ LAYERS = {  # name: (N, C, K, D, H, W, stride)
     "enc3.0s2": (2, 128, 256, 40, 48, 40, 2), "enc4.0s2": (2, 256, 320, 20, 24, 20, 2),
     "enc4.1": (2, 320, 320, 10, 12, 10, 1), "dec0.0": (2, 640, 320, 10, 12, 10, 1), "enc5.1": (2, 320, 320, 5, 6, 5, 1),
     "dec1.0": (2, 512, 256, 20, 24, 20, 1),
+    "enc5.0s2": (2, 320, 320, 10, 12, 10, 2), "enc3.1h": (2, 256, 256, 10, 12, 10, 1),
 }
 UPS = {  # transposed conv k2s2: name: (N, C, K, D, H, W) (low-res extents)
     "up4": (2, 64, 32, 80, 96, 80), "up3": (2, 128, 64, 40, 48, 40), "up2": (2, 256, 128, 20, 24, 20),
+    "up1": (2, 320, 256, 10, 12, 10), "up0": (2, 320, 320, 5, 6, 5),
 }
 
 
@@ -31,12 +33,15 @@ def main():
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--down2", type=int, default=-1, help="lnn_debug_force_down2_kernel: 0 tile kernel, 1 z-streaming kernel")
+    ap.add_argument("--gen", type=int, default=-1, help="lnn_debug_set_gen_mode: 0 never the generic flattened-voxel kernels, 1 always, -1 automatic")
     ap.add_argument("--phases", action="store_true", help="print the v3 conv kernel's per-phase cycle split")
     ap.add_argument("--check", default="", help="comma list of forced kernels (e.g. 5,9): run fwd/dgrad with each and compare outputs")
     ap.add_argument("--wgrad-phases", action="store_true", help="print the stride-1 wgrad kernel's per-phase cycle split (LNN_WGRAD_DEBUG=4)")
     a = ap.parse_args()
     dev = "cuda:0"
     nat.lib().lnn_debug_force_down2_kernel(a.down2)
+    nat.lib().lnn_debug_set_gen_mode(a.gen)
+    ws = torch.zeros(1 << 24, device=dev)          # split-K scratch the engine hands to the small layers
     wdbg = None
     if a.wgrad_phases:
         wdbg = torch.zeros(6, dtype=torch.int64, device=dev)
@@ -48,7 +53,7 @@ def main():
             x = (torch.randn((N, D, H, W, C), device=dev) * 0.5).half()
             y = torch.empty((N, 2 * D, 2 * H, 2 * W, K), dtype=torch.float16, device=dev)
             wf = torch.randn(nat.query("lnn_packed_weight_elems", 8, K, C), device=dev).half()
-            fn = lambda: nat.call("lnn_convT3d_k2s2_fwd", x, C, wf, y, K, N, D, H, W, C, K)
+            fn = lambda: nat.call("lnn_convT3d_k2s2_fwd_ws", x, C, wf, y, K, N, D, H, W, C, K, ws, ws.numel())
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -58,6 +63,17 @@ def main():
             t = e0.elapsed_time(e1) / a.iters * 1e-3
             gb = (x.numel() + y.numel()) * 2 / 1e9
             line = f"{name:9s} {C:4d}->{K:<4d} convT @{D}x{H}x{W} : fwd {t*1e3:7.3f} ms  {gb/t:6.0f} GB/s algorithmic"
+            if "dgrad" in a.which:
+                wdg = torch.randn(nat.query("lnn_packed_weight_elems", 8, C, K), device=dev).half()
+                dxx = torch.empty_like(x)
+                fd = lambda: nat.call("lnn_convT3d_k2s2_dgrad_ws", y, K, wdg, dxx, C, N, D, H, W, C, K, 0, ws, ws.numel())
+                fd(); torch.cuda.synchronize()
+                e0.record()
+                for _ in range(a.iters):
+                    fd()
+                e1.record(); torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) / a.iters * 1e-3
+                line += f" | dgrad {t*1e3:7.3f} ms"
             if "wgrad" in a.which:
                 panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 8, C, K), device=dev)
                 fw = lambda: nat.call("lnn_convT3d_k2s2_wgrad", x, C, y, K, panel, N, D, H, W, C, K)
@@ -89,8 +105,9 @@ def main():
         if cat:
             xa = x[..., :C // 2].contiguous(); xb = x[..., C // 2:].contiguous()
         fns = {"fwd": (lambda: nat.call("lnn_conv3d_fwd_cat", xa, xb, C // 2, C // 2, wf, b, y, K, N, D, H, W, C, K)) if cat else
+                      (lambda: nat.call("lnn_conv3d_fwd_g", x, C, wf, b, y, K, N, D, H, W, C, K, 3, 3, 3, s, s, s, ws, ws.numel())) if a.gen == 1 else
                       (lambda: nat.call("lnn_conv3d_fwd", x, C, wf, b, y, K, N, D, H, W, C, K, s)),
-               "dgrad": lambda: nat.call("lnn_conv3d_dgrad", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0),
+               "dgrad": lambda: nat.call("lnn_conv3d_dgrad_ws", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0, ws, ws.numel()),
                "wgrad": lambda: nat.call("lnn_conv3d_wgrad", x, C, dy, K, panel, N, D, H, W, C, K, s)}
         out = []
         for k in a.which.split(","):
