@@ -369,6 +369,25 @@ int lnn_f32_convT3d_k2s2_dgrad(lnn_stream_t s, const float* dy, int ld_dy, const
                                int D, int H, int W, int C, int K, int accumulate);
 int lnn_f32_convT3d_k2s2_wgrad(lnn_stream_t s, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N,
                                int D, int H, int W, int C, int K);
+/* generic geometry of the fp32 parity path (same meaning as the lnn_*_g entries above; weights in PyTorch's layouts
+ * (K,C,kz,ky,kx) / (Cin,Cout,sz,sy,sx)) */
+int lnn_f32_conv3d_fwd_g(lnn_stream_t s, const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, int N,
+                         int Di, int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx);
+int lnn_f32_conv3d_dgrad_g(lnn_stream_t s, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N, int Di,
+                           int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx, int accumulate);
+int lnn_f32_conv3d_wgrad_g(lnn_stream_t s, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N, int Di,
+                           int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx);
+int lnn_f32_convT3d_fwd_g(lnn_stream_t s, const float* x, int ld_x, const float* w, float* y, int ld_y, int N, int D, int H,
+                          int W, int C, int K, int sz, int sy, int sx);
+int lnn_f32_convT3d_dgrad_g(lnn_stream_t s, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N, int D,
+                            int H, int W, int C, int K, int sz, int sy, int sx, int accumulate);
+int lnn_f32_convT3d_wgrad_g(lnn_stream_t s, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N, int D,
+                            int H, int W, int C, int K, int sz, int sy, int sx);
+/* multi-channel image: (N, C, V) fp32 (the data dict's layout, nnUNetTrainerMultiHead.py:606-608) -> channels-last with channel
+ * stride ld, fp16 for the MFMA path (ld = 16: the first convolution runs with its input channels zero-padded to one 16-channel
+ * chunk) or fp32 for the parity path; channels [C, ld) are not written */
+int lnn_image_to_cl_h(lnn_stream_t s, const float* src, void* dst_h, int N, int C, long V, int ld);
+int lnn_f32_image_to_cl(lnn_stream_t s, const float* src, float* dst, int N, int C, long V, int ld);
 int lnn_f32_instnorm_lrelu_fwd(lnn_stream_t s, const float* y, int ld_y, float* z, int ld_z, int N, long V, int C, float eps,
                                float* mean, float* rstd, const float* gamma, const float* beta, float slope);
 int lnn_f32_instnorm_lrelu_bwd(lnn_stream_t s, float* y, int ld_y, const float* dz, int ld_dz, int N, long V, int C,

@@ -256,23 +256,31 @@ int launch_v7_maybe_splitk(hipStream_t s, ConvParams& p, float* ws, long ws_elem
 
 }  // namespace
 
-// Small volumes go to the flattened-voxel split-K kernels of igemm_gen.hip (see there): default = at most 4096 output voxels
-// (levels 4 and 5 of the 160x192x160 plan).
+// Small volumes go to the flattened-voxel split-K kernels of igemm_gen.hip (see there).  Which ones: measured per op on the
+// 160x192x160 plan (profiles/r04_gen_vs_tile_kernels.txt; output voxels = N x output extents):
+//   stride-1 conv fwd / dgrad   512 < voxels <= 4096   (level 4: 73 / 66 -> 54 / 53 us; level 5 stays on the split-K tile kernel: 25 us)
+//   stride-2 conv fwd / dgrad   voxels <= 4096         (enc4.0 84 -> 48 us, enc5.0 92 -> 41 us)
+//   transposed-conv dgrad       voxels <= 20000        (tu0 51 -> 26, tu1 47 -> 27, tu2 88 -> 53 us)
+//   transposed-conv fwd, every weight gradient: never (the tile kernels are as fast or faster)
+// LNN_GEN=0 forbids them (A/B measurements); lnn_debug_set_gen_mode(1 / 0) forces / forbids them for every op (parity tests).
 static int g_gen_mode = -1;      // lnn_debug_set_gen_mode: -1 automatic, 0 never, 1 wherever supported
 extern "C" int lnn_debug_set_gen_mode(int mode) {
     LNN_REQUIRE(mode >= -1 && mode <= 1, "lnn_debug_set_gen_mode: %d is not one of -1, 0, 1", mode);
     g_gen_mode = mode;
     return LNN_OK;
 }
-bool lnn_gen_prefers(long loop_voxels) {
+bool lnn_gen_prefers(int op, long voxels) {
     if (g_gen_mode >= 0) return g_gen_mode == 1;
     if (g_force_conv >= 0) return false;          // a specialised kernel is pinned by a parity test
-    static long maxvox = -1;
-    if (maxvox < 0) {
-        const char* e = getenv("LNN_GEN_MAXVOX");
-        maxvox = e ? atol(e) : 4096;
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("LNN_GEN"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off) return false;
+    switch (op) {
+        case LNN_GEN_OP_CONV_S1: return voxels > 512 && voxels <= 4096;
+        case LNN_GEN_OP_CONV_S2: return voxels <= 4096;
+        case LNN_GEN_OP_CONVT_DGRAD: return voxels <= 20000;
+        default: return false;
     }
-    return loop_voxels <= maxvox;
 }
 
 namespace {
@@ -337,7 +345,7 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         return LNN_OK;
     }
     if (int e = check_act(x, ld_x, x2 ? c_a : C, "lnn_conv3d_fwd(x)")) return e;
-    if (!x2 && lnn_gen_prefers((long)N * p.Do * p.Ho * p.Wo)) {
+    if (!x2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * p.Do * p.Ho * p.Wo)) {
         const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
         return lnn_gen_conv3d_fwd(s, x, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, k3, st3, splitk_ws, splitk_elems);
     }
@@ -422,7 +430,7 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
     if (int e = check_act(dy, ld_dy, K, "lnn_conv3d_dgrad(dy)")) return e;
     if (int e = check_act(dx, ld_dx, dx2 ? c_a : C, "lnn_conv3d_dgrad(dx)")) return e;
     const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-    if (!dx2 && lnn_gen_prefers((long)N * Di * Hi * Wi)) {
+    if (!dx2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * Di * Hi * Wi)) {
         const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
         return lnn_gen_conv3d_dgrad(s, dy, ld_dy, wp, dx, ld_dx, N, Di, Hi, Wi, C, K, k3, st3, accumulate, splitk_ws, splitk_elems);
     }
@@ -479,7 +487,7 @@ int convT3d_k2s2_fwd_impl(lnn_stream_t s_, const void* x, int ld_x, const void* 
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_convT3d_k2s2_fwd: weight panel null/misaligned");
     if (int e = check_act(x, ld_x, C, "lnn_convT3d_k2s2_fwd(x)")) return e;
     if (int e = check_act(y, ld_y, K, "lnn_convT3d_k2s2_fwd(y)")) return e;
-    if (lnn_gen_prefers((long)N * D * H * W * 8)) {
+    if (lnn_gen_prefers(LNN_GEN_OP_CONVT_FWD, (long)N * D * H * W * 8)) {
         const int st3[3] = {2, 2, 2};
         return lnn_gen_convT3d_fwd(s, x, ld_x, wp, y, ld_y, N, D, H, W, C, K, st3, ws, ws_elems);
     }
@@ -508,7 +516,7 @@ int convT3d_k2s2_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const vo
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_convT3d_k2s2_dgrad: weight panel null/misaligned");
     if (int e = check_act(dy, ld_dy, K, "lnn_convT3d_k2s2_dgrad(dy)")) return e;
     if (int e = check_act(dx, ld_dx, C, "lnn_convT3d_k2s2_dgrad(dx)")) return e;
-    if (lnn_gen_prefers((long)N * D * H * W)) {
+    if (lnn_gen_prefers(LNN_GEN_OP_CONVT_DGRAD, (long)N * D * H * W)) {
         const int st3[3] = {2, 2, 2};
         return lnn_gen_convT3d_dgrad(s, dy, ld_dy, wp, dx, ld_dx, N, D, H, W, C, K, st3, accumulate, ws, ws_elems);
     }

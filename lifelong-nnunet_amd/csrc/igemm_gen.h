@@ -64,7 +64,8 @@ int lnn_gen_conv3d_wgrad(hipStream_t s, const void* x, int ld_x, const void* dy,
                          int C, int K, const int k[3], const int st[3], float* parts, long parts_elems);
 int lnn_gen_convT3d_wgrad(hipStream_t s, const void* x, int ld_x, const void* dy, int ld_dy, float* dwp, int N, int D, int H, int W,
                           int C, int K, const int st[3], float* parts, long parts_elems);
-// true when an isotropic layer with this many loop voxels (N x output extents) should run on the generic kernels: volumes the tile
-// kernels cannot fill the chip with.  LNN_GEN_MAXVOX overrides the threshold (0 = never; A/B measurements);
-// lnn_debug_set_gen_mode(1 / 0) forces / forbids the generic kernels for every isotropic layer (parity tests).
-bool lnn_gen_prefers(long loop_voxels);
+// true when an ISOTROPIC layer of this kind and size (output voxels, N x extents) should run on the generic kernels: the volumes
+// the tile kernels cannot fill the chip with, per op as measured (rule and numbers in igemm_conv.hip).
+// lnn_debug_set_gen_mode(1 / 0) forces / forbids the generic kernels for every isotropic op (parity tests); LNN_GEN=0 forbids.
+enum { LNN_GEN_OP_CONV_S1 = 0, LNN_GEN_OP_CONV_S2 = 1, LNN_GEN_OP_CONVT_FWD = 2, LNN_GEN_OP_CONVT_DGRAD = 3, LNN_GEN_OP_WGRAD = 4 };
+bool lnn_gen_prefers(int op, long voxels);

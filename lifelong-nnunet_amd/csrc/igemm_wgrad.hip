@@ -1380,7 +1380,7 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
         return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(C=1,reduce)");
     }
     if (int e = check_act_w(x, ld_x, x2 ? c_a : C, "lnn_conv3d_wgrad(x)")) return e;
-    if (!x2 && lnn_gen_prefers((long)N * p.Ld * p.Lh * p.Lw)) {
+    if (!x2 && lnn_gen_prefers(LNN_GEN_OP_WGRAD, (long)N * p.Ld * p.Lh * p.Lw)) {
         const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
         return lnn_gen_conv3d_wgrad(s, x, ld_x, dy, ld_dy, dwp, N, Di, Hi, Wi, C, K, k3, st3, parts, parts_elems);
     }
@@ -1462,7 +1462,7 @@ int convT3d_k2s2_wgrad_impl(lnn_stream_t s_, const void* x, int ld_x, const void
     LNN_REQUIRE(dwp != nullptr, "lnn_convT3d_k2s2_wgrad: null panel");
     if (int e = check_act_w(x, ld_x, C, "lnn_convT3d_k2s2_wgrad(x)")) return e;
     if (int e = check_act_w(dy, ld_dy, K, "lnn_convT3d_k2s2_wgrad(dy)")) return e;
-    if (lnn_gen_prefers((long)N * D * H * W)) {
+    if (lnn_gen_prefers(LNN_GEN_OP_WGRAD, (long)N * D * H * W)) {
         const int st3[3] = {2, 2, 2};
         return lnn_gen_convT3d_wgrad(s, x, ld_x, dy, ld_dy, dwp, N, D, H, W, C, K, st3, parts, parts_elems);
     }

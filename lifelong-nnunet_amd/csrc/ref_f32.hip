@@ -19,11 +19,16 @@ __host__ int blocks_for_elems(long n) {
     return (int)(b < 1 ? 1 : (b > 65535L * 16 ? 65535L * 16 : b));
 }
 
-// y[n, o, k] = bias[k] + sum_{tap, c} x[n, o*stride + tap - 1, c] * w[k, c, tap]
+// per-axis geometry (round 4): kernel extents k* in {1, 3} (padding k / 2) and strides s* in {1, 2}; transposed convolutions
+// have kernel == stride.  The isotropic entry points pass {3,3,3, s,s,s} / {2,2,2, 2,2,2}.
+struct F32Geo { int kz, ky, kx, sz, sy, sx; };
+
+// y[n, o, k] = bias[k] + sum_{tap, c} x[n, o*stride + tap - pad, c] * w[k, c, tap]
 __global__ __launch_bounds__(NT) void f32_conv_fwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int ld_y, int N,
-                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int K, int stride) {
+                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int K, F32Geo g) {
     const long total = (long)N * Do * Ho * Wo * K;
+    const int T = g.kz * g.ky * g.kx;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         const int k = (int)(e % K);
         long v = e / K;
@@ -32,18 +37,18 @@ __global__ __launch_bounds__(NT) void f32_conv_fwd_kernel(const float* __restric
         const int oz = (int)(v % Do);
         const int n = (int)(v / Do);
         double acc = bias ? (double)bias[k] : 0.0;
-        for (int dz = 0; dz < 3; ++dz) {
-            const int iz = oz * stride + dz - 1;
+        for (int dz = 0; dz < g.kz; ++dz) {
+            const int iz = oz * g.sz + dz - g.kz / 2;
             if ((unsigned)iz >= (unsigned)Di) continue;
-            for (int dy = 0; dy < 3; ++dy) {
-                const int iy = oy * stride + dy - 1;
+            for (int dy = 0; dy < g.ky; ++dy) {
+                const int iy = oy * g.sy + dy - g.ky / 2;
                 if ((unsigned)iy >= (unsigned)Hi) continue;
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int ix = ox * stride + dx - 1;
+                for (int dx = 0; dx < g.kx; ++dx) {
+                    const int ix = ox * g.sx + dx - g.kx / 2;
                     if ((unsigned)ix >= (unsigned)Wi) continue;
                     const float* xp = x + ((((long)n * Di + iz) * Hi + iy) * Wi + ix) * ld_x;
-                    const float* wp = w + (long)k * C * 27 + (dz * 9 + dy * 3 + dx);
-                    for (int c = 0; c < C; ++c) acc += (double)xp[c] * (double)wp[(long)c * 27];
+                    const float* wp = w + (long)k * C * T + ((dz * g.ky + dy) * g.kx + dx);
+                    for (int c = 0; c < C; ++c) acc += (double)xp[c] * (double)wp[(long)c * T];
                 }
             }
         }
@@ -51,11 +56,12 @@ __global__ __launch_bounds__(NT) void f32_conv_fwd_kernel(const float* __restric
     }
 }
 
-// dx[n, i, c] (+)= sum_{tap, k} dy[n, o, k] * w[k, c, tap]  with  o * stride + tap - 1 == i
+// dx[n, i, c] (+)= sum_{tap, k} dy[n, o, k] * w[k, c, tap]  with  o * stride + tap - pad == i
 __global__ __launch_bounds__(NT) void f32_conv_dgrad_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ w,
                                                             float* __restrict__ dx, int ld_dx, int N, int Di, int Hi, int Wi, int Do,
-                                                            int Ho, int Wo, int C, int K, int stride, int accumulate) {
+                                                            int Ho, int Wo, int C, int K, F32Geo g, int accumulate) {
     const long total = (long)N * Di * Hi * Wi * C;
+    const int T = g.kz * g.ky * g.kx;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         const int c = (int)(e % C);
         long v = e / C;
@@ -64,18 +70,18 @@ __global__ __launch_bounds__(NT) void f32_conv_dgrad_kernel(const float* __restr
         const int iz = (int)(v % Di);
         const int n = (int)(v / Di);
         double acc = 0.0;
-        for (int dz = 0; dz < 3; ++dz) {
-            const int tz = iz + 1 - dz;
-            if (tz < 0 || tz % stride != 0 || tz / stride >= Do) continue;
-            for (int dyy = 0; dyy < 3; ++dyy) {
-                const int ty = iy + 1 - dyy;
-                if (ty < 0 || ty % stride != 0 || ty / stride >= Ho) continue;
-                for (int dxx = 0; dxx < 3; ++dxx) {
-                    const int tx = ix + 1 - dxx;
-                    if (tx < 0 || tx % stride != 0 || tx / stride >= Wo) continue;
-                    const float* gp = dy + ((((long)n * Do + tz / stride) * Ho + ty / stride) * Wo + tx / stride) * ld_dy;
-                    const float* wp = w + (long)c * 27 + (dz * 9 + dyy * 3 + dxx);
-                    for (int k = 0; k < K; ++k) acc += (double)gp[k] * (double)wp[(long)k * C * 27];
+        for (int dz = 0; dz < g.kz; ++dz) {
+            const int tz = iz + g.kz / 2 - dz;
+            if (tz < 0 || tz % g.sz != 0 || tz / g.sz >= Do) continue;
+            for (int dyy = 0; dyy < g.ky; ++dyy) {
+                const int ty = iy + g.ky / 2 - dyy;
+                if (ty < 0 || ty % g.sy != 0 || ty / g.sy >= Ho) continue;
+                for (int dxx = 0; dxx < g.kx; ++dxx) {
+                    const int tx = ix + g.kx / 2 - dxx;
+                    if (tx < 0 || tx % g.sx != 0 || tx / g.sx >= Wo) continue;
+                    const float* gp = dy + ((((long)n * Do + tz / g.sz) * Ho + ty / g.sy) * Wo + tx / g.sx) * ld_dy;
+                    const float* wp = w + (long)c * T + ((dz * g.ky + dyy) * g.kx + dxx);
+                    for (int k = 0; k < K; ++k) acc += (double)gp[k] * (double)wp[(long)k * C * T];
                 }
             }
         }
@@ -92,13 +98,14 @@ __device__ __forceinline__ double block_sum_d1(double v, double* sm) {       // 
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-// dw[k, c, tap] += sum_{n, o} dy[n, o, k] * x[n, o*stride + tap - 1, c]       (one block per (k, c, tap))
+// dw[k, c, tap] += sum_{n, o} dy[n, o, k] * x[n, o*stride + tap - pad, c]       (one block per (k, c, tap))
 __global__ __launch_bounds__(NT) void f32_conv_wgrad_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
                                                             int ld_dy, float* __restrict__ dw, int N, int Di, int Hi, int Wi, int Do,
-                                                            int Ho, int Wo, int C, int K, int stride) {
+                                                            int Ho, int Wo, int C, int K, F32Geo g) {
     __shared__ double sm[4];
-    const int tap = blockIdx.x % 27, c = (blockIdx.x / 27) % C, k = blockIdx.x / (27 * C);
-    const int dz = tap / 9, dyy = (tap / 3) % 3, dxx = tap % 3;
+    const int T = g.kz * g.ky * g.kx;
+    const int tap = blockIdx.x % T, c = (blockIdx.x / T) % C, k = blockIdx.x / (T * C);
+    const int dz = tap / (g.ky * g.kx), dyy = (tap / g.kx) % g.ky, dxx = tap % g.kx;
     const long total = (long)N * Do * Ho * Wo;
     double acc = 0.0;
     for (long v0 = threadIdx.x; v0 < total; v0 += NT) {
@@ -107,38 +114,41 @@ __global__ __launch_bounds__(NT) void f32_conv_wgrad_kernel(const float* __restr
         const int oy = (int)(v % Ho); v /= Ho;
         const int oz = (int)(v % Do);
         const int n = (int)(v / Do);
-        const int iz = oz * stride + dz - 1, iy = oy * stride + dyy - 1, ix = ox * stride + dxx - 1;
+        const int iz = oz * g.sz + dz - g.kz / 2, iy = oy * g.sy + dyy - g.ky / 2, ix = ox * g.sx + dxx - g.kx / 2;
         if ((unsigned)iz >= (unsigned)Di || (unsigned)iy >= (unsigned)Hi || (unsigned)ix >= (unsigned)Wi) continue;
         acc += (double)dy[v0 * ld_dy + k] * (double)x[((((long)n * Di + iz) * Hi + iy) * Wi + ix) * ld_x + c];
     }
     const double s = block_sum_d1(acc, sm);
-    if (threadIdx.x == 0) dw[((long)k * C + c) * 27 + tap] += (float)s;
+    if (threadIdx.x == 0) dw[((long)k * C + c) * T + tap] += (float)s;
 }
 
-// ConvTranspose3d k2 s2: y[n, 2i + a, k] = sum_c x[n, i, c] * w[c, k, a]     (a = the 2x2x2 offset)
+// ConvTranspose3d kernel == stride: y[n, s*i + a, k] = sum_c x[n, i, c] * w[c, k, a]     (a = the offset inside the s-cell)
 __global__ __launch_bounds__(NT) void f32_convT_fwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ w,
-                                                           float* __restrict__ y, int ld_y, int N, int D, int H, int W, int C, int K) {
-    const long total = (long)N * 8 * D * H * W * K;
+                                                           float* __restrict__ y, int ld_y, int N, int D, int H, int W, int C, int K,
+                                                           F32Geo g) {
+    const int T = g.sz * g.sy * g.sx, Do = D * g.sz, Ho = H * g.sy, Wo = W * g.sx;
+    const long total = (long)N * Do * Ho * Wo * K;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         const int k = (int)(e % K);
         long v = e / K;
-        const int ox = (int)(v % (2 * W)); v /= 2 * W;
-        const int oy = (int)(v % (2 * H)); v /= 2 * H;
-        const int oz = (int)(v % (2 * D));
-        const int n = (int)(v / (2 * D));
-        const int a = ((oz & 1) * 2 + (oy & 1)) * 2 + (ox & 1);
-        const float* xp = x + ((((long)n * D + (oz >> 1)) * H + (oy >> 1)) * W + (ox >> 1)) * ld_x;
-        const float* wp = w + (long)k * 8 + a;
+        const int ox = (int)(v % Wo); v /= Wo;
+        const int oy = (int)(v % Ho); v /= Ho;
+        const int oz = (int)(v % Do);
+        const int n = (int)(v / Do);
+        const int a = ((oz % g.sz) * g.sy + (oy % g.sy)) * g.sx + (ox % g.sx);
+        const float* xp = x + ((((long)n * D + oz / g.sz) * H + oy / g.sy) * W + ox / g.sx) * ld_x;
+        const float* wp = w + (long)k * T + a;
         double acc = 0.0;
-        for (int c = 0; c < C; ++c) acc += (double)xp[c] * (double)wp[(long)c * K * 8];
-        y[((((long)n * 2 * D + oz) * 2 * H + oy) * 2 * W + ox) * ld_y + k] = (float)acc;
+        for (int c = 0; c < C; ++c) acc += (double)xp[c] * (double)wp[(long)c * K * T];
+        y[((((long)n * Do + oz) * Ho + oy) * Wo + ox) * ld_y + k] = (float)acc;
     }
 }
 
-// dx[n, i, c] = sum_{a, k} dy[n, 2i + a, k] * w[c, k, a]
+// dx[n, i, c] = sum_{a, k} dy[n, s*i + a, k] * w[c, k, a]
 __global__ __launch_bounds__(NT) void f32_convT_dgrad_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ w,
                                                              float* __restrict__ dx, int ld_dx, int N, int D, int H, int W, int C, int K,
-                                                             int accumulate) {
+                                                             F32Geo g, int accumulate) {
+    const int T = g.sz * g.sy * g.sx, Ho = H * g.sy, Wo = W * g.sx, Do = D * g.sz;
     const long total = (long)N * D * H * W * C;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         const int c = (int)(e % C);
@@ -148,22 +158,24 @@ __global__ __launch_bounds__(NT) void f32_convT_dgrad_kernel(const float* __rest
         const int iz = (int)(v % D);
         const int n = (int)(v / D);
         double acc = 0.0;
-        for (int a = 0; a < 8; ++a) {
-            const int oz = 2 * iz + (a >> 2), oy = 2 * iy + ((a >> 1) & 1), ox = 2 * ix + (a & 1);
-            const float* gp = dy + ((((long)n * 2 * D + oz) * 2 * H + oy) * 2 * W + ox) * ld_dy;
-            const float* wp = w + (long)c * K * 8 + a;
-            for (int k = 0; k < K; ++k) acc += (double)gp[k] * (double)wp[(long)k * 8];
+        for (int a = 0; a < T; ++a) {
+            const int oz = g.sz * iz + a / (g.sy * g.sx), oy = g.sy * iy + (a / g.sx) % g.sy, ox = g.sx * ix + a % g.sx;
+            const float* gp = dy + ((((long)n * Do + oz) * Ho + oy) * Wo + ox) * ld_dy;
+            const float* wp = w + (long)c * K * T + a;
+            for (int k = 0; k < K; ++k) acc += (double)gp[k] * (double)wp[(long)k * T];
         }
         float* o = dx + e / C * ld_dx + c;
         *o = accumulate ? *o + (float)acc : (float)acc;
     }
 }
 
-// dw[c, k, a] += sum_{n, i} x[n, i, c] * dy[n, 2i + a, k]       (one block per (c, k, a))
+// dw[c, k, a] += sum_{n, i} x[n, i, c] * dy[n, s*i + a, k]       (one block per (c, k, a))
 __global__ __launch_bounds__(NT) void f32_convT_wgrad_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
-                                                             int ld_dy, float* __restrict__ dw, int N, int D, int H, int W, int C, int K) {
+                                                             int ld_dy, float* __restrict__ dw, int N, int D, int H, int W, int C, int K,
+                                                             F32Geo g) {
     __shared__ double sm[4];
-    const int a = blockIdx.x % 8, k = (blockIdx.x / 8) % K, c = blockIdx.x / (8 * K);
+    const int T = g.sz * g.sy * g.sx, Ho = H * g.sy, Wo = W * g.sx, Do = D * g.sz;
+    const int a = blockIdx.x % T, k = (blockIdx.x / T) % K, c = blockIdx.x / (T * K);
     const long total = (long)N * D * H * W;
     double acc = 0.0;
     for (long v0 = threadIdx.x; v0 < total; v0 += NT) {
@@ -172,11 +184,21 @@ __global__ __launch_bounds__(NT) void f32_convT_wgrad_kernel(const float* __rest
         const int iy = (int)(v % H); v /= H;
         const int iz = (int)(v % D);
         const int n = (int)(v / D);
-        const int oz = 2 * iz + (a >> 2), oy = 2 * iy + ((a >> 1) & 1), ox = 2 * ix + (a & 1);
-        acc += (double)x[v0 * ld_x + c] * (double)dy[((((long)n * 2 * D + oz) * 2 * H + oy) * 2 * W + ox) * ld_dy + k];
+        const int oz = g.sz * iz + a / (g.sy * g.sx), oy = g.sy * iy + (a / g.sx) % g.sy, ox = g.sx * ix + a % g.sx;
+        acc += (double)x[v0 * ld_x + c] * (double)dy[((((long)n * Do + oz) * Ho + oy) * Wo + ox) * ld_dy + k];
     }
     const double s = block_sum_d1(acc, sm);
-    if (threadIdx.x == 0) dw[((long)c * K + k) * 8 + a] += (float)s;
+    if (threadIdx.x == 0) dw[((long)c * K + k) * T + a] += (float)s;
+}
+
+// NCDHW fp32 image -> channels-last (stride ld, channels beyond C left untouched): fp32 copy / fp16 cast of a multi-channel input
+template <typename TO>
+__global__ __launch_bounds__(NT) void ncdhw_to_cl_kernel(const float* __restrict__ src, TO* __restrict__ dst, int N, int C, long V, int ld) {
+    const long total = (long)N * V;
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+        const long n = e / V, v = e % V;
+        for (int c = 0; c < C; ++c) dst[e * ld + c] = (TO)src[(n * C + c) * V + v];
+    }
 }
 
 // InstanceNorm statistics: one block per (n, c): mean, rstd = 1 / sqrt(biased var + eps)
@@ -310,59 +332,123 @@ __global__ __launch_bounds__(NT) void f32_seg_wgrad_kernel(const float* __restri
 
 #define F32_REQ(c, ...) LNN_REQUIRE(c, __VA_ARGS__)
 
-extern "C" int lnn_f32_conv3d_fwd(lnn_stream_t s_, const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y,
-                                  int N, int Di, int Hi, int Wi, int C, int K, int stride) {
-    F32_REQ(x && w && y && (stride == 1 || stride == 2) && ld_x >= C && ld_y >= K, "lnn_f32_conv3d_fwd: bad arguments");
-    const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+namespace {
+int f32_check_geo(const F32Geo& g, bool transposed, const char* what) {
+    const int k[3] = {g.kz, g.ky, g.kx}, st[3] = {g.sz, g.sy, g.sx};
+    for (int a = 0; a < 3; ++a) {
+        F32_REQ(st[a] == 1 || st[a] == 2, "%s: stride %d unsupported", what, st[a]);
+        if (transposed) F32_REQ(k[a] == st[a], "%s: kernel must equal stride", what);
+        else F32_REQ(k[a] == 1 || k[a] == 3, "%s: kernel extent %d unsupported", what, k[a]);
+    }
+    return LNN_OK;
+}
+}  // namespace
+
+extern "C" int lnn_f32_conv3d_fwd_g(lnn_stream_t s_, const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, int N,
+                                    int Di, int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx) {
+    const F32Geo g{kz, ky, kx, sz, sy, sx};
+    if (int e = f32_check_geo(g, false, "lnn_f32_conv3d_fwd")) return e;
+    F32_REQ(x && w && y && ld_x >= C && ld_y >= K, "lnn_f32_conv3d_fwd: bad arguments");
+    const int Do = (Di - 1) / sz + 1, Ho = (Hi - 1) / sy + 1, Wo = (Wi - 1) / sx + 1;
     hipLaunchKernelGGL(f32_conv_fwd_kernel, dim3(blocks_for_elems((long)N * Do * Ho * Wo * K)), dim3(NT), 0, (hipStream_t)s_, x, ld_x,
-                       w, bias, y, ld_y, N, Di, Hi, Wi, Do, Ho, Wo, C, K, stride);
+                       w, bias, y, ld_y, N, Di, Hi, Wi, Do, Ho, Wo, C, K, g);
     LNN_CHECK_LAUNCH("lnn_f32_conv3d_fwd");
     return LNN_OK;
 }
+extern "C" int lnn_f32_conv3d_fwd(lnn_stream_t s, const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, int N,
+                                  int Di, int Hi, int Wi, int C, int K, int stride) {
+    return lnn_f32_conv3d_fwd_g(s, x, ld_x, w, bias, y, ld_y, N, Di, Hi, Wi, C, K, 3, 3, 3, stride, stride, stride);
+}
 
-extern "C" int lnn_f32_conv3d_dgrad(lnn_stream_t s_, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N, int Di,
-                                    int Hi, int Wi, int C, int K, int stride, int accumulate) {
-    F32_REQ(dy && w && dx && (stride == 1 || stride == 2) && ld_dy >= K && ld_dx >= C, "lnn_f32_conv3d_dgrad: bad arguments");
-    const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+extern "C" int lnn_f32_conv3d_dgrad_g(lnn_stream_t s_, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N, int Di,
+                                      int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx, int accumulate) {
+    const F32Geo g{kz, ky, kx, sz, sy, sx};
+    if (int e = f32_check_geo(g, false, "lnn_f32_conv3d_dgrad")) return e;
+    F32_REQ(dy && w && dx && ld_dy >= K && ld_dx >= C, "lnn_f32_conv3d_dgrad: bad arguments");
+    const int Do = (Di - 1) / sz + 1, Ho = (Hi - 1) / sy + 1, Wo = (Wi - 1) / sx + 1;
     hipLaunchKernelGGL(f32_conv_dgrad_kernel, dim3(blocks_for_elems((long)N * Di * Hi * Wi * C)), dim3(NT), 0, (hipStream_t)s_, dy,
-                       ld_dy, w, dx, ld_dx, N, Di, Hi, Wi, Do, Ho, Wo, C, K, stride, accumulate);
+                       ld_dy, w, dx, ld_dx, N, Di, Hi, Wi, Do, Ho, Wo, C, K, g, accumulate);
     LNN_CHECK_LAUNCH("lnn_f32_conv3d_dgrad");
     return LNN_OK;
 }
+extern "C" int lnn_f32_conv3d_dgrad(lnn_stream_t s, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N, int Di,
+                                    int Hi, int Wi, int C, int K, int stride, int accumulate) {
+    return lnn_f32_conv3d_dgrad_g(s, dy, ld_dy, w, dx, ld_dx, N, Di, Hi, Wi, C, K, 3, 3, 3, stride, stride, stride, accumulate);
+}
 
-extern "C" int lnn_f32_conv3d_wgrad(lnn_stream_t s_, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N, int Di,
-                                    int Hi, int Wi, int C, int K, int stride) {
-    F32_REQ(x && dy && dw && (stride == 1 || stride == 2), "lnn_f32_conv3d_wgrad: bad arguments");
-    const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-    hipLaunchKernelGGL(f32_conv_wgrad_kernel, dim3(K * C * 27), dim3(NT), 0, (hipStream_t)s_, x, ld_x, dy, ld_dy, dw, N, Di, Hi, Wi,
-                       Do, Ho, Wo, C, K, stride);
+extern "C" int lnn_f32_conv3d_wgrad_g(lnn_stream_t s_, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N, int Di,
+                                      int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx) {
+    const F32Geo g{kz, ky, kx, sz, sy, sx};
+    if (int e = f32_check_geo(g, false, "lnn_f32_conv3d_wgrad")) return e;
+    F32_REQ(x && dy && dw, "lnn_f32_conv3d_wgrad: bad arguments");
+    const int Do = (Di - 1) / sz + 1, Ho = (Hi - 1) / sy + 1, Wo = (Wi - 1) / sx + 1;
+    hipLaunchKernelGGL(f32_conv_wgrad_kernel, dim3(K * C * kz * ky * kx), dim3(NT), 0, (hipStream_t)s_, x, ld_x, dy, ld_dy, dw, N, Di, Hi,
+                       Wi, Do, Ho, Wo, C, K, g);
     LNN_CHECK_LAUNCH("lnn_f32_conv3d_wgrad");
     return LNN_OK;
 }
+extern "C" int lnn_f32_conv3d_wgrad(lnn_stream_t s, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N, int Di,
+                                    int Hi, int Wi, int C, int K, int stride) {
+    return lnn_f32_conv3d_wgrad_g(s, x, ld_x, dy, ld_dy, dw, N, Di, Hi, Wi, C, K, 3, 3, 3, stride, stride, stride);
+}
 
-extern "C" int lnn_f32_convT3d_k2s2_fwd(lnn_stream_t s_, const float* x, int ld_x, const float* w, float* y, int ld_y, int N, int D,
+extern "C" int lnn_f32_convT3d_fwd_g(lnn_stream_t s_, const float* x, int ld_x, const float* w, float* y, int ld_y, int N, int D,
+                                     int H, int W, int C, int K, int sz, int sy, int sx) {
+    const F32Geo g{sz, sy, sx, sz, sy, sx};
+    if (int e = f32_check_geo(g, true, "lnn_f32_convT3d_fwd")) return e;
+    F32_REQ(x && w && y && ld_x >= C && ld_y >= K, "lnn_f32_convT3d_fwd: bad arguments");
+    hipLaunchKernelGGL(f32_convT_fwd_kernel, dim3(blocks_for_elems((long)N * sz * sy * sx * D * H * W * K)), dim3(NT), 0, (hipStream_t)s_, x,
+                       ld_x, w, y, ld_y, N, D, H, W, C, K, g);
+    LNN_CHECK_LAUNCH("lnn_f32_convT3d_fwd");
+    return LNN_OK;
+}
+extern "C" int lnn_f32_convT3d_k2s2_fwd(lnn_stream_t s, const float* x, int ld_x, const float* w, float* y, int ld_y, int N, int D,
                                         int H, int W, int C, int K) {
-    F32_REQ(x && w && y && ld_x >= C && ld_y >= K, "lnn_f32_convT3d_k2s2_fwd: bad arguments");
-    hipLaunchKernelGGL(f32_convT_fwd_kernel, dim3(blocks_for_elems((long)N * 8 * D * H * W * K)), dim3(NT), 0, (hipStream_t)s_, x,
-                       ld_x, w, y, ld_y, N, D, H, W, C, K);
-    LNN_CHECK_LAUNCH("lnn_f32_convT3d_k2s2_fwd");
-    return LNN_OK;
+    return lnn_f32_convT3d_fwd_g(s, x, ld_x, w, y, ld_y, N, D, H, W, C, K, 2, 2, 2);
 }
 
-extern "C" int lnn_f32_convT3d_k2s2_dgrad(lnn_stream_t s_, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N,
-                                          int D, int H, int W, int C, int K, int accumulate) {
-    F32_REQ(dy && w && dx, "lnn_f32_convT3d_k2s2_dgrad: null pointer");
+extern "C" int lnn_f32_convT3d_dgrad_g(lnn_stream_t s_, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N,
+                                       int D, int H, int W, int C, int K, int sz, int sy, int sx, int accumulate) {
+    const F32Geo g{sz, sy, sx, sz, sy, sx};
+    if (int e = f32_check_geo(g, true, "lnn_f32_convT3d_dgrad")) return e;
+    F32_REQ(dy && w && dx, "lnn_f32_convT3d_dgrad: null pointer");
     hipLaunchKernelGGL(f32_convT_dgrad_kernel, dim3(blocks_for_elems((long)N * D * H * W * C)), dim3(NT), 0, (hipStream_t)s_, dy, ld_dy,
-                       w, dx, ld_dx, N, D, H, W, C, K, accumulate);
-    LNN_CHECK_LAUNCH("lnn_f32_convT3d_k2s2_dgrad");
+                       w, dx, ld_dx, N, D, H, W, C, K, g, accumulate);
+    LNN_CHECK_LAUNCH("lnn_f32_convT3d_dgrad");
     return LNN_OK;
 }
+extern "C" int lnn_f32_convT3d_k2s2_dgrad(lnn_stream_t s, const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, int N,
+                                          int D, int H, int W, int C, int K, int accumulate) {
+    return lnn_f32_convT3d_dgrad_g(s, dy, ld_dy, w, dx, ld_dx, N, D, H, W, C, K, 2, 2, 2, accumulate);
+}
 
-extern "C" int lnn_f32_convT3d_k2s2_wgrad(lnn_stream_t s_, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N,
+extern "C" int lnn_f32_convT3d_wgrad_g(lnn_stream_t s_, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N,
+                                       int D, int H, int W, int C, int K, int sz, int sy, int sx) {
+    const F32Geo g{sz, sy, sx, sz, sy, sx};
+    if (int e = f32_check_geo(g, true, "lnn_f32_convT3d_wgrad")) return e;
+    F32_REQ(x && dy && dw, "lnn_f32_convT3d_wgrad: null pointer");
+    hipLaunchKernelGGL(f32_convT_wgrad_kernel, dim3(C * K * sz * sy * sx), dim3(NT), 0, (hipStream_t)s_, x, ld_x, dy, ld_dy, dw, N, D, H, W,
+                       C, K, g);
+    LNN_CHECK_LAUNCH("lnn_f32_convT3d_wgrad");
+    return LNN_OK;
+}
+extern "C" int lnn_f32_convT3d_k2s2_wgrad(lnn_stream_t s, const float* x, int ld_x, const float* dy, int ld_dy, float* dw, int N,
                                           int D, int H, int W, int C, int K) {
-    F32_REQ(x && dy && dw, "lnn_f32_convT3d_k2s2_wgrad: null pointer");
-    hipLaunchKernelGGL(f32_convT_wgrad_kernel, dim3(C * K * 8), dim3(NT), 0, (hipStream_t)s_, x, ld_x, dy, ld_dy, dw, N, D, H, W, C, K);
-    LNN_CHECK_LAUNCH("lnn_f32_convT3d_k2s2_wgrad");
+    return lnn_f32_convT3d_wgrad_g(s, x, ld_x, dy, ld_dy, dw, N, D, H, W, C, K, 2, 2, 2);
+}
+
+/* (N, C, V) fp32 -> channels-last with channel stride ld: fp16 (the MFMA path's multi-channel image; ld = 16, the channels beyond C
+ * stay zero) or fp32 (the parity path).  Replaces the implicit layout of torch's NCDHW conv input. */
+extern "C" int lnn_image_to_cl_h(lnn_stream_t s_, const float* src, void* dst_h, int N, int C, long V, int ld) {
+    F32_REQ(src && dst_h && C >= 1 && ld >= C, "lnn_image_to_cl_h: bad arguments");
+    hipLaunchKernelGGL((ncdhw_to_cl_kernel<half_t>), dim3(blocks_for_elems((long)N * V)), dim3(NT), 0, (hipStream_t)s_, src, (half_t*)dst_h, N, C, V, ld);
+    LNN_CHECK_LAUNCH("lnn_image_to_cl_h");
+    return LNN_OK;
+}
+extern "C" int lnn_f32_image_to_cl(lnn_stream_t s_, const float* src, float* dst, int N, int C, long V, int ld) {
+    F32_REQ(src && dst && C >= 1 && ld >= C, "lnn_f32_image_to_cl: bad arguments");
+    hipLaunchKernelGGL((ncdhw_to_cl_kernel<float>), dim3(blocks_for_elems((long)N * V)), dim3(NT), 0, (hipStream_t)s_, src, dst, N, C, V, ld);
+    LNN_CHECK_LAUNCH("lnn_f32_image_to_cl");
     return LNN_OK;
 }
 

@@ -64,11 +64,17 @@ class ParamSlot:
 
 @dataclass
 class ConvBlock:
-    """conv3x3x3(+bias) -> InstanceNorm(affine) -> LeakyReLU (ConvDropoutNormNonlin, dropout p=0 omitted)."""
+    """conv(+bias) -> InstanceNorm(affine) -> LeakyReLU (ConvDropoutNormNonlin, dropout p=0 omitted).  ``kernel`` / ``strides``:
+    per-axis extents from the plans (3x3x3 and stride 1 or 2 everywhere in the isotropic plans); ``stride`` is the common
+    stride of an isotropic block (the specialised kernels), 0 otherwise (the generic-geometry kernels, csrc/igemm_gen.hip)."""
     prefix: str
     cin: int
     cout: int
     stride: int
+    kernel: tuple = (3, 3, 3)
+    strides: tuple = (1, 1, 1)
+    cin_k: int = 0                 # channels of the input as the kernels see it (a multi-channel image is zero-padded to 16)
+    first: bool = False            # the network's first convolution (no data gradient)
     x: Optional[Act] = None        # input activation (None -> the fp16 image, C == 1 path)
     gx: Optional[Act] = None       # gradient wrt input (None -> not needed)
     gx_accumulate: bool = False
@@ -88,13 +94,22 @@ class ConvBlock:
     panel: int = 0
     in_dims: tuple = ()
 
+    @property
+    def iso(self):
+        return self.stride != 0
+
+    @property
+    def ntaps(self):
+        return self.kernel[0] * self.kernel[1] * self.kernel[2]
+
 
 @dataclass
 class UpBlock:
-    """ConvTranspose3d k2 s2, no bias (``tu``)."""
+    """ConvTranspose3d with kernel == stride == the pooling of its level, no bias (``tu``)."""
     prefix: str
     cin: int
     cout: int
+    strides: tuple = (2, 2, 2)
     x: Act = None
     gx: Act = None
     y: Act = None
@@ -103,6 +118,14 @@ class UpBlock:
     wp_fwd: int = 0
     wp_dgrad: int = 0
     panel: int = 0
+
+    @property
+    def iso(self):
+        return tuple(self.strides) == (2, 2, 2)
+
+    @property
+    def ntaps(self):
+        return self.strides[0] * self.strides[1] * self.strides[2]
 
 
 @dataclass
@@ -146,28 +169,52 @@ class ParamArena:
         return getattr(self, which)[s.offset:s.offset + s.numel].view(s.shape)
 
 
-def param_slots(in_channels, base_features, num_classes, num_pool, max_features=320) -> List[ParamSlot]:
+def unet_geometry(num_pool, patch_size=None, pool_op_kernel_sizes=None, conv_kernel_sizes=None):
+    """(pools, kernels, dims) of a plan: ``pool_op_kernel_sizes`` (num_pool per-axis strides, default 2x2x2), ``conv_kernel_sizes``
+    (num_pool + 1 per-axis kernel extents, default 3x3x3) as the reference hands them to Generic_UNet
+    (nnUNetTrainerMultiHead.py:348-369 -> nnViTUNetTrainer.py:117-122), and the spatial extents of every level for ``patch_size``.
+    Upstream Generic_UNet (nnunet @77bc485): encoder stage d uses kernel d and the stride of pooling d - 1 in its first block;
+    the bottleneck kernel num_pool and pooling num_pool - 1; decoder stage u the transposed convolution of pooling -(u + 1) and
+    -- as upstream indexes it -- conv kernel -(u + 1), i.e. the kernel of the encoder stage ONE LEVEL BELOW its resolution."""
+    pools = [tuple(int(v) for v in q) for q in (pool_op_kernel_sizes if pool_op_kernel_sizes is not None else [(2, 2, 2)] * num_pool)]
+    kernels = [tuple(int(v) for v in q) for q in (conv_kernel_sizes if conv_kernel_sizes is not None else [(3, 3, 3)] * (num_pool + 1))]
+    assert len(pools) == num_pool and len(kernels) == num_pool + 1, "one pooling per level, one conv kernel per stage (+ bottleneck)"
+    assert all(v in (1, 2) for q in pools for v in q), "pool_op_kernel_sizes entries must be 1 or 2"
+    assert all(v in (1, 3) for q in kernels for v in q), "conv_kernel_sizes entries must be 1 or 3"
+    dims = None
+    if patch_size is not None:
+        dims = [tuple(int(v) for v in patch_size)]
+        for d in range(num_pool):
+            assert all(dims[d][a] % pools[d][a] == 0 for a in range(3)), \
+                f"patch size {tuple(patch_size)} must be divisible by the cumulative pooling strides"
+            dims.append(tuple(dims[d][a] // pools[d][a] for a in range(3)))
+    return pools, kernels, dims
+
+
+def param_slots(in_channels, base_features, num_classes, num_pool, max_features=320, pool_op_kernel_sizes=None,
+                conv_kernel_sizes=None) -> List[ParamSlot]:
     """Parameter tensors of Generic_UNet in FORWARD EXECUTION order (names as test_MultiHead_Module.py:282-431)."""
     feats = [min(base_features * 2 ** d, max_features) for d in range(num_pool + 1)]
+    pools, kernels, _ = unet_geometry(num_pool, None, pool_op_kernel_sizes, conv_kernel_sizes)
     out = []
 
-    def block(prefix, cin, cout):
-        out.extend([ParamSlot(prefix + ".conv.weight", (cout, cin, 3, 3, 3)), ParamSlot(prefix + ".conv.bias", (cout,)),
+    def block(prefix, cin, cout, k):
+        out.extend([ParamSlot(prefix + ".conv.weight", (cout, cin) + tuple(k)), ParamSlot(prefix + ".conv.bias", (cout,)),
                     ParamSlot(prefix + ".instnorm.weight", (cout,)), ParamSlot(prefix + ".instnorm.bias", (cout,))])
 
     cin = in_channels
     for d in range(num_pool):
-        block(f"conv_blocks_context.{d}.blocks.0", cin, feats[d])
-        block(f"conv_blocks_context.{d}.blocks.1", feats[d], feats[d])
+        block(f"conv_blocks_context.{d}.blocks.0", cin, feats[d], kernels[d])
+        block(f"conv_blocks_context.{d}.blocks.1", feats[d], feats[d], kernels[d])
         cin = feats[d]
-    block(f"conv_blocks_context.{num_pool}.0.blocks.0", cin, feats[num_pool])
-    block(f"conv_blocks_context.{num_pool}.1.blocks.0", feats[num_pool], feats[num_pool])
+    block(f"conv_blocks_context.{num_pool}.0.blocks.0", cin, feats[num_pool], kernels[num_pool])
+    block(f"conv_blocks_context.{num_pool}.1.blocks.0", feats[num_pool], feats[num_pool], kernels[num_pool])
     cdown = feats[num_pool]
     for u in range(num_pool):
         cs = feats[num_pool - 1 - u]
-        out.append(ParamSlot(f"tu.{u}.weight", (cdown, cs, 2, 2, 2)))
-        block(f"conv_blocks_localization.{u}.0.blocks.0", 2 * cs, cs)
-        block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs)
+        out.append(ParamSlot(f"tu.{u}.weight", (cdown, cs) + pools[-(u + 1)]))
+        block(f"conv_blocks_localization.{u}.0.blocks.0", 2 * cs, cs, kernels[-(u + 1)])
+        block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, kernels[-(u + 1)])
         out.append(ParamSlot(f"seg_outputs.{u}.weight", (num_classes, cs, 1, 1, 1)))
         cdown = cs
     return out
@@ -175,21 +222,24 @@ def param_slots(in_channels, base_features, num_classes, num_pool, max_features=
 
 class UNetEngine:
     def __init__(self, arena: ParamArena, in_channels, base_features, num_classes, num_pool, patch_size, batch_size,
-                 device="cuda", max_features=320, conv_per_stage=2):
+                 device="cuda", max_features=320, conv_per_stage=2, pool_op_kernel_sizes=None, conv_kernel_sizes=None):
         assert conv_per_stage == 2, "nnUNetTrainerV2 uses conv_per_stage=2 (nnViTUNetTrainer.py:119)"
-        assert in_channels == 1, "the build's image path handles single-modality input (BASELINE configs)"
         assert base_features % 8 == 0, "channel counts must be multiples of 8 (16-byte vectors)"
         self.arena = arena
-        for p in patch_size:
-            assert p % (2 ** num_pool) == 0, "patch size must be divisible by 2^num_pool"
+        pools, kernels, dims = unet_geometry(num_pool, patch_size, pool_op_kernel_sizes, conv_kernel_sizes)
+        self.pools, self.kernels = pools, kernels
         self.in_channels, self.base, self.K, self.num_pool = in_channels, base_features, num_classes, num_pool
         self.patch, self.N, self.device = tuple(patch_size), batch_size, torch.device(device)
         self.max_features = max_features
         dev, N = self.device, batch_size
 
         feats = [min(base_features * 2 ** d, max_features) for d in range(num_pool + 1)]
-        dims = [tuple(p // 2 ** d for p in patch_size) for d in range(num_pool + 1)]
         self.feats, self.dims = feats, dims
+        # the first convolution: C == 1 with a 3x3x3 kernel has its own kernels (taps are the contraction); any other input
+        # (several modalities, an anisotropic first kernel) becomes a channels-last fp16 image zero-padded to a multiple of 16
+        # channels and runs as an ordinary block (the weight panel pads the same channels with zeros)
+        self.c1_path = in_channels == 1 and kernels[0] == (3, 3, 3)
+        self.cin_pad = in_channels if in_channels % 8 == 0 else -(-in_channels // 16) * 16
 
         # ---- concat buffers (one per decoder level u; level u sits at encoder depth d = num_pool-1-u).
         # torch.cat((up, skip), 1) (generic_ViT_UNet.py:263) is never executed: producers write straight into the two
@@ -200,7 +250,9 @@ class UNetEngine:
         self.cat, self.gcat, self.split_cat = [], [], []
         for u in range(num_pool):
             d = num_pool - 1 - u
-            split = feats[d] % 32 == 0 and feats[d] * 2 <= 64 and os.environ.get("LNN_NO_SPLIT_CAT", "0") != "1"
+            # (the two-tensor form exists in the specialised 3x3x3 kernels only; the decoder stage u convolves with kernel -(u + 1))
+            split = feats[d] % 32 == 0 and feats[d] * 2 <= 64 and os.environ.get("LNN_NO_SPLIT_CAT", "0") != "1" and \
+                kernels[-(u + 1)] == (3, 3, 3)
             self.split_cat.append(split)
             if split:
                 self.cat.append((_cl(N, dims[d], feats[d], dev), _cl(N, dims[d], feats[d], dev)))
@@ -209,15 +261,18 @@ class UNetEngine:
                 self.cat.append(_cl(N, dims[d], 2 * feats[d], dev))
                 self.gcat.append(_cl(N, dims[d], 2 * feats[d], dev))
 
-        self.image = torch.zeros((N,) + dims[0], dtype=torch.float16, device=dev)
+        self.image = torch.zeros((N,) + dims[0] + (() if self.c1_path else (self.cin_pad,)), dtype=torch.float16, device=dev)
         self.blocks: List[ConvBlock] = []
         self.ups: List[UpBlock] = []
         self.segs: List[SegHead] = []
         order: List[object] = []     # forward execution order
 
-        def new_block(prefix, cin, cout, stride, x, gx, gx_acc, z_target, gz_target, in_dims):
-            od = tuple((s - 1) // stride + 1 for s in in_dims)
-            blk = ConvBlock(prefix, cin, cout, stride, x=x, gx=gx, gx_accumulate=gx_acc, in_dims=in_dims)
+        def new_block(prefix, cin, cout, strides, kernel, x, gx, gx_acc, z_target, gz_target, in_dims):
+            strides, kernel = tuple(strides), tuple(kernel)
+            od = tuple((s - 1) // st + 1 for s, st in zip(in_dims, strides))
+            iso = kernel == (3, 3, 3) and strides in ((1, 1, 1), (2, 2, 2))
+            blk = ConvBlock(prefix, cin, cout, strides[0] if iso else 0, kernel=kernel, strides=strides, cin_k=cin, x=x, gx=gx,
+                            gx_accumulate=gx_acc, in_dims=in_dims)
             blk.y = _cl(N, od, cout, dev)
             if z_target is None:
                 zb, gzb = _cl(N, od, cout, dev), _cl(N, od, cout, dev)
@@ -230,13 +285,14 @@ class UNetEngine:
             blk.b = arena.by_name[prefix + ".conv.bias"]
             blk.gamma = arena.by_name[prefix + ".instnorm.weight"]
             blk.beta = arena.by_name[prefix + ".instnorm.bias"]
-            assert blk.w.shape == (cout, cin, 3, 3, 3)
+            assert blk.w.shape == (cout, cin) + kernel, f"{prefix}: parameter arena built for another plan"
             self.blocks.append(blk)
             order.append(blk)
             return blk
 
         # ---- encoder
-        x, gx = None, None
+        one = (1, 1, 1)
+        x, gx = (None, None) if self.c1_path else (Act(self.image, 0, self.cin_pad), None)
         cin = in_channels
         for d in range(num_pool):
             u = num_pool - 1 - d
@@ -246,15 +302,19 @@ class UNetEngine:
                 skip = Act(self.cat[u], feats[d], feats[d])
                 gskip = Act(self.gcat[u], feats[d], feats[d])
             in_dims = dims[d - 1] if d > 0 else dims[0]
-            b0 = new_block(f"conv_blocks_context.{d}.blocks.0", cin, feats[d], 2 if d > 0 else 1,
+            b0 = new_block(f"conv_blocks_context.{d}.blocks.0", cin, feats[d], pools[d - 1] if d > 0 else one, kernels[d],
                            x, gx, d > 0, None, None, in_dims)
-            b1 = new_block(f"conv_blocks_context.{d}.blocks.1", feats[d], feats[d], 1, b0.z, b0.gz, False,
+            if d == 0:
+                b0.first = True
+                b0.cin_k = 1 if self.c1_path else self.cin_pad
+            b1 = new_block(f"conv_blocks_context.{d}.blocks.1", feats[d], feats[d], one, kernels[d], b0.z, b0.gz, False,
                            skip, gskip, dims[d])
             x, gx, cin = b1.z, b1.gz, feats[d]
         # ---- bottleneck: Sequential(Stacked(1 strided conv), Stacked(1 conv))  (test_MultiHead_Module.py:394-415)
         nb = num_pool
-        b0 = new_block(f"conv_blocks_context.{nb}.0.blocks.0", cin, feats[nb], 2, x, gx, True, None, None, dims[nb - 1])
-        b1 = new_block(f"conv_blocks_context.{nb}.1.blocks.0", feats[nb], feats[nb], 1, b0.z, b0.gz, False, None, None,
+        b0 = new_block(f"conv_blocks_context.{nb}.0.blocks.0", cin, feats[nb], pools[nb - 1], kernels[nb], x, gx, True, None, None,
+                       dims[nb - 1])
+        b1 = new_block(f"conv_blocks_context.{nb}.1.blocks.0", feats[nb], feats[nb], one, kernels[nb], b0.z, b0.gz, False, None, None,
                        dims[nb])
         x, gx, cdown = b1.z, b1.gz, feats[nb]
         # ---- decoder
@@ -267,15 +327,17 @@ class UNetEngine:
             else:
                 up_y, up_gy = Act(self.cat[u], 0, cs), Act(self.gcat[u], 0, cs)
                 cat_act, gcat_act = Act(self.cat[u], 0, 2 * cs), Act(self.gcat[u], 0, 2 * cs)
-            up = UpBlock(f"tu.{u}", cdown, cs, x=x, gx=gx, y=up_y, gy=up_gy)
+            up = UpBlock(f"tu.{u}", cdown, cs, strides=pools[-(u + 1)], x=x, gx=gx, y=up_y, gy=up_gy)
             up.w = arena.by_name[f"tu.{u}.weight"]
+            assert up.w.shape == (cdown, cs) + pools[-(u + 1)], f"tu.{u}: parameter arena built for another plan"
             self.ups.append(up)
             order.append(up)
-            b0 = new_block(f"conv_blocks_localization.{u}.0.blocks.0", 2 * cs, cs, 1, cat_act, gcat_act, False,
+            b0 = new_block(f"conv_blocks_localization.{u}.0.blocks.0", 2 * cs, cs, one, kernels[-(u + 1)], cat_act, gcat_act, False,
                            None, None, dims[d])
             if self.split_cat[u]:
                 b0.x2, b0.gx2 = Act(self.cat[u][1], 0, cs), Act(self.gcat[u][1], 0, cs)
-            b1 = new_block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, 1, b0.z, b0.gz, False, None, None, dims[d])
+            b1 = new_block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, one, kernels[-(u + 1)], b0.z, b0.gz, False, None, None,
+                           dims[d])
             seg = SegHead(f"seg_outputs.{u}", cs, x=b1.z, gx=b1.gz, gx_has_prior=(u < num_pool - 1))
             seg.x_block = b1
             seg.w = arena.by_name[f"seg_outputs.{u}.weight"]
@@ -292,17 +354,19 @@ class UNetEngine:
         wp_off, pn_off = 0, 0
         for item in order:
             if isinstance(item, ConvBlock):
-                if item.cin == 1:
+                nt = item.ntaps
+                if item.cin_k == 1:
                     item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 1, item.cout, 27)
                     item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", 1, item.cout, 27)
                 else:
-                    item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 27, item.cout, item.cin)
-                    item.wp_dgrad = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 27, item.cin, item.cout)
-                    item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", 27, item.cout, item.cin)
+                    item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", nt, item.cout, item.cin)
+                    item.wp_dgrad = wp_off; wp_off += nat.query("lnn_packed_weight_elems", nt, item.cin, item.cout)
+                    item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", nt, item.cout, item.cin)
             elif isinstance(item, UpBlock):
-                item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 8, item.cout, item.cin)
-                item.wp_dgrad = wp_off; wp_off += nat.query("lnn_packed_weight_elems", 8, item.cin, item.cout)
-                item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", 8, item.cin, item.cout)
+                nt = item.ntaps
+                item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", nt, item.cout, item.cin)
+                item.wp_dgrad = wp_off; wp_off += nat.query("lnn_packed_weight_elems", nt, item.cin, item.cout)
+                item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", nt, item.cin, item.cout)
             wp_off = (wp_off + 7) // 8 * 8
             pn_off = (pn_off + 3) // 4 * 4
         self.wpanels = torch.zeros(wp_off, dtype=torch.float16, device=dev)
@@ -324,19 +388,19 @@ class UNetEngine:
 
         for item in order:
             if isinstance(item, ConvBlock):
-                K, C = item.cout, item.cin
-                if C == 1:
+                K, C, nt = item.cout, item.cin, item.ntaps
+                if item.cin_k == 1:
                     add_pack(item.w, item.wp_fwd, 1, K, 27, 27, 1, 0)
                     add_unpack(item.w, item.panel, 1, K, 27, 27, 1, 0)
                 else:
-                    add_pack(item.w, item.wp_fwd, 27, K, C, C * 27, 27, 1)
-                    add_pack(item.w, item.wp_dgrad, 27, C, K, 27, C * 27, 1)
-                    add_unpack(item.w, item.panel, 27, K, C, C * 27, 27, 1)
+                    add_pack(item.w, item.wp_fwd, nt, K, C, C * nt, nt, 1)
+                    add_pack(item.w, item.wp_dgrad, nt, C, K, nt, C * nt, 1)
+                    add_unpack(item.w, item.panel, nt, K, C, C * nt, nt, 1)
             elif isinstance(item, UpBlock):
-                C, K = item.cin, item.cout
-                add_pack(item.w, item.wp_fwd, 8, K, C, 8, K * 8, 1)
-                add_pack(item.w, item.wp_dgrad, 8, C, K, K * 8, 8, 1)
-                add_unpack(item.w, item.panel, 8, C, K, K * 8, 8, 1)
+                C, K, nt = item.cin, item.cout, item.ntaps
+                add_pack(item.w, item.wp_fwd, nt, K, C, nt, K * nt, 1)
+                add_pack(item.w, item.wp_dgrad, nt, C, K, K * nt, nt, 1)
+                add_unpack(item.w, item.panel, nt, C, K, K * nt, nt, 1)
         self._pack_desc = torch.tensor(pk, dtype=torch.int64, device=dev)
         self._unpack_desc = torch.tensor(up, dtype=torch.int64, device=dev)
         self._pack_total, self._unpack_total = pk_total, up_total
@@ -350,7 +414,7 @@ class UNetEngine:
         # 64 ways: room for min(64, 2048 waves / their unsplit wave count) slices of every such output
         need = 1
         for blk in self.blocks:
-            if blk.stride != 1 or blk.cin == 1:
+            if blk.stride != 1 or blk.cin_k == 1:
                 continue
             od = blk.in_dims
             vox = N * od[0] * od[1] * od[2]
@@ -359,22 +423,23 @@ class UNetEngine:
                 if tiles * -(-ch // 32) < 512:
                     need = max(need, 8 * vox * (-(-ch // 32) * 32))
 
-        def gen_need(vox, ch):
-            if vox > 4096:
+        def gen_need(vox, ch, classes=1, always=False):
+            if vox > 4096 and not always:                 # (isotropic layers above the threshold stay on the specialised kernels)
                 return 1
             mp = -(-ch // 32) * 32
-            waves = -(-vox // 64) * -(-mp // 64)
+            waves = classes * -(-(vox // classes) // 64) * -(-mp // 64)
             ks = 1
             while waves * ks * 2 <= 2048 and ks < 64:
                 ks *= 2
-            return ks * vox * mp
+            return ks * vox * mp if ks > 1 else 1
         for blk in self.blocks:
-            if blk.cin == 1:
+            if blk.cin_k == 1:
                 continue
-            need = max(need, gen_need(N * blk.z.V, blk.cout))                                     # forward
-            need = max(need, gen_need(N * blk.in_dims[0] * blk.in_dims[1] * blk.in_dims[2], blk.cin))   # data gradient
+            ncls = blk.strides[0] * blk.strides[1] * blk.strides[2]
+            need = max(need, gen_need(N * blk.z.V, blk.cout, 1, not blk.iso))                                     # forward
+            need = max(need, gen_need(N * blk.in_dims[0] * blk.in_dims[1] * blk.in_dims[2], blk.cin_k, ncls, not blk.iso))   # data gradient
         for up in self.ups:
-            need = max(need, gen_need(N * up.y.V, up.cout), gen_need(N * up.x.V, up.cin))
+            need = max(need, gen_need(N * up.y.V, up.cout, up.ntaps, not up.iso), gen_need(N * up.x.V, up.cin, 1, not up.iso))
         self.splitk_ws = torch.zeros(need, dtype=torch.float32, device=dev)
         self.packed_version = -1
         self.unused_heads: List[str] = []
@@ -458,11 +523,15 @@ class UNetEngine:
         parameters (used to evaluate several heads on one body pass); ``body=False`` reuses the stored
         body activations."""
         N = self.N
-        assert tuple(x.shape) == (N, 1) + self.patch, f"engine built for {(N, 1) + self.patch}, got {tuple(x.shape)}"
+        assert tuple(x.shape) == (N, self.in_channels) + self.patch, \
+            f"engine built for {(N, self.in_channels) + self.patch}, got {tuple(x.shape)}"
         if self.packed_version != self.arena.version:
             self.pack_weights()
         if body:
-            nat.call("lnn_cast_f32_to_h", x.contiguous(), self.image, x.numel())
+            if self.c1_path:
+                nat.call("lnn_cast_f32_to_h", x.contiguous(), self.image, x.numel())
+            else:       # (N, C, D, H, W) fp32 -> channels-last fp16, channels [C, cin_pad) stay zero
+                nat.call("lnn_image_to_cl_h", x.contiguous(), self.image, N, self.in_channels, x[0, 0].numel(), self.cin_pad)
         logits = [torch.empty((N, self.K) + seg.x.dims, device=self.device) for seg in self.segs]
         sw = None if seg_weights is None else [w.contiguous() for w in seg_weights]
         at = self._at
@@ -480,20 +549,26 @@ class UNetEngine:
                     C = item.cout
                     V = item.z.V
                     mean, rstd = item.mean[n0 * C:], item.rstd[n0 * C:]
-                    if self.fuse_in_stats:
+                    if not item.iso:
+                        # per-axis kernel / stride from the plans: generic-geometry kernel, statistics as a separate pass
+                        self._probed("fwd", item, lambda: nat.call(
+                            "lnn_conv3d_fwd_g", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C, nn, D, H, W,
+                            item.cin_k, C, *item.kernel, *item.strides, splitk_ws, splitk_ws.numel()))
+                        nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
+                    elif self.fuse_in_stats:
                         # conv + InstanceNorm statistics in one call (the z-streaming kernel sums in its epilogue)
                         self._probed("fwd", item, lambda: nat.call(
                             "lnn_conv3d_fwd_in_stats", xin, None if item.x2 is None else at(item.x2, n0), ldx,
                             item.x.C if item.x2 is not None else 0, self._wp(item.wp_fwd), self.pview(item.b),
-                            at(item.y, n0), nn, D, H, W, item.cin, C, item.stride, IN_EPS, mean, rstd, ws,
+                            at(item.y, n0), nn, D, H, W, item.cin_k, C, item.stride, IN_EPS, mean, rstd, ws,
                             splitk_ws, splitk_ws.numel()))
                     else:
                         if item.x2 is not None:
                             nat.call("lnn_conv3d_fwd_cat", xin, at(item.x2, n0), ldx, item.x.C, self._wp(item.wp_fwd),
-                                     self.pview(item.b), at(item.y, n0), C, nn, D, H, W, item.cin, C)
+                                     self.pview(item.b), at(item.y, n0), C, nn, D, H, W, item.cin_k, C)
                         else:
                             nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
-                                     nn, D, H, W, item.cin, C, item.stride)
+                                     nn, D, H, W, item.cin_k, C, item.stride)
                         nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
                     seg = self._seg_after.get(id(item))
                     if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
@@ -511,9 +586,14 @@ class UNetEngine:
                     if not body:
                         continue
                     D, H, W = item.x.dims
-                    self._probed("fwd", item, lambda: nat.call(
-                        "lnn_convT3d_k2s2_fwd_ws", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
-                        item.y.ld, nn, D, H, W, item.cin, item.cout, splitk_ws, splitk_ws.numel()))
+                    if item.iso:
+                        self._probed("fwd", item, lambda: nat.call(
+                            "lnn_convT3d_k2s2_fwd_ws", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
+                            item.y.ld, nn, D, H, W, item.cin, item.cout, splitk_ws, splitk_ws.numel()))
+                    else:
+                        self._probed("fwd", item, lambda: nat.call(
+                            "lnn_convT3d_fwd_g", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
+                            item.y.ld, nn, D, H, W, item.cin, item.cout, *item.strides, splitk_ws, splitk_ws.numel()))
                 else:
                     if id(item) not in fused_segs:
                         w = self.pview(item.w) if sw is None else sw[u]
@@ -582,16 +662,17 @@ class UNetEngine:
         per_layer_unpack = progress is not None
 
         def unpack(item):
+            nt = item.ntaps
             if isinstance(item, ConvBlock):
                 K, C = item.cout, item.cin
                 gw = self.pview(item.w, self.grad)
-                if C == 1:
+                if item.cin_k == 1:
                     nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 1, K, 27, 27, 1, 0, 1.0, 1)
                 else:
-                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 27, K, C, C * 27, 27, 1, 1.0, 1)
+                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, nt, K, C, C * nt, nt, 1, 1.0, 1)
             else:
                 C, K = item.cin, item.cout
-                nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), 8, C, K, K * 8, 8, 1, 1.0, 1)
+                nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), nt, C, K, K * nt, nt, 1, 1.0, 1)
 
         fuse_seg = self.fuse_seg_bwd and not skip_body and not self.numeric_conv_bias_grad and self.K <= 4
 
@@ -621,7 +702,7 @@ class UNetEngine:
                 elif skip_body:
                     continue
                 elif isinstance(item, ConvBlock):
-                    V, K, C = item.z.V, item.cout, item.cin
+                    V, K, C = item.z.V, item.cout, item.cin_k
                     if id(item) in pending:
                         seg, dl = pending.pop(id(item))
                         self._probed("in_bwd", item, lambda: nat.call(
@@ -629,7 +710,7 @@ class UNetEngine:
                             item.gz.ld, self.pview(seg.w), dl[n0:], self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
                             nn, V, K, item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta),
                             LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
-                    elif item.x is None and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
+                    elif item.cin_k == 1 and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
                         # the first block has no data gradient: only the sums of its normalisation backward are taken here,
                         # dy is rebuilt tile by tile inside the weight gradient below (lnn_conv3d_wgrad_c1_in_bwd)
                         self._probed("in_bwd", item, lambda: nat.call(
@@ -665,7 +746,10 @@ class UNetEngine:
 
                     def conv_wgrad_call(item, xin, ldx, K, C, D, H, W):
                         det = self._det_scratch()
-                        if item.x2 is not None and det is not None:
+                        if not item.iso:
+                            nat.call("lnn_conv3d_wgrad_g", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
+                                     *item.kernel, *item.strides, det, 0 if det is None else det.numel())
+                        elif item.x2 is not None and det is not None:
                             nat.call("lnn_conv3d_wgrad_cat_det", xin, at(item.x2, n0), ldx, item.x.C, at(item.y, n0), K,
                                      self._pn(item.panel), nn, D, H, W, C, K, det, det.numel())
                         elif item.x2 is not None:
@@ -678,11 +762,18 @@ class UNetEngine:
                             nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
                                      item.stride)
                     on_side(conv_wgrad)
-                    if C != 1 and item.gx is not None and item.gx2 is not None:
+                    if item.first or item.gx is None:
+                        pass                                   # the first convolution has no data gradient
+                    elif not item.iso:
+                        self._probed("dgrad", item, lambda: nat.call(
+                            "lnn_conv3d_dgrad_g", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
+                            nn, D, H, W, C, K, *item.kernel, *item.strides, 1 if item.gx_accumulate else 0, splitk_ws,
+                            splitk_ws.numel()))
+                    elif item.gx2 is not None:
                         self._probed("dgrad", item, lambda: nat.call(
                             "lnn_conv3d_dgrad_cat", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0),
                             at(item.gx2, n0), item.gx.ld, item.gx.C, nn, D, H, W, C, K, 1 if item.gx_accumulate else 0))
-                    elif C != 1 and item.gx is not None:
+                    else:
                         self._probed("dgrad", item, lambda: nat.call(
                             "lnn_conv3d_dgrad_ws", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
                             nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0, splitk_ws,
@@ -698,16 +789,24 @@ class UNetEngine:
 
                     def up_wgrad_call(item, C, K, D, H, W):
                         det = self._det_scratch()
-                        if det is not None:
+                        if not item.iso:
+                            nat.call("lnn_convT3d_wgrad_g", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
+                                     self._pn(item.panel), nn, D, H, W, C, K, *item.strides, det, 0 if det is None else det.numel())
+                        elif det is not None:
                             nat.call("lnn_convT3d_k2s2_wgrad_det", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
                                      self._pn(item.panel), nn, D, H, W, C, K, det, det.numel())
                         else:
                             nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
                                      self._pn(item.panel), nn, D, H, W, C, K)
                     on_side(up_wgrad)
-                    self._probed("dgrad", item, lambda: nat.call(
-                        "lnn_convT3d_k2s2_dgrad_ws", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
-                        item.gx.ld, nn, D, H, W, C, K, 0, splitk_ws, splitk_ws.numel()))
+                    if item.iso:
+                        self._probed("dgrad", item, lambda: nat.call(
+                            "lnn_convT3d_k2s2_dgrad_ws", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
+                            item.gx.ld, nn, D, H, W, C, K, 0, splitk_ws, splitk_ws.numel()))
+                    else:
+                        self._probed("dgrad", item, lambda: nat.call(
+                            "lnn_convT3d_dgrad_g", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
+                            item.gx.ld, nn, D, H, W, C, K, *item.strides, 0, splitk_ws, splitk_ws.numel()))
 
         self._fork(lane)
         if side is not None:
@@ -727,12 +826,12 @@ class UNetEngine:
         first = 0
         for item in self.order:
             if isinstance(item, ConvBlock):
-                m = item.z.V * item.cin * item.cout * 27
+                m = item.z.V * item.cin * item.cout * item.ntaps
                 mac += m
-                if item.x is None:
+                if item.first:
                     first = m
             elif isinstance(item, UpBlock):
-                mac += item.x.V * item.cin * item.cout * 8
+                mac += item.x.V * item.cin * item.cout * item.ntaps
             else:
                 mac += item.x.V * item.cin * self.K
         return 6 * mac - 2 * first, mac

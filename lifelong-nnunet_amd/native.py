@@ -87,6 +87,14 @@ SIGNATURES = {
     "lnn_f32_convT3d_k2s2_fwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "lnn_f32_convT3d_k2s2_dgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
     "lnn_f32_convT3d_k2s2_wgrad": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
+    "lnn_f32_conv3d_fwd_g": (_i, [_p, _p, _i, _p, _p, _p, _i] + [_i] * 12),
+    "lnn_f32_conv3d_dgrad_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 13),
+    "lnn_f32_conv3d_wgrad_g": (_i, [_p, _p, _i, _p, _i, _p] + [_i] * 12),
+    "lnn_f32_convT3d_fwd_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 9),
+    "lnn_f32_convT3d_dgrad_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 10),
+    "lnn_f32_convT3d_wgrad_g": (_i, [_p, _p, _i, _p, _i, _p] + [_i] * 9),
+    "lnn_image_to_cl_h": (_i, [_p, _p, _p, _i, _i, _l, _i]),
+    "lnn_f32_image_to_cl": (_i, [_p, _p, _p, _i, _i, _l, _i]),
     "lnn_f32_instnorm_lrelu_fwd": (_i, [_p, _p, _i, _p, _i, _i, _l, _i, _f, _p, _p, _p, _p, _f]),
     "lnn_f32_instnorm_lrelu_bwd": (_i, [_p, _p, _i, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
     "lnn_f32_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),

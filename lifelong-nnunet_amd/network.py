@@ -19,7 +19,7 @@ from typing import Dict, Tuple
 import torch
 from torch import nn
 
-from .engine import ParamArena, UNetEngine, param_slots
+from .engine import ParamArena, UNetEngine, param_slots, unet_geometry
 from .engine_f32 import UNetEngineF32
 
 
@@ -71,10 +71,14 @@ class Generic_UNet(nn.Module):
     MAX_NUM_FILTERS_3D = 320
 
     def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2,
-                 deep_supervision=True, device="cuda", **_ignored):
+                 deep_supervision=True, device="cuda", pool_op_kernel_sizes=None, conv_kernel_sizes=None, **_ignored):
+        """``pool_op_kernel_sizes`` / ``conv_kernel_sizes``: the plans' per-level poolings (strides, 1 or 2 per axis) and conv
+        kernel extents (1 or 3 per axis) the reference hands to its network class (nnViTUNetTrainer.py:117-122 /
+        nnUNetTrainerMultiHead.py:348-369); None = 2x2x2 / 3x3x3 everywhere (upstream's defaults)."""
         super().__init__()
         self.input_channels, self.base_num_features = input_channels, base_num_features
         self.num_classes, self.num_pool = num_classes, num_pool
+        self.pool_op_kernel_sizes, self.conv_kernel_sizes, _ = unet_geometry(num_pool, None, pool_op_kernel_sizes, conv_kernel_sizes)
         self._deep_supervision = deep_supervision
         self.do_ds = True
         self.inference_apply_nonlin = lambda x: torch.softmax(x, 1)
@@ -82,7 +86,8 @@ class Generic_UNet(nn.Module):
         self.device_ = torch.device(device)
         self.storage = "fp16"      # "fp32": the reference's fp16=False branch (MH.py:632-641) on the direct fp32 kernels
 
-        slots = param_slots(input_channels, base_num_features, num_classes, num_pool, self.MAX_NUM_FILTERS_3D)
+        slots = param_slots(input_channels, base_num_features, num_classes, num_pool, self.MAX_NUM_FILTERS_3D,
+                            self.pool_op_kernel_sizes, self.conv_kernel_sizes)
         self.arena = ParamArena(slots, self.device_)
         self._engines: Dict[Tuple, UNetEngine] = {}
         self.params_without_grad = set()
@@ -166,7 +171,8 @@ class Generic_UNet(nn.Module):
         if eng is None:
             cls = UNetEngineF32 if self.storage == "fp32" else UNetEngine
             eng = cls(self.arena, self.input_channels, self.base_num_features, self.num_classes, self.num_pool,
-                      tuple(x.shape[2:]), x.shape[0], self.device_, self.MAX_NUM_FILTERS_3D)
+                      tuple(x.shape[2:]), x.shape[0], self.device_, self.MAX_NUM_FILTERS_3D,
+                      pool_op_kernel_sizes=self.pool_op_kernel_sizes, conv_kernel_sizes=self.conv_kernel_sizes)
             if getattr(self, "deterministic_wgrad", False) and hasattr(eng, "deterministic_wgrad"):
                 eng.deterministic_wgrad = True        # ordered reduction instead of fp32 atomics in every weight gradient
             self._engines[key] = eng

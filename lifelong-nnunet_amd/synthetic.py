@@ -19,9 +19,20 @@ def _smooth_field(shape, gen, passes=3, k=5):
     return f / (f.std() + 1e-8)
 
 
-def make_patch_batch(batch, patch, num_pool, in_channels=1, num_labels=3, seed=12345, blob_scale=1.0):
+def ds_strides(num_pool, pool_op_kernel_sizes=None):
+    """Cumulative per-axis strides of the deep-supervision levels 0 .. num_pool - 1: upstream's ``deep_supervision_scales``
+    (``1 / cumprod(net_num_pool_op_kernel_sizes)``, the lowest resolution dropped); 2^i per axis for the isotropic plans."""
+    pools = [(2, 2, 2)] * num_pool if pool_op_kernel_sizes is None else [tuple(int(v) for v in q) for q in pool_op_kernel_sizes]
+    out, cur = [], (1, 1, 1)
+    for i in range(num_pool):
+        out.append(cur)
+        cur = tuple(c * q for c, q in zip(cur, pools[i]))
+    return out
+
+
+def make_patch_batch(batch, patch, num_pool, in_channels=1, num_labels=3, seed=12345, blob_scale=1.0, pool_op_kernel_sizes=None):
     """Returns ``(data, targets)``: data (B,C,D,H,W) f32, targets list of ``num_pool`` tensors
-    (B,1,D/2^i,...) f32 holding integer labels (nearest-neighbour subsampled, positions 0,2,4,...)."""
+    (B,1,D/s_i,...) f32 holding integer labels (nearest-neighbour subsampled at the cumulative pooling strides s_i)."""
     gen = torch.Generator().manual_seed(int(seed))
     data = torch.randn((batch, in_channels) + tuple(patch), generator=gen)
     full = torch.zeros((batch, 1) + tuple(patch))
@@ -38,7 +49,7 @@ def make_patch_batch(batch, patch, num_pool, in_channels=1, num_labels=3, seed=1
         full[b, 0] = lab
         # make the image weakly informative about the label so training has signal
         data[b] += 0.75 * lab[None]
-    targets = [full[:, :, ::2 ** i, ::2 ** i, ::2 ** i].contiguous() for i in range(num_pool)]
+    targets = [full[:, :, ::sz, ::sy, ::sx].contiguous() for sz, sy, sx in ds_strides(num_pool, pool_op_kernel_sizes)]
     return data, targets
 
 
@@ -47,9 +58,9 @@ class SyntheticPatchGenerator:
     (the reference pairs batch ``i mod 250`` with stored teacher logits, lwf/nnUNetTrainerLWF.py:349)."""
 
     def __init__(self, batch, patch, num_pool, in_channels=1, num_labels=3, seed=12345, period=4,
-                 blob_scale=1.0, key_prefix="case"):
+                 blob_scale=1.0, key_prefix="case", pool_op_kernel_sizes=None):
         self.batches = [make_patch_batch(batch, patch, num_pool, in_channels, num_labels, seed + 1000 * i,
-                                         blob_scale) for i in range(period)]
+                                         blob_scale, pool_op_kernel_sizes) for i in range(period)]
         self.keys = [[f"{key_prefix}_{i:03d}_{b}" for b in range(batch)] for i in range(period)]
         self.i = 0
 

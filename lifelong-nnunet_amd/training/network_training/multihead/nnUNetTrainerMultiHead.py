@@ -41,7 +41,8 @@ def default_data_provider(task, split, plans, seed=12345):
                                    plans["num_input_channels"], plans["num_classes"],
                                    seed=seed + 17 * h + (0 if split == "train" else 500000),
                                    period=plans.get("synthetic_period", 4),
-                                   blob_scale=1.0 + 0.5 * (h % 3), key_prefix=f"{task}_{split}")
+                                   blob_scale=1.0 + 0.5 * (h % 3), key_prefix=f"{task}_{split}",
+                                   pool_op_kernel_sizes=plans.get("pool_op_kernel_sizes"))
 
 
 class nnUNetTrainerMultiHead:
@@ -102,7 +103,7 @@ class nnUNetTrainerMultiHead:
                    call_for_eval=False):
         self.max_num_epochs = num_epochs
         self.initialize_network()
-        self._update_loss_after_plans_change(self.plans["num_pool"], self.plans["patch_size"])
+        self._update_loss_after_plans_change(self.plans.get("pool_op_kernel_sizes") or self.plans["num_pool"], self.plans["patch_size"])
         if training:
             self.tr_gen = self.data_provider(self.task, "train", self.plans)
             self.val_gen = self.data_provider(self.task, "val", self.plans)
@@ -120,9 +121,14 @@ class nnUNetTrainerMultiHead:
     def initialize_network(self):
         p = self.plans
         prev = self.trainer_model
+        # the network is built from the plans (MH.py:348-369 -> upstream nnUNetTrainerV2.initialize_network): input channels,
+        # one pooling per level and one conv kernel per stage; plans without the two lists are isotropic (2x2x2 / 3x3x3)
+        if p.get("pool_op_kernel_sizes") is not None:
+            assert len(p["pool_op_kernel_sizes"]) == p["num_pool"], "num_pool = len(net_num_pool_op_kernel_sizes) (MH.py:360)"
         self.mh_network = MultiHead_Module(Generic_UNet, self.split, self.task, prev, p["num_input_channels"],
                                            p["base_num_features"], p["num_classes"], p["num_pool"],
-                                           device=self.device)
+                                           device=self.device, pool_op_kernel_sizes=p.get("pool_op_kernel_sizes"),
+                                           conv_kernel_sizes=p.get("conv_kernel_sizes"))
         self.network = self.mh_network.model
         self.network.deterministic_wgrad = bool(self.deterministic_wgrad)
         self.network.inference_apply_nonlin = lambda x: torch.softmax(x, 1)
@@ -152,7 +158,8 @@ class nnUNetTrainerMultiHead:
         evaluated without autograd."""
         from ....network import Generic_UNet
         p = self.plans
-        old = Generic_UNet(p["num_input_channels"], p["base_num_features"], p["num_classes"], p["num_pool"], device=self.device)
+        old = Generic_UNet(p["num_input_channels"], p["base_num_features"], p["num_classes"], p["num_pool"], device=self.device,
+                           pool_op_kernel_sizes=p.get("pool_op_kernel_sizes"), conv_kernel_sizes=p.get("conv_kernel_sizes"))
         old.storage = self.network.storage
         old.load_state_dict(self.network.state_dict())
         for prm in old.parameters():

@@ -168,8 +168,10 @@ def _check_flow(f, out, rt_first, rt_later, pod_rel, pod_abs):
         ok = ~np.isnan(exp)
         rel = np.abs(got[ok] - exp[ok]) / np.abs(exp[ok])
         if len(rel):
-            # the first iteration of a task sees weights that the earlier tasks' fp16-storage steps already moved
-            first = rt_first if t == f["tasks"][0] else max(rt_first, rt_later / 2)
+            # the first iteration of a task sees weights that the earlier tasks' fp16-storage steps already moved (and the
+            # pseudo-label mask sits on an entropy threshold: a different fp32 summation order in one kernel moves the later
+            # tasks' losses by 1e-3 .. 3e-3): only the very first iteration of the flow gets the tight bound
+            first = rt_first if t == f["tasks"][0] else rt_later
             assert rel[0] <= first and np.all(rel <= rt_later), (t, got.tolist(), exp.tolist())
         ep = np.asarray(f["pods_" + t])
         gp = np.asarray(pods)
