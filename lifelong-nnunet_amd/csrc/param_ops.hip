@@ -27,10 +27,11 @@ extern "C" int lnn_device_info(int* cu_count, int* clock_khz, char* name, int na
 
 namespace {
 constexpr int NT = 256;
+constexpr int RED_BLOCKS = 512;          // partial sums per reduction = what lnn_flat_reduce_ws_doubles() reports
 
 int red_blocks(long n) {                 // blocks of a two-stage reduction: <= RED_BLOCKS partial sums
     long b = (n + (long)NT * 16 - 1) / ((long)NT * 16);
-    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
 }
 
 int flat_blocks(long n, int per_thread) {
@@ -221,7 +222,6 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 // Flat-arena reductions are deterministic: every block writes its partial sum to the caller's scratch and ONE block adds
 // the partials in a fixed order (fp64 atomics from ~2000 blocks onto one address serialise in L2, 50-100 ns each, and
 // make the clip coefficient differ between data-parallel ranks in the last bit).  All flat kernels move 16 bytes per lane.
-constexpr int RED_BLOCKS = 512;          // partial sums per reduction = what lnn_flat_reduce_ws_doubles() reports
 
 __device__ __forceinline__ void block_sum_d(double (&v)[2], double* sm) {      // fixed-order block reduction (256 threads)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -310,25 +310,56 @@ __global__ __launch_bounds__(NT) void fisher_kernel(const float* __restrict__ g,
     }
 }
 
-__global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ g, long n, float unscale, double* partial, int vec) {
+// One launch (round 4; the separate one-block reduce launch was 5 of the call's 29 us): every block leaves its partial pair, takes a
+// ticket, and the block that draws the LAST ticket adds all partials in index order (the order does not depend on which block
+// that is: bit-reproducible) and resets the ticket counter.  Four independent 16-byte loads per lane and iteration.
+__global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ g, long n, float unscale, double* out2, int vec,
+                                                      int accumulate) {
     __shared__ double sm[2 * (NT / 64)];
+    __shared__ int is_last;
+    double* partial = out2 + 2;
+    unsigned* ticket = reinterpret_cast<unsigned*>(out2 + 2 + 2 * RED_BLOCKS);
     float acc[2] = {0.f, 0.f};
     const long n4 = vec ? n >> 2 : 0;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
-        const floatx4 gv = reinterpret_cast<const floatx4*>(g)[i];
+    const long stride = (long)gridDim.x * NT;
+    auto take = [&](const floatx4 gv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = gv[e] * unscale;
             if (!isfinite(x)) acc[1] += 1.f; else acc[0] += x * x;
         }
+    };
+    long i = (long)blockIdx.x * NT + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const floatx4 a = reinterpret_cast<const floatx4*>(g)[i], b = reinterpret_cast<const floatx4*>(g)[i + stride],
+                      c = reinterpret_cast<const floatx4*>(g)[i + 2 * stride], d = reinterpret_cast<const floatx4*>(g)[i + 3 * stride];
+        take(a); take(b); take(c); take(d);
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
-        const float x = g[i] * unscale;
+    for (; i < n4; i += stride) take(reinterpret_cast<const floatx4*>(g)[i]);
+    for (long j = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; j < n; j += stride) {
+        const float x = g[j] * unscale;
         if (!isfinite(x)) acc[1] += 1.f; else acc[0] += x * x;
     }
     double v[2] = {(double)acc[0], (double)acc[1]};
     block_sum_d(v, sm);
-    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = v[0]; partial[2 * blockIdx.x + 1] = v[1]; }
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = v[0]; partial[2 * blockIdx.x + 1] = v[1];
+        __threadfence();
+        is_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    double t[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += NT) {
+        t[0] += __builtin_nontemporal_load(partial + 2 * b); t[1] += __builtin_nontemporal_load(partial + 2 * b + 1);
+    }
+    block_sum_d(t, sm);
+    if (threadIdx.x == 0) {
+        out2[0] = (accumulate ? out2[0] : 0.0) + t[0];
+        out2[1] = (accumulate ? out2[1] : 0.0) + t[1];
+        *ticket = 0u;
+    }
 }
 
 // torch.optim.SGD(nesterov=True, dampening=0): g += wd*theta; buf = g (first) | mu*buf + g; theta -= lr*(g + mu*buf)
@@ -614,16 +645,14 @@ extern "C" int lnn_fisher_ema(lnn_stream_t s_, const float* grad, float* fisher,
     return LNN_OK;
 }
 
-extern "C" long lnn_flat_reduce_ws_doubles(void) { return 2 + 2 * 512; }
+extern "C" long lnn_flat_reduce_ws_doubles(void) { return 2 + 2 * RED_BLOCKS + 1; }       // pair, partials, ticket counter
 
 extern "C" int lnn_gradnorm_sumsq(lnn_stream_t s_, const float* grad, long n, float unscale, double* out2, int zero_first) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(grad && out2, "lnn_gradnorm_sumsq: null pointer");
     const int nb = red_blocks(n);
-    hipLaunchKernelGGL(gradnorm_kernel, dim3(nb), dim3(NT), 0, s, grad, n, unscale, out2 + 2, (int)lnn_aligned16(grad));
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(nb), dim3(NT), 0, s, grad, n, unscale, out2, (int)lnn_aligned16(grad), zero_first ? 0 : 1);
     LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(NT), 0, s, out2 + 2, nb, out2, zero_first ? 0 : 1);
-    LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq(reduce)");
     return LNN_OK;
 }
 

@@ -187,13 +187,14 @@ template <int KT, int VEC>
 __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                          int K, long V, double* ws, int N) {
     constexpr int KK = KT > 0 ? KT : KMAX;
-    __shared__ float sm[(3 * KMAX + 1) * (NT / 64)];
+    constexpr int NA = 3 * KK + 1;                  // accumulators this instantiation reduces (round 3 reduced 25 for K = 3)
+    __shared__ float sm[NA * (NT / 64)];
     const int n = blockIdx.y;
     const float* ln = logits + (long)n * K * V;
     const float* yn = labels + (long)n * V;
-    float acc[3 * KMAX + 1];
+    float acc[NA];
 #pragma unroll
-    for (int i = 0; i < 3 * KMAX + 1; ++i) acc[i] = 0.f;
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
     for (long v = ((long)blockIdx.x * NT + threadIdx.x) * VEC; v < V; v += (long)gridDim.x * NT * VEC) {
         float xv[KMAX][VEC], yv[VEC];
 #pragma unroll
@@ -228,15 +229,17 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
                     acc[k * 3 + 0] += p[k] * y;
                     acc[k * 3 + 1] += p[k] * (1.f - y);
                     acc[k * 3 + 2] += (1.f - p[k]) * y;
-                    if (k == lab) acc[3 * KMAX] += lse - x[k];
+                    if (k == lab) acc[3 * KK] += lse - x[k];
                 }
         }
     }
-    block_sum<3 * KMAX + 1>(acc, sm);
+    block_sum<NA>(acc, sm);
     if (threadIdx.x == 0) {
-        float* pws = reinterpret_cast<float*>(ws + (long)N * K * 3 + 2) + ((long)n * gridDim.x + blockIdx.x) * (3 * KMAX + 1);
+        // partials [n][value 0 .. 3 KMAX][block]: the finalize kernel reads one value's partials as a contiguous run
+        float* pws = reinterpret_cast<float*>(ws + (long)N * K * 3 + 2) + (long)n * (3 * KMAX + 1) * gridDim.x + blockIdx.x;
 #pragma unroll
-        for (int i = 0; i < 3 * KMAX + 1; ++i) pws[i] = acc[i];
+        for (int i = 0; i < 3 * KK; ++i) pws[(long)i * gridDim.x] = acc[i];
+        pws[(long)(3 * KMAX) * gridDim.x] = acc[3 * KK];
     }
 }
 
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nb
         const int n = j / per_n, jj = j % per_n;
         const int i = jj < 3 * K ? jj : 3 * KMAX;
         double s = 0;
-        for (int b = lane; b < nblk; b += 64) s += (double)pws[((long)n * nblk + b) * W + i];
+        for (int b = lane; b < nblk; b += 64) s += (double)pws[((long)n * W + i) * nblk + b];
         s = wave_sum_d(s);
         if (lane == 0) {
             if (i < 3 * KMAX) ws[((long)n * K + i / 3) * 3 + i % 3] = s;
@@ -650,7 +653,11 @@ static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* l
     LNN_REQUIRE(logits && labels && out_loss && ws, "lnn_dice_ce_fwd: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
     LNN_REQUIRE(N >= 1 && N <= LNN_DICE_CE_MAX_BATCH, "lnn_dice_ce_fwd: batch %d unsupported (1..%d)", N, LNN_DICE_CE_MAX_BATCH);
-    const int nblk = vox_blocks(V);
+    // 512 blocks per launch at most (two 4-wave blocks per CU keep ~8 KB of 16-byte loads in flight per CU-block): the per-block
+    // reduction of 3K + 1 values and the finalize pass scale with the block count (1024 blocks per sample: finalize 25 us)
+    int nblk = vox_blocks(V);
+    const int cap = 512 / N > 1 ? 512 / N : 1;
+    if (nblk > cap) nblk = cap;
     const bool vec = (V & 3) == 0 && lnn_aligned16(logits) && lnn_aligned16(labels);
 #define LNN_DCE_FWD(KT, VEC) hipLaunchKernelGGL((dice_ce_fwd_kernel<KT, VEC>), dim3(nblk, N), dim3(NT), 0, s, logits, labels, K, V, ws, N)
     if (vec) { if (K == 3) LNN_DCE_FWD(3, 4); else if (K == 2) LNN_DCE_FWD(2, 4); else if (K == 4) LNN_DCE_FWD(4, 4); else LNN_DCE_FWD(0, 4); }

@@ -170,14 +170,16 @@ class DataLoader3D:
         return self.generate_train_batch()
 
 
-def downsample_seg_for_ds(seg: np.ndarray, num_pool: int):
-    """``DownsampleSegForDSTransform2`` with scales ``1 / 2^i`` and order 0: nearest neighbour at the pixel-centre
-    coordinate ``2^i * (o + 0.5) - 0.5``, rounded half up -> input index ``2^i * o + 2^(i-1)`` (clipped)."""
+def downsample_seg_for_ds(seg: np.ndarray, num_pool: int, pool_op_kernel_sizes=None):
+    """``DownsampleSegForDSTransform2`` with upstream's ``deep_supervision_scales`` (1 / the cumulative pooling strides per axis,
+    2^i for the isotropic plans) and order 0: nearest neighbour at the pixel-centre coordinate ``f * (o + 0.5) - 0.5``, rounded
+    half up -> input index ``f * o + f / 2`` (clipped)."""
+    from .synthetic import ds_strides
     out = [seg]
-    for i in range(1, num_pool):
-        f = 2 ** i
-        new_shape = [int(round(s / f)) for s in seg.shape[2:]]
-        idx = [np.minimum(np.floor(f * (np.arange(n) + 0.5)).astype(int), s - 1) for n, s in zip(new_shape, seg.shape[2:])]
+    for fz, fy, fx in ds_strides(num_pool, pool_op_kernel_sizes)[1:]:
+        fs = (fz, fy, fx)
+        new_shape = [int(round(s / f)) for s, f in zip(seg.shape[2:], fs)]
+        idx = [np.minimum(np.floor(f * (np.arange(n) + 0.5)).astype(int), s - 1) for n, s, f in zip(new_shape, seg.shape[2:], fs)]
         out.append(np.ascontiguousarray(seg[:, :, idx[0]][:, :, :, idx[1]][:, :, :, :, idx[2]]))
     return out
 
@@ -205,7 +207,7 @@ class PreprocessedDataProvider:
     def generator_for(self, dataset, plans, split="train"):
         loader = DataLoader3D(dataset, plans["patch_size"], plans["patch_size"], plans["batch_size"], False,
                               oversample_foreground_percent=self.oversample, pad_mode="constant", memmap_mode='r')
-        return _DictAdapter(loader, plans["num_pool"])
+        return _DictAdapter(loader, plans["num_pool"], plans.get("pool_op_kernel_sizes"))
 
     def __call__(self, task, split, plans):
         tr, val = do_split(self.dataset_for(task), self.fold, self.splits_file_for(task))
@@ -216,8 +218,8 @@ class PreprocessedDataProvider:
 
 
 class _DictAdapter:
-    def __init__(self, loader, num_pool):
-        self.loader, self.num_pool = loader, num_pool
+    def __init__(self, loader, num_pool, pool_op_kernel_sizes=None):
+        self.loader, self.num_pool, self.pools = loader, num_pool, pool_op_kernel_sizes
 
     def __iter__(self):
         return self
@@ -226,6 +228,6 @@ class _DictAdapter:
         import torch
         b = next(self.loader)
         seg = np.maximum(b['seg'], 0)               # -1 (outside the volume) trains as background, as upstream's
-        targets = downsample_seg_for_ds(seg, self.num_pool)     # RemoveLabelTransform(-1, 0) does
+        targets = downsample_seg_for_ds(seg, self.num_pool, self.pools)     # RemoveLabelTransform(-1, 0) does
         return {'data': torch.from_numpy(b['data']), 'target': [torch.from_numpy(t) for t in targets],
                 'keys': list(b['keys']), 'properties': b['properties']}

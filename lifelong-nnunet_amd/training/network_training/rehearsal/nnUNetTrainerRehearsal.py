@@ -49,7 +49,7 @@ class RehearsalPatchGenerator:
         if case not in self._cache:
             h = sum(ord(c) * (i + 1) for i, c in enumerate(case)) % 100003
             d, t = make_patch_batch(1, self.plans["patch_size"], self.plans["num_pool"], self.plans["num_input_channels"],
-                                    self.plans["num_classes"], seed=h)
+                                    self.plans["num_classes"], seed=h, pool_op_kernel_sizes=self.plans.get("pool_op_kernel_sizes"))
             self._cache[case] = (d, t)
         return self._cache[case]
 

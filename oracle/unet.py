@@ -16,9 +16,10 @@ from torch import nn
 
 class ConvDropoutNormNonlin(nn.Module):
     # attribute names conv / instnorm / lrelu as in test_MultiHead_Module.py:287-291; dropout p=0 is omitted upstream
-    def __init__(self, cin, cout, stride):
+    def __init__(self, cin, cout, stride, kernel=(3, 3, 3)):
         super().__init__()
-        self.conv = nn.Conv3d(cin, cout, 3, stride, 1, bias=True)
+        # upstream: conv_kwargs['kernel_size'] = conv_kernel_sizes[level], 'padding' = [1 if k == 3 else 0 for k in kernel]
+        self.conv = nn.Conv3d(cin, cout, tuple(kernel), stride, tuple(1 if k == 3 else 0 for k in kernel), bias=True)
         self.instnorm = nn.InstanceNorm3d(cout, eps=1e-5, affine=True)
         self.lrelu = nn.LeakyReLU(1e-2, inplace=True)
 
@@ -27,12 +28,12 @@ class ConvDropoutNormNonlin(nn.Module):
 
 
 class StackedConvLayers(nn.Module):
-    def __init__(self, cin, cout, num_convs, first_stride=1):
+    def __init__(self, cin, cout, num_convs, first_stride=1, kernel=(3, 3, 3)):
         super().__init__()
         self.input_channels, self.output_channels = cin, cout
         self.blocks = nn.Sequential(
-            *([ConvDropoutNormNonlin(cin, cout, first_stride)]
-              + [ConvDropoutNormNonlin(cout, cout, 1) for _ in range(num_convs - 1)]))
+            *([ConvDropoutNormNonlin(cin, cout, first_stride, kernel)]
+              + [ConvDropoutNormNonlin(cout, cout, 1, kernel) for _ in range(num_convs - 1)]))
 
     def forward(self, x):
         return self.blocks(x)
@@ -50,8 +51,16 @@ class OracleGenericUNet(nn.Module):
     """3-D Generic_UNet: conv pooling, transposed-conv upsampling, deep supervision, no logits upscaling."""
     MAX_FEATURES_3D = 320
 
-    def __init__(self, in_channels, base_features, num_classes, num_pool, conv_per_stage=2):
+    def __init__(self, in_channels, base_features, num_classes, num_pool, conv_per_stage=2, pool_op_kernel_sizes=None,
+                 conv_kernel_sizes=None):
+        """``pool_op_kernel_sizes`` / ``conv_kernel_sizes``: as the reference hands them over (nnViTUNetTrainer.py:122); the way
+        upstream's constructor (nnunet @77bc485, absent from the reference tree: recalled, parity unpinned) uses them: encoder
+        stage d = kernel d, first block strided by pooling d - 1; bottleneck = kernel num_pool, pooling -1; decoder stage u =
+        ConvTranspose3d(kernel = stride = pooling -(u + 1)) and conv kernel -(u + 1)."""
         super().__init__()
+        pools = [tuple(q) for q in (pool_op_kernel_sizes if pool_op_kernel_sizes is not None else [(2, 2, 2)] * num_pool)]
+        kernels = [tuple(q) for q in (conv_kernel_sizes if conv_kernel_sizes is not None else [(3, 3, 3)] * (num_pool + 1))]
+        assert len(pools) == num_pool and len(kernels) == num_pool + 1
         self.num_classes = num_classes
         self.do_ds = True
         self._deep_supervision = True
@@ -66,23 +75,23 @@ class OracleGenericUNet(nn.Module):
 
         cin, cout = in_channels, base_features
         for d in range(num_pool):
-            self.conv_blocks_context.append(StackedConvLayers(cin, cout, conv_per_stage, 2 if d > 0 else 1))
+            self.conv_blocks_context.append(StackedConvLayers(cin, cout, conv_per_stage, pools[d - 1] if d > 0 else 1, kernels[d]))
             cin = cout
             cout = min(cout * 2, self.MAX_FEATURES_3D)
         # bottleneck (test_MultiHead_Module.py:394-415): Sequential(Stacked(strided, n-1 convs), Stacked(1 conv))
         final = cout  # convolutional_upsampling=True -> final_num_features = output_features
         self.conv_blocks_context.append(nn.Sequential(
-            StackedConvLayers(cin, cout, conv_per_stage - 1, 2),
-            StackedConvLayers(cout, final, 1)))
+            StackedConvLayers(cin, cout, conv_per_stage - 1, pools[-1], kernels[num_pool]),
+            StackedConvLayers(cout, final, 1, 1, kernels[num_pool])))
 
         for u in range(num_pool):
             from_down = final
             from_skip = self.conv_blocks_context[-(2 + u)].output_channels
             final = from_skip
-            self.tu.append(nn.ConvTranspose3d(from_down, from_skip, 2, 2, bias=False))
+            self.tu.append(nn.ConvTranspose3d(from_down, from_skip, pools[-(u + 1)], pools[-(u + 1)], bias=False))
             self.conv_blocks_localization.append(nn.Sequential(
-                StackedConvLayers(2 * from_skip, from_skip, conv_per_stage - 1),
-                StackedConvLayers(from_skip, final, 1)))
+                StackedConvLayers(2 * from_skip, from_skip, conv_per_stage - 1, 1, kernels[-(u + 1)]),
+                StackedConvLayers(from_skip, final, 1, 1, kernels[-(u + 1)])))
         for u in range(num_pool):
             self.seg_outputs.append(nn.Conv3d(self.conv_blocks_localization[u][-1].output_channels,
                                               num_classes, 1, 1, 0, bias=False))
