@@ -2,6 +2,7 @@
 // deep-supervision level (forward statistics, backward dlogits), hard Dice counts, LwF distillation KL.
 // All HBM-bound: one pass over the logits per kernel, fp32 math, fp64 cross-block accumulation.
 #include "lnn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -656,7 +657,9 @@ static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* l
     // 512 blocks per launch at most (two 4-wave blocks per CU keep ~8 KB of 16-byte loads in flight per CU-block): the per-block
     // reduction of 3K + 1 values and the finalize pass scale with the block count (1024 blocks per sample: finalize 25 us)
     int nblk = vox_blocks(V);
-    const int cap = 512 / N > 1 ? 512 / N : 1;
+    static int total_cap = -1;            // LNN_DCE_BLOCKS (A/B measurement, tools/gpu_r4_d.sh)
+    if (total_cap < 0) { const char* e = getenv("LNN_DCE_BLOCKS"); total_cap = e ? atoi(e) : 1024; }
+    const int cap = total_cap / N > 1 ? total_cap / N : 1;
     if (nblk > cap) nblk = cap;
     const bool vec = (V & 3) == 0 && lnn_aligned16(logits) && lnn_aligned16(labels);
 #define LNN_DCE_FWD(KT, VEC) hipLaunchKernelGGL((dice_ce_fwd_kernel<KT, VEC>), dim3(nblk, N), dim3(NT), 0, s, logits, labels, K, V, ws, N)

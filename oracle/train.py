@@ -193,6 +193,31 @@ def lwf_iteration(net, opt, gen, heads, target_logits, batch_idx, weights, tempe
     return float(l.detach())
 
 
+def lwf_iteration_same_batch(net, opt, gen, heads, target_logits, batch_idx, weights, temperature=2.0, clip=12.0):
+    """The flag-fixed variant of ``lwf_iteration`` (product: ``nnUNetTrainerLWF.same_batch_predictions``): the paper's
+    distillation -- every head's prediction is taken on the TRAINING batch itself, ONE batch per iteration; otherwise the
+    reference's arithmetic (value-only KL of deep_supervision.py:194-196 against the stored teacher logits, clip 12, SGD)."""
+    tasks = list(heads.keys())
+    cur = {n: p.detach().clone() for n, p in net.named_parameters() if n.startswith("seg_outputs.")}
+    b = next(gen)
+    data, target = torch.as_tensor(b["data"]), [torch.as_tensor(t) for t in b["target"]]
+    preds, targets = [], []
+    for task in tasks[:-1]:
+        _with_head(net, heads[task])
+        with torch.no_grad():
+            preds.append(net(data)[0].detach())
+        targets.append(target_logits[task][batch_idx % 250])
+    _with_head(net, cur)
+    opt.zero_grad()
+    out = net(data)
+    preds.append(out[0].detach())
+    l = lwf_loss_value(losses.multiple_output_loss(out, target, weights), preds, targets, temperature)
+    l.backward()
+    torch.nn.utils.clip_grad_norm_(net.parameters(), clip)
+    opt.step()
+    return float(l.detach())
+
+
 def rehearsal_sample(train_keys_per_prev_task, samples_in_perc=0.25, seed=3299):
     """rehearsal/nnUNetTrainerRehearsal.py:73,132 -- one ``random.seed(seed)`` then, per previous task in
     head order, ``random.sample(items, round(len * perc))`` over the (sorted) train keys."""

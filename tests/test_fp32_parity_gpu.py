@@ -16,6 +16,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from oracle import losses as olosses, train as otrain                      # noqa: E402
+from oracle.unet import OracleGenericUNet                                   # noqa: E402
 from lifelong_nnunet_amd import get_trainer_class, native as nat          # noqa: E402
 from lifelong_nnunet_amd.synthetic import make_patch_batch                 # noqa: E402
 
@@ -52,6 +54,50 @@ def _close(got, exp, rl2=2e-6):
     rel = float((got.double() - exp.double()).norm() / (exp.double().norm() + 1e-30))
     assert rel <= rl2, rel
     assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5 * float(exp.abs().max()))
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W,k,st", [(2, 8, 16, 6, 9, 7, (1, 3, 3), (1, 2, 2)), (1, 5, 8, 7, 9, 11, (3, 1, 3), (2, 1, 2)),
+                                              (1, 2, 8, 5, 6, 7, (3, 3, 1), (1, 1, 1))])
+def test_f32_generic_geometry_kernels(N, C, K, D, H, W, k, st):
+    """fp32 parity kernels with per-axis kernel extents / strides (lnn_f32_*_g) vs torch's CPU ops."""
+    x = _rand((N, C, D, H, W), 1).requires_grad_(True)
+    w = _rand((K, C) + k, 2, 0.2).requires_grad_(True)
+    b = _rand((K,), 3)
+    y = F.conv3d(x, w, b, stride=st, padding=tuple(a // 2 for a in k))
+    dy = _rand(y.shape, 4)
+    y.backward(dy)
+    xb, yb = _cl(x.detach(), ld=C + 3, off=2), torch.zeros((N,) + tuple(y.shape[2:]) + (K,), device=DEV)
+    nat.call("lnn_f32_conv3d_fwd_g", _V(xb, 2), C + 3, w.detach().to(DEV), b.to(DEV), yb, K, N, D, H, W, C, K, *k, *st)
+    _close(_ncdhw(yb, K), y.detach())
+    dyb, dxb = _cl(dy), torch.zeros((N, D, H, W, C), device=DEV)
+    nat.call("lnn_f32_conv3d_dgrad_g", dyb, K, w.detach().to(DEV), dxb, C, N, D, H, W, C, K, *k, *st, 0)
+    _close(_ncdhw(dxb, C), x.grad)
+    dw = torch.zeros((K, C) + k, device=DEV)
+    nat.call("lnn_f32_conv3d_wgrad_g", _V(xb, 2), C + 3, dyb, K, dw, N, D, H, W, C, K, *k, *st)
+    _close(dw.cpu(), w.grad)
+    # transposed convolution with kernel == stride
+    wt = _rand((C, K) + st, 6, 0.2).requires_grad_(True)
+    x2 = _rand((N, C, D, H, W), 7).requires_grad_(True)
+    yt = F.conv_transpose3d(x2, wt, None, stride=st)
+    dyt = _rand(yt.shape, 8)
+    yt.backward(dyt)
+    x2b, ytb = _cl(x2.detach()), torch.zeros((N,) + tuple(yt.shape[2:]) + (K,), device=DEV)
+    nat.call("lnn_f32_convT3d_fwd_g", x2b, C, wt.detach().to(DEV), ytb, K, N, D, H, W, C, K, *st)
+    _close(_ncdhw(ytb, K), yt.detach())
+    dytb, dx2b = _cl(dyt), torch.zeros((N, D, H, W, C), device=DEV)
+    nat.call("lnn_f32_convT3d_dgrad_g", dytb, K, wt.detach().to(DEV), dx2b, C, N, D, H, W, C, K, *st, 0)
+    _close(_ncdhw(dx2b, C), x2.grad)
+    dwt = torch.zeros((C, K) + st, device=DEV)
+    nat.call("lnn_f32_convT3d_wgrad_g", x2b, C, dytb, K, dwt, N, D, H, W, C, K, *st)
+    _close(dwt.cpu(), wt.grad)
+    # the multi-channel image casts
+    img = _rand((N, C, D, H, W), 9)
+    dst = torch.full((N, D, H, W, C + 3), 5.0, device=DEV)
+    nat.call("lnn_f32_image_to_cl", img.to(DEV), dst, N, C, D * H * W, C + 3)
+    assert torch.equal(dst[..., :C].permute(0, 4, 1, 2, 3).cpu(), img) and torch.all(dst[..., C:] == 5.0)
+    dsth = torch.zeros((N, D, H, W, 16), dtype=torch.float16, device=DEV)
+    nat.call("lnn_image_to_cl_h", img.to(DEV), dsth, N, C, D * H * W, 16)
+    assert torch.equal(dsth[..., :C].permute(0, 4, 1, 2, 3).cpu(), img.half()) and torch.all(dsth[..., C:] == 0)
 
 
 @pytest.mark.parametrize("N,C,K,D,H,W,s", [(2, 8, 16, 6, 9, 7, 1), (1, 16, 8, 7, 9, 11, 2), (1, 1, 8, 5, 6, 7, 1), (2, 24, 24, 4, 4, 6, 2)])
@@ -280,6 +326,52 @@ def test_fp32_lwf_flow_matches_reference(ref):
     assert gB.n == f["batches_consumed_B"] == 12 and tr.batch_idx == f["batch_idx"]
     assert np.allclose(lB, f["lossesB"], rtol=1e-4), (lB, f["lossesB"])
     assert _rel(arr, "lwf::final_theta", dict(tr.network.named_parameters()), names) < 1e-4
+
+
+def test_fp32_lwf_same_batch_predictions_match_the_oracle(ref):
+    """``same_batch_predictions=True`` (the fix behind a flag: every head evaluated on the training batch, one batch and one body
+    pass per iteration -- the variant bench.py reports next to the reference-semantics number) against the oracle run with the
+    SAME fix (oracle.train.lwf_iteration_same_batch): losses 1e-4, weights 1e-4, one batch consumed per iteration."""
+    from collections import OrderedDict
+    from lifelong_nnunet_amd.training.network_training.lwf.nnUNetTrainerLWF import calculate_target_logits
+    meta, arr = ref
+    f = meta["lwf_flow"]
+    tr = _trainer("lwf", {"taskA": 5000, "taskB": 7000}, 2, arr, 2, lwf_temperature=f["T"])
+    onet = OracleGenericUNet(1, 8, 3, 2)
+    onet.load_state_dict({k: v.detach().cpu() for k, v in tr.network.state_dict().items()})
+    oopt = otrain.make_optimizer(onet)
+    w = olosses.ds_loss_weights(2)
+    head0 = {n: p.detach().clone() for n, p in onet.named_parameters() if n.startswith("seg_outputs.")}      # use_init head state
+    # task A: two plain iterations on both sides
+    tr.freeze_run, tr.loss = False, tr.loss_orig
+    gA, ogA = _Counting(_batches(5000, 2)), _Counting(_batches(5000, 2))
+    for _ in range(2):
+        la = float(tr.run_iteration(gA, True))
+        b = next(ogA)
+        lo, _ = otrain.run_iteration(onet, oopt, b["data"], b["target"], w)
+        assert abs(la - lo) <= 1e-4 * abs(lo)
+    headA = {n: p.detach().clone() for n, p in onet.named_parameters() if n.startswith("seg_outputs.")}
+    # task B starts from the initial head (use_init); teacher logits of both heads with the task-A body
+    tr.mh_network.add_new_task("taskB", use_init=True)
+    tr.network = tr.mh_network.assemble_model("taskB", freeze_body=False)
+    otrain._with_head(onet, head0)
+    heads = OrderedDict([("taskA", headA), ("taskB", head0)])
+    tr.target_logits = calculate_target_logits(tr.mh_network, _Counting(_batches(6000, 6)), 3, False)
+    oteach = otrain.lwf_target_logits(onet, heads, _Counting(_batches(6000, 6)), 3)
+    tr.network.train()
+    tr.loss, tr.task, tr.batch_idx = tr.LwFloss, "taskB", 0
+    tr.same_batch_predictions = True
+    gB, ogB = _Counting(_batches(7000, 4)), _Counting(_batches(7000, 4))
+    for it in range(3):
+        lb = float(tr.run_iteration(gB, True))
+        lo = otrain.lwf_iteration_same_batch(onet, oopt, ogB, heads, oteach, it, w, temperature=f["T"])
+        print(f"LwF same-batch iter {it}: oracle {lo:.6f} hip {lb:.6f}")
+        assert abs(lb - lo) <= 1e-4 * abs(lo)
+    assert gB.n == ogB.n == 3
+    osd = onet.state_dict()
+    num = sum(float(((v.cpu() - osd[k]) ** 2).sum()) for k, v in tr.network.state_dict().items())
+    den = sum(float((v ** 2).sum()) for v in osd.values())
+    assert (num / den) ** 0.5 < 1e-4
 
 
 @pytest.mark.parametrize("transfer", [False, True])
