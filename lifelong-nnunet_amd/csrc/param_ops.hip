@@ -659,7 +659,7 @@ extern "C" int lnn_gradnorm_sumsq(lnn_stream_t s_, const float* grad, long n, fl
     // LNN_GRADNORM_VARIANT (A/B measurement, tools/gpu_r4_d.sh): bit 0 = 4 loads in flight per lane, bit 1 = one launch (ticketed
     // last-block reduce) instead of two, bits 2.. = log2 of the block-count multiplier
     static int var = -1;
-    if (var < 0) { const char* e = getenv("LNN_GRADNORM_VARIANT"); var = e ? atoi(e) : 3; }
+    if (var < 0) { const char* e = getenv("LNN_GRADNORM_VARIANT"); var = e ? atoi(e) : 1; }
     int nb = red_blocks(n) << (var >> 2);
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     hipLaunchKernelGGL(gradnorm_kernel, dim3(nb), dim3(NT), 0, s, grad, n, unscale, out2, (int)lnn_aligned16(grad), zero_first ? 0 : 1,
