@@ -337,8 +337,7 @@ int lnn_rw_update(lnn_stream_t s, const float* theta, float* prev, const float* 
  * reduction (fixed summation order, no atomics: data-parallel ranks holding identical gradients get identical clip
  * coefficients): out2 must have room for lnn_flat_reduce_ws_doubles() doubles -- the pair first, block partials after. */
 int lnn_gradnorm_sumsq(lnn_stream_t s, const float* grad, long n, float unscale, double* out2, int zero_first);
-/* doubles the `ws` / `out2` argument of lnn_ewc_penalty_fwd / lnn_gradnorm_sumsq must hold.  lnn_gradnorm_sumsq keeps a ticket
- * counter in the last one: its out2 must be ZERO when first used (the call leaves the counter zeroed again). */
+/* doubles the `ws` / `out2` argument of lnn_ewc_penalty_fwd / lnn_gradnorm_sumsq must hold */
 long lnn_flat_reduce_ws_doubles(void);
 int lnn_sgd_nesterov_step(lnn_stream_t s, float* theta, float* momentum_buf, const float* grad, long n,
                           float lr, float momentum, float weight_decay, float grad_scale, int first_step);

@@ -28,11 +28,11 @@ extern "C" int lnn_device_info(int* cu_count, int* clock_khz, char* name, int na
 
 namespace {
 constexpr int NT = 256;
-constexpr int RED_BLOCKS = 2048;         // partial sums per reduction = what lnn_flat_reduce_ws_doubles() reports
+constexpr int RED_BLOCKS = 512;          // partial sums per reduction = what lnn_flat_reduce_ws_doubles() reports
 
 int red_blocks(long n) {                 // blocks of a two-stage reduction: <= RED_BLOCKS partial sums
     long b = (n + (long)NT * 16 - 1) / ((long)NT * 16);
-    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
 }
 
 int flat_blocks(long n, int per_thread) {
@@ -311,15 +311,13 @@ __global__ __launch_bounds__(NT) void fisher_kernel(const float* __restrict__ g,
     }
 }
 
-// One launch (round 4; the separate one-block reduce launch was 5 of the call's 29 us): every block leaves its partial pair, takes a
-// ticket, and the block that draws the LAST ticket adds all partials in index order (the order does not depend on which block
-// that is: bit-reproducible) and resets the ticket counter.  Four independent 16-byte loads per lane and iteration.
-__global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ g, long n, float unscale, double* out2, int vec,
-                                                      int accumulate, int unroll4, int fused) {
+// Four independent 16-byte loads per lane and iteration (round 4: 29.2 -> 23.0 us for the 125 MB arena, 4.28 -> 5.43 TB/s).  The
+// partial pairs are added by reduce_partials_kernel in index order (bit-reproducible).  Folding that second launch into this
+// kernel (ticket counter, the block that draws the last ticket adds the partials) was measured and rejected: the device-scope
+// release every block needs across the 8 XCD L2s cost 10 us, twice what the dependent launch costs
+// (profiles/r04_reduction_variants.txt).
+__global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ g, long n, float unscale, double* partial, int vec) {
     __shared__ double sm[2 * (NT / 64)];
-    __shared__ int is_last;
-    double* partial = out2 + 2;
-    unsigned* ticket = reinterpret_cast<unsigned*>(out2 + 2 + 2 * RED_BLOCKS);
     float acc[2] = {0.f, 0.f};
     const long n4 = vec ? n >> 2 : 0;
     const long stride = (long)gridDim.x * NT;
@@ -331,7 +329,6 @@ __global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ 
         }
     };
     long i = (long)blockIdx.x * NT + threadIdx.x;
-    if (unroll4)
     for (; i + 3 * stride < n4; i += 4 * stride) {
         const floatx4 a = reinterpret_cast<const floatx4*>(g)[i], b = reinterpret_cast<const floatx4*>(g)[i + stride],
                       c = reinterpret_cast<const floatx4*>(g)[i + 2 * stride], d = reinterpret_cast<const floatx4*>(g)[i + 3 * stride];
@@ -344,28 +341,7 @@ __global__ __launch_bounds__(NT) void gradnorm_kernel(const float* __restrict__ 
     }
     double v[2] = {(double)acc[0], (double)acc[1]};
     block_sum_d(v, sm);
-    if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = v[0]; partial[2 * blockIdx.x + 1] = v[1];
-        if (fused) {
-            __threadfence();
-            is_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
-        } else {
-            is_last = 0;
-        }
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    double t[2] = {0.0, 0.0};
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += NT) {
-        t[0] += __builtin_nontemporal_load(partial + 2 * b); t[1] += __builtin_nontemporal_load(partial + 2 * b + 1);
-    }
-    block_sum_d(t, sm);
-    if (threadIdx.x == 0) {
-        out2[0] = (accumulate ? out2[0] : 0.0) + t[0];
-        out2[1] = (accumulate ? out2[1] : 0.0) + t[1];
-        *ticket = 0u;
-    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = v[0]; partial[2 * blockIdx.x + 1] = v[1]; }
 }
 
 // torch.optim.SGD(nesterov=True, dampening=0): g += wd*theta; buf = g (first) | mu*buf + g; theta -= lr*(g + mu*buf)
@@ -651,24 +627,16 @@ extern "C" int lnn_fisher_ema(lnn_stream_t s_, const float* grad, float* fisher,
     return LNN_OK;
 }
 
-extern "C" long lnn_flat_reduce_ws_doubles(void) { return 2 + 2 * RED_BLOCKS + 1; }       // pair, partials, ticket counter
+extern "C" long lnn_flat_reduce_ws_doubles(void) { return 2 + 2 * RED_BLOCKS; }       // the pair, then the block partials
 
 extern "C" int lnn_gradnorm_sumsq(lnn_stream_t s_, const float* grad, long n, float unscale, double* out2, int zero_first) {
     hipStream_t s = (hipStream_t)s_;
     LNN_REQUIRE(grad && out2, "lnn_gradnorm_sumsq: null pointer");
-    // LNN_GRADNORM_VARIANT (A/B measurement, tools/gpu_r4_d.sh): bit 0 = 4 loads in flight per lane, bit 1 = one launch (ticketed
-    // last-block reduce) instead of two, bits 2.. = log2 of the block-count multiplier
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("LNN_GRADNORM_VARIANT"); var = e ? atoi(e) : 1; }
-    int nb = red_blocks(n) << (var >> 2);
-    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-    hipLaunchKernelGGL(gradnorm_kernel, dim3(nb), dim3(NT), 0, s, grad, n, unscale, out2, (int)lnn_aligned16(grad), zero_first ? 0 : 1,
-                       var & 1, (var >> 1) & 1);
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(nb), dim3(NT), 0, s, grad, n, unscale, out2 + 2, (int)lnn_aligned16(grad));
     LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq");
-    if (!((var >> 1) & 1)) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(NT), 0, s, out2 + 2, nb, out2, zero_first ? 0 : 1);
-        LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq(reduce)");
-    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(NT), 0, s, out2 + 2, nb, out2, zero_first ? 0 : 1);
+    LNN_CHECK_LAUNCH("lnn_gradnorm_sumsq(reduce)");
     return LNN_OK;
 }
 

@@ -196,8 +196,7 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
     float acc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.f;
-    for (long v = ((long)blockIdx.x * NT + threadIdx.x) * VEC; v < V; v += (long)gridDim.x * NT * VEC) {
-        float xv[KMAX][VEC], yv[VEC];
+    auto load = [&](long v, float (&xv)[KMAX][VEC], float (&yv)[VEC]) {
 #pragma unroll
         for (int k = 0; k < KK; ++k)
             if (KT > 0 || k < K) {
@@ -216,6 +215,8 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
         } else {
             yv[0] = yn[v];
         }
+    };
+    auto consume = [&](const float (&xv)[KMAX][VEC], const float (&yv)[VEC]) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float x[KMAX], p[KMAX], lse;
@@ -233,6 +234,22 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
                     if (k == lab) acc[3 * KK] += lse - x[k];
                 }
         }
+    };
+    // two voxel groups per iteration: their (K + 1) x 2 loads are in flight before the first softmax starts (the kernel is bound by
+    // the overlap of its ~80 VALU operations per voxel with the loads, not by HBM: 8 loads in flight instead of 4)
+    const long step = (long)gridDim.x * NT * VEC;
+    long v = ((long)blockIdx.x * NT + threadIdx.x) * VEC;
+    for (; v + step < V; v += 2 * step) {
+        float xa[KMAX][VEC], ya[VEC], xb[KMAX][VEC], yb[VEC];
+        load(v, xa, ya);
+        load(v + step, xb, yb);
+        consume(xa, ya);
+        consume(xb, yb);
+    }
+    for (; v < V; v += step) {
+        float xa[KMAX][VEC], ya[VEC];
+        load(v, xa, ya);
+        consume(xa, ya);
     }
     block_sum<NA>(acc, sm);
     if (threadIdx.x == 0) {
@@ -654,12 +671,10 @@ static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* l
     LNN_REQUIRE(logits && labels && out_loss && ws, "lnn_dice_ce_fwd: null pointer");
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
     LNN_REQUIRE(N >= 1 && N <= LNN_DICE_CE_MAX_BATCH, "lnn_dice_ce_fwd: batch %d unsupported (1..%d)", N, LNN_DICE_CE_MAX_BATCH);
-    // 512 blocks per launch at most (two 4-wave blocks per CU keep ~8 KB of 16-byte loads in flight per CU-block): the per-block
-    // reduction of 3K + 1 values and the finalize pass scale with the block count (1024 blocks per sample: finalize 25 us)
+    // 1024 blocks per launch at most: the per-block reduction of 3K + 1 values and the finalize pass scale with the block count
+    // (measured at 2 x 3 x 160x192x160, profiles/r04_reduction_variants.txt: 256 blocks 57 us, 512 / 1024 46 us, 2048 59 us)
     int nblk = vox_blocks(V);
-    static int total_cap = -1;            // LNN_DCE_BLOCKS (A/B measurement, tools/gpu_r4_d.sh)
-    if (total_cap < 0) { const char* e = getenv("LNN_DCE_BLOCKS"); total_cap = e ? atoi(e) : 1024; }
-    const int cap = total_cap / N > 1 ? total_cap / N : 1;
+    const int cap = 1024 / N > 1 ? 1024 / N : 1;
     if (nblk > cap) nblk = cap;
     const bool vec = (V & 3) == 0 && lnn_aligned16(logits) && lnn_aligned16(labels);
 #define LNN_DCE_FWD(KT, VEC) hipLaunchKernelGGL((dice_ce_fwd_kernel<KT, VEC>), dim3(nblk, N), dim3(NT), 0, s, logits, labels, K, V, ws, N)

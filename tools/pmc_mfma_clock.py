@@ -1,5 +1,5 @@
-"""profiles/r03_pmc_mfma_clock.json from a `rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
-SQ_BUSY_CYCLES` pass over bench.py (tools/gpu_r3_final.sh): for every MFMA kernel group of the step
+"""profiles/r04_pmc_mfma_clock.json from a `rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
+SQ_BUSY_CYCLES` pass over bench.py (tools/gpu_r4_pmc.sh): for every MFMA kernel group of the step
 
   clock_ghz      = GRBM_GUI_ACTIVE per dispatch / 8 XCDs (the counter is summed over the XCDs) / launch duration
   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8): share of the matrix pipes' CYCLES
@@ -10,7 +10,7 @@ The launch DURATION comes from a pass without GRBM / SQ counters (the FETCH_SIZE
 exactly 8x the duration for every kernel when GRBM_GUI_ACTIVE is collected (memory-bound kernels come out at the nominal
 2.2-2.5 GHz with the unperturbed duration, which is the check that this reading is right); ratios inside one pass are unaffected.
 
-usage: python tools/pmc_mfma_clock.py gpurun_out/<tag>/pmc_mfma.txt gpurun_out/<tag>/pmc_fetch.txt profiles/r03_pmc_mfma_clock.json
+usage: python tools/pmc_mfma_clock.py gpurun_out/<tag>/pmc_mfma.txt gpurun_out/<tag>/pmc_fetch.txt profiles/r04_pmc_mfma_clock.json
 """
 import json
 import re

@@ -1,10 +1,10 @@
-"""Turn the per-kernel PMC listings of tools/gpu_r3_pmc.sh (tools/rocpd_pmc.py --by-grid over separate FETCH_SIZE / WRITE_SIZE
-rocprofv3 passes of bench.py) into profiles/r03_pmc_traffic.json: HBM bytes per launch for every kernel group of the step.
+"""Turn the per-kernel PMC listings of tools/gpu_r4_pmc.sh (tools/rocpd_pmc.py --by-grid over separate FETCH_SIZE / WRITE_SIZE
+rocprofv3 passes of bench.py) into profiles/r04_pmc_traffic.json: HBM bytes per launch for every kernel group of the step.
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE is reported in KB and on gfx950 tallies the
 128-byte requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE is taken as reported (it equals the output size of
 the conv kernels exactly).
-usage: python tools/pmc_traffic.py gpurun_out/r3pmc profiles/r03_pmc_traffic.json
+usage: python tools/pmc_traffic.py gpurun_out/r4pmc profiles/r04_pmc_traffic.json
 """
 import json
 import re
@@ -72,7 +72,7 @@ def main(src, dst):
         alg = vox * (64 + 32) * 2
         return dict(r, algorithmic_bytes=alg, ratio_to_algorithmic=round(r["hbm_bytes_per_launch_corrected"] / alg, 3))
     out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py itself "
-                   "(tools/gpu_r3_pmc.sh, C2 step, weight gradients on the main stream, mean over 7 steps); FETCH_SIZE x2 per "
+                   "(tools/gpu_r4_pmc.sh, C2 step, weight gradients on the main stream, mean over 7 steps); FETCH_SIZE x2 per "
                    "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported; per launch",
            "layer": "conv_blocks_localization.4.0 64->32 @160x192x160 N=2 (algorithmic bytes 1.887 GB for each of the three)",
            "kernels": {"fwd": pick("conv_s1_v9<4,1,2,stats=1>", 131072), "dgrad": pick("conv_s1_v9<2,2,2,stats=0>", 131072),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Markdown table of the C2 step by kernel group from the committed evidence: launches and time per step (serialised trace),
 HBM bytes and TB/s per launch (PMC traffic pass), matrix-pipe busy share and shader clock (PMC MFMA pass).
-    python tools/step_table.py > /tmp/table.md        (inputs: profiles/r03_pmc_traffic.json, r03_pmc_mfma_clock.json)"""
+    python tools/step_table.py > /tmp/table.md        (inputs: profiles/r04_pmc_traffic.json, r04_pmc_mfma_clock.json)"""
 import json
 import os
 
@@ -9,9 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["all_kernels_over_40us"]
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))["all_kernels_over_40us"]
     ck = {(k["kernel"], k["grid_x"], k["size_rank"]): k
-          for k in json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_mfma_clock.json")))["kernels"]}
+          for k in json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mfma_clock.json")))["kernels"]}
     rows = sorted(tr, key=lambda r: -r["mean_us"] * r["launches_per_step"])
     tot = sum(r["mean_us"] * r["launches_per_step"] for r in rows)
     print("| kernel (launch-size cluster) | launches / step | µs / launch | ms / step | HBM GB / launch | TB/s | pipes busy | clock GHz |")
