@@ -235,18 +235,10 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
                 }
         }
     };
-    // two voxel groups per iteration: their (K + 1) x 2 loads are in flight before the first softmax starts (the kernel is bound by
-    // the overlap of its ~80 VALU operations per voxel with the loads, not by HBM: 8 loads in flight instead of 4)
+    // (two voxel groups per iteration -- 8 loads in flight instead of 4 -- measured SLOWER, 51 vs 46 us: the ~80 VALU operations per
+    // voxel bound this kernel, not the loads; profiles/r04_reduction_variants.txt)
     const long step = (long)gridDim.x * NT * VEC;
-    long v = ((long)blockIdx.x * NT + threadIdx.x) * VEC;
-    for (; v + step < V; v += 2 * step) {
-        float xa[KMAX][VEC], ya[VEC], xb[KMAX][VEC], yb[VEC];
-        load(v, xa, ya);
-        load(v + step, xb, yb);
-        consume(xa, ya);
-        consume(xb, yb);
-    }
-    for (; v < V; v += step) {
+    for (long v = ((long)blockIdx.x * NT + threadIdx.x) * VEC; v < V; v += step) {
         float xa[KMAX][VEC], ya[VEC];
         load(v, xa, ya);
         consume(xa, ya);

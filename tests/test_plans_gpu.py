@@ -80,16 +80,17 @@ def test_plan_driven_network_trains_like_the_oracle(name, storage):
         for a, b in zip(gout, oout):
             tol = 1e-4 if storage == "fp32" else 3e-2
             assert float((a.detach().cpu() - b.detach()).abs().max()) <= tol * max(1.0, float(b.detach().abs().max()))
+    # the 3-step update vector.  Conv biases are left out: in front of an InstanceNorm their gradient is analytically zero; the HIP
+    # path uses that zero, autograd sums fp32 rounding noise (~1e-9), so "error / own update" is 1 for those tensors by construction
+    # (engine.numeric_conv_bias_grad reproduces the noise sum if someone wants it)
     osd = onet.state_dict()
-    num = sum(float(((v.cpu() - osd[k]) ** 2).sum()) for k, v in net.state_dict().items())
-    den = sum(float(((osd[k] - init[k]) ** 2).sum()) for k in osd)
+    keys = [k for k in osd if not k.endswith("conv.bias")]
+    sd = net.state_dict()
+    num = sum(float(((sd[k].cpu() - osd[k]) ** 2).sum()) for k in keys)
+    den = sum(float(((osd[k] - init[k]) ** 2).sum()) for k in keys)
     print(f"{name} {storage}: relative error of the 3-step update {np.sqrt(num / den):.2e}")
-    per = sorted(((float((v.cpu() - osd[k]).norm() / ((osd[k] - init[k]).norm() + 1e-30)), k) for k, v in net.state_dict().items()),
-                 reverse=True)[:4]
-    print("   worst tensors (error / own update):", [(k, f"{e:.1e}") for e, k in per])
-    # relative to the UPDATE vector (3 steps at lr 1e-2 move theta by ~1e-3 of its norm, so fp32 round-off of theta itself is
-    # ~1e-4 of the update); relative to theta the fp32 engine sits at 1e-7
-    assert np.sqrt(num / den) < (2e-3 if storage == "fp32" else 6e-2)      # fp16: three steps of fp16-stored activation gradients
+    assert np.sqrt(num / den) < (1e-4 if storage == "fp32" else 6e-2)      # fp16: three steps of fp16-stored activation gradients
+    assert max(float((sd[k].cpu() - init[k]).abs().max()) for k in osd if k.endswith("conv.bias")) == 0.0
 
 
 def test_prostate_shaped_plan_through_the_trainer():
