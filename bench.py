@@ -42,12 +42,27 @@ WORKLOADS = {       # BASELINE.json configs[...]: (plans, trainer extension, des
 class ResidentBatches:
     """The reference's data dict, with tensors already in HBM (inputs resident when the timed region starts)."""
 
-    def __init__(self, gen, device, n=1):
-        self.items = []
-        for _ in range(n):
-            d = next(gen)
-            self.items.append({"data": d["data"].to(device), "target": [t.to(device) for t in d["target"]], "keys": d["keys"]})
+    def __init__(self, make_gen, device, n=1):
+        """``make_gen``: a generator, or a zero-argument callable that builds one on first use (the validation generators of the
+        benchmark trainers are never drawn from: their full-size synthetic batches are not generated at all)."""
+        self._make, self._device, self._n = make_gen, device, n
+        self._items = None
         self.i = 0
+        if not callable(make_gen):
+            self._fill()
+
+    def _fill(self):
+        gen = self._make() if callable(self._make) else self._make
+        self._items = []
+        for _ in range(self._n):
+            d = next(gen)
+            self._items.append({"data": d["data"].to(self._device), "target": [t.to(self._device) for t in d["target"]], "keys": d["keys"]})
+
+    @property
+    def items(self):
+        if self._items is None:
+            self._fill()
+        return self._items
 
     def __iter__(self):
         return self
@@ -363,7 +378,8 @@ def build_trainer(workload, device, rank):
     def provider(task, split, p):
         from lifelong_nnunet_amd.training.network_training.multihead.nnUNetTrainerMultiHead import default_data_provider
         # TWO distinct resident batches, alternated: no step sees the patch of the step before it
-        return ResidentBatches(default_data_provider(task, split, p, seed=12345 + 7919 * rank), device, n=2)
+        make = lambda: default_data_provider(task, split, p, seed=12345 + 7919 * rank)
+        return ResidentBatches(make() if split == "train" else make, device, n=2)
 
     kw = {"cases_per_task": 8} if ext == "rehearsal_ewc" else {}
     tr = Trainer("seg_outputs", "synthetic_task_A", plans=plans, data_provider=provider, device=device, fold=0, **kw)
