@@ -406,7 +406,8 @@ int lnn_f32_seg1x1_bwd(lnn_stream_t s, const float* z, int ld_z, const float* w,
  * their autograd for those shapes.  Di/Hi/Wi = the convolution's INPUT extents, output extents (D - 1) / s + 1;
  * D/H/W of the transposed entries = ITS input extents, output D * s.  splitk_ws (optional, may be NULL): fp32 scratch that lets
  * small volumes split the contraction over more waves; parts (optional): scratch of the deterministic weight gradient.
- * The tensors a call gathers from must be smaller than 2 GB (error otherwise, not a fallback).
+ * The tensors a call gathers from must be smaller than 2 GB and a weight-gradient call may loop over at most 2^24 voxels per launch
+ * (error otherwise, not a fallback: split the batch).
  * ---------------------------------------------------------------------------------------------- */
 int lnn_conv3d_fwd_g(lnn_stream_t s, const void* x, int ld_x, const void* wp, const float* bias, void* y, int ld_y, int N,
                      int Di, int Hi, int Wi, int C, int K, int kz, int ky, int kx, int sz, int sy, int sx, float* splitk_ws,
