@@ -429,6 +429,11 @@ int lnn_convT3d_k2s2_fwd_ws(lnn_stream_t s, const void* x, int ld_x, const void*
 int lnn_convT3d_k2s2_dgrad_ws(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int D,
                               int H, int W, int C, int K, int accumulate, float* splitk_ws, long splitk_elems);
 
+/* Launch configuration (process-wide, set before enqueueing; not thread-safe): the persistent MFMA kernels size their grids for `cus`
+ * CUs instead of the whole device (0 = all).  The two-lane engine uses it so that one sample's InstanceNorm / loss-side kernels run on
+ * the CUs the other sample's convolution leaves free (no counterpart in the reference: its kernels come from MIOpen / cuDNN). */
+int lnn_set_cu_budget(int cus);
+
 /* fp32 <-> fp16 helpers for the image input (N,1,D,H,W f32 -> fp16, same memory order when C == 1) */
 int lnn_cast_f32_to_h(lnn_stream_t s, const float* src, void* dst_h, long n);
 

@@ -426,7 +426,7 @@ int d2_num_cu() {
         hipDeviceProp_t prop;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    return num_cu;
+    return lnn_cu_budget(num_cu);
 }
 
 }  // namespace

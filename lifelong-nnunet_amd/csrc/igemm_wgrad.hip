@@ -1189,7 +1189,7 @@ int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
     }
     p.debug = dbg4; p.dbgbuf = dbgbuf4;
     // one block per CU: spread tiles x panels over ~num_cu blocks, >= 1 tile per block
-    int tpb = lnn_cdiv((long)p.tiles_total * panels, num_cu);
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, lnn_cu_budget(num_cu));
     if (tpb < 1) tpb = 1;
     if (tpb > p.tiles_total) tpb = p.tiles_total;
     p.tiles_per_block = tpb;
@@ -1288,7 +1288,7 @@ int launch_wgrad_s2(hipStream_t s, WgradParams& p, const char* name) {
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     // one 8-wave block per CU: tiles x panels over ~num_cu blocks, whole tiles per block
-    int tpb = lnn_cdiv((long)p.tiles_total * panels, num_cu);
+    int tpb = lnn_cdiv((long)p.tiles_total * panels, lnn_cu_budget(num_cu));
     if (tpb < 1) tpb = 1;
     if (tpb > p.tiles_total) tpb = p.tiles_total;
     p.tiles_per_block = tpb;

@@ -681,7 +681,7 @@ __global__ void in_lrelu_seg_bwd_sums_kernel(const float* pws, int nblk, int N, 
     const int i = (blockIdx.x - nb_in) * FEB + ii;
     double t[1] = {i < K * C ? slice_sum<FSL>(pseg + i, (long)K * C, nblk * N, sl) : 0.0};
     reduce_slices<FSL, 1>(t, red);
-    if (sl == 0 && i < K * C) dsegw[i] += (float)(t[0] * unscale);
+    if (sl == 0 && i < K * C) atomicAdd(dsegw + i, (float)(t[0] * unscale));      // (one add per entry and launch; two sample lanes may add concurrently)
 }
 
 // pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V) over y, dz rebuilt as in pass 1

@@ -129,7 +129,7 @@ __global__ void seg_bwd_finalize_kernel(const float* __restrict__ pws, int npart
     if (sl == 0 && i < K * C) {
 #pragma unroll
         for (int k = 1; k < 16; ++k) s += red[k * 16 + ii];
-        dw[i] += (float)(s * unscale);
+        atomicAdd(dw + i, (float)(s * unscale));       // (one add per entry and launch; two sample lanes may add concurrently)
     }
 }
 

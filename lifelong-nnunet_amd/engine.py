@@ -444,6 +444,11 @@ class UNetEngine:
         self.packed_version = -1
         self.unused_heads: List[str] = []
         self._side = None
+        self._lstreams, self._lws, self._lsplitk = [], [], []
+        # two-lane mode (see _fork): opt-in until it is measured on the whole step
+        self.sample_lanes = os.environ.get("LNN_SAMPLE_LANES", "0") == "1"
+        self.lane_cus = int(os.environ.get("LNN_LANE_CUS", "192"))
+        self.lane_stagger = os.environ.get("LNN_LANE_STAGGER", "1") == "1"
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
@@ -510,11 +515,61 @@ class UNetEngine:
             return _Ptr(obj.buf, n0 * obj.V * obj.ld + obj.off)
         return obj[n0:]
 
+    # ------------------------------------------------------------------------------------------ sample lanes
+    # Patches are independent through the whole network (InstanceNorm is per sample).  Two-lane mode (``sample_lanes``, round 4):
+    # the batch is processed as two halves on two HIP streams, their launches enqueued ALTERNATELY item by item, and the
+    # persistent MFMA kernels size their grids for ``lane_cus`` CUs (lnn_set_cu_budget) -- a persistent 8-wave block owns its CU's
+    # registers, so only CUs it does not occupy can run the other lane's HBM-bound normalisation / loss-side kernels.  Measured
+    # on one conv + one normalisation pass (profiles/r04_overlap_probe.txt): a 192-CU grid costs the conv 7 % (the part is
+    # power-limited) and hides the other sample's normalisation pass almost completely.  Round 1's two-lane mode had no CU
+    # budget and lost 1.5 %.
+    def _lanes(self):
+        if not self.sample_lanes or self.N < 2:
+            return [(0, self.N)]
+        h = self.N // 2
+        return [(0, h), (h, self.N - h)]
+
+    def _lane_streams(self, n):
+        while len(self._lstreams) < n:
+            self._lstreams.append(torch.cuda.Stream(device=self.device))
+            self._lws.append(torch.zeros_like(self.ws))
+            # every lane runs on its own stream: the split-K scratch of the small deep layers must not be shared either
+            self._lsplitk.append(self.splitk_ws if not self._lsplitk else torch.zeros_like(self.splitk_ws))
+        return self._lstreams[:n]
+
     def _fork(self, fn):
-        """Run fn(n0, nn, ws, splitk_ws) over the whole batch.  (A two-lane variant -- half the samples per HIP stream, so that one
-        lane's HBM-bound normalisation passes would run under the other lane's MFMA-bound convolutions -- measured 1.5 % SLOWER
-        on C2 in round 1: the 8-wave convolution blocks own their CU's register file, nothing co-schedules; removed in round 4.)"""
-        fn(0, self.N, self.ws, self.splitk_ws)
+        """``fn(n0, nn, ws, splitk_ws)`` is a GENERATOR that enqueues one item of the plan per step.  One lane: run it through.  Two
+        lanes: one generator per lane, each on its own stream (own workspaces), advanced alternately so that the two lanes' launches
+        interleave on the host as they are meant to on the chip; joined before returning."""
+        lanes = self._lanes()
+        if len(lanes) == 1:
+            for _ in fn(0, self.N, self.ws, self.splitk_ws):
+                pass
+            return
+        nat.call_plain("lnn_set_cu_budget", self.lane_cus)
+        main = torch.cuda.current_stream()
+        streams = self._lane_streams(len(lanes))
+        ev = torch.cuda.Event()
+        ev.record(main)
+        gens = []
+        for (n0, nn), st, ws, sk in zip(lanes, streams, self._lws, self._lsplitk):
+            st.wait_event(ev)
+            gens.append(fn(n0, nn, ws, sk))
+        alive = list(range(len(gens)))
+        first = True
+        while alive:
+            for i in list(alive):
+                if first and i > 0 and self.lane_stagger:
+                    continue                      # lane 1 starts one item late: its convolution meets lane 0's normalisation
+                with torch.cuda.stream(streams[i]):
+                    try:
+                        next(gens[i])
+                    except StopIteration:
+                        alive.remove(i)
+            first = False
+        for st in streams:
+            main.wait_stream(st)
+        nat.call_plain("lnn_set_cu_budget", 0)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, seg_weights: Optional[List[torch.Tensor]] = None, body: bool = True):
@@ -570,6 +625,7 @@ class UNetEngine:
                             nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
                                      nn, D, H, W, item.cin_k, C, item.stride)
                         nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
+                    yield                      # (two lanes: the other lane's next launch goes between the conv and its normalisation)
                     seg = self._seg_after.get(id(item))
                     if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
                         # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y
@@ -599,6 +655,7 @@ class UNetEngine:
                         w = self.pview(item.w) if sw is None else sw[u]
                         nat.call("lnn_seg1x1_fwd", at(item.x, n0), item.x.ld, w, logits[u][n0:], nn, item.x.V, item.cin, self.K)
                     u += 1
+                yield
 
         self._fork(lane)
         return logits
@@ -645,7 +702,11 @@ class UNetEngine:
         # data parallel (progress given): the weight gradients stay on the side stream; a layer's panel is folded into the
         # gradient arena there too, and the all-reduce of every bucket that became final is launched FROM the side stream
         # (parallel.GradAllReducer.progress): two streams share the chip, as in the single-GPU plan
-        side = self._side_stream() if self.overlap_wgrad else None
+        multi = len(self._lanes()) > 1
+        assert not (multi and (progress is not None or self.deterministic_wgrad)), \
+            "two-lane mode (LNN_SAMPLE_LANES=1) is single-GPU and uses the atomic weight-gradient panels"
+        # two lanes: each lane runs its weight gradients on its own stream (the OTHER lane is what overlaps with them)
+        side = self._side_stream() if (self.overlap_wgrad and not multi) else None
 
         def on_side(fn):
             if side is None:
@@ -727,7 +788,9 @@ class UNetEngine:
                                      0 if det is None else det.numel())
                             if per_layer_unpack:
                                 unpack(item)
+                        yield
                         on_side(lambda: self._probed("wgrad", item, first_wgrad))
+                        yield
                         continue
                     else:
                         self._probed("in_bwd", item, lambda: nat.call(
@@ -735,6 +798,7 @@ class UNetEngine:
                             item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
                             self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
                             self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws))
+                    yield                          # (two lanes: between the normalisation backward and the MFMA kernels)
                     D, H, W = item.in_dims
                     xin = at(self.image, n0) if item.x is None else at(item.x, n0)
                     ldx = 1 if item.x is None else item.x.ld
@@ -762,6 +826,7 @@ class UNetEngine:
                             nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
                                      item.stride)
                     on_side(conv_wgrad)
+                    yield
                     if item.first or item.gx is None:
                         pass                                   # the first convolution has no data gradient
                     elif not item.iso:
@@ -799,6 +864,7 @@ class UNetEngine:
                             nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
                                      self._pn(item.panel), nn, D, H, W, C, K)
                     on_side(up_wgrad)
+                    yield
                     if item.iso:
                         self._probed("dgrad", item, lambda: nat.call(
                             "lnn_convT3d_k2s2_dgrad_ws", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
@@ -807,6 +873,7 @@ class UNetEngine:
                         self._probed("dgrad", item, lambda: nat.call(
                             "lnn_convT3d_dgrad_g", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
                             item.gx.ld, nn, D, H, W, C, K, *item.strides, 0, splitk_ws, splitk_ws.numel()))
+                yield
 
         self._fork(lane)
         if side is not None:

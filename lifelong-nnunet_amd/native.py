@@ -105,6 +105,7 @@ SIGNATURES = {
     "lnn_debug_force_down2_kernel": (_i, [_i]),
     "lnn_debug_set_v9_zseg": (_i, [_i]),
     "lnn_debug_set_gen_mode": (_i, [_i]),
+    "lnn_set_cu_budget": (_i, [_i]),
     # generic geometry (kernel extent 1 / 3 and stride 1 / 2 per axis; transposed convolutions with kernel == stride)
     "lnn_conv3d_fwd_g": (_i, [_p, _p, _i, _p, _p, _p, _i] + [_i] * 12 + [_p, _l]),
     "lnn_conv3d_dgrad_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 13 + [_p, _l]),
@@ -158,6 +159,13 @@ def call(name, *args):
     rc = fn(stream_handle(), *[_ptr(a) if (a is None or hasattr(a, "data_ptr")) else a for a in args])
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {h.lnn_last_error().decode()}")
+
+
+def call_plain(name, *args):
+    """Invoke an entry point that takes no stream (launch configuration)."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib().lnn_last_error().decode()}")
 
 
 def query(name, *args):
