@@ -226,6 +226,7 @@ class UNetEngine:
         assert conv_per_stage == 2, "nnUNetTrainerV2 uses conv_per_stage=2 (nnViTUNetTrainer.py:119)"
         assert base_features % 8 == 0, "channel counts must be multiples of 8 (16-byte vectors)"
         self.arena = arena
+        self._pviews = {}
         pools, kernels, dims = unet_geometry(num_pool, patch_size, pool_op_kernel_sizes, conv_kernel_sizes)
         self.pools, self.kernels = pools, kernels
         self.in_channels, self.base, self.K, self.num_pool = in_channels, base_features, num_classes, num_pool
@@ -487,8 +488,14 @@ class UNetEngine:
 
     # ------------------------------------------------------------------------------------------ views
     def pview(self, slot: ParamSlot, arena=None):
+        """View of a parameter slot in theta (default) or another flat arena; memoised: a step asks ~600 times and a fresh
+        slice + view costs 4 us of host time each (the arenas never move)."""
         a = self.theta if arena is None else arena
-        return a[slot.offset:slot.offset + slot.numel].view(slot.shape)
+        key = (slot.name, a.data_ptr())
+        v = self._pviews.get(key)
+        if v is None:
+            v = self._pviews[key] = a[slot.offset:slot.offset + slot.numel].view(slot.shape)
+        return v
 
     def _wp(self, off):
         return _Ptr(self.wpanels, off)
@@ -513,7 +520,7 @@ class UNetEngine:
         """Pointer to sample n0 of an activation (Act) or batch-major tensor."""
         if isinstance(obj, Act):
             return _Ptr(obj.buf, n0 * obj.V * obj.ld + obj.off)
-        return obj[n0:]
+        return _Ptr(obj, n0 * obj.stride(0)) if n0 else obj
 
     # ------------------------------------------------------------------------------------------ sample lanes
     # Patches are independent through the whole network (InstanceNorm is per sample).  Two-lane mode (``sample_lanes``, round 4):
@@ -556,17 +563,22 @@ class UNetEngine:
             st.wait_event(ev)
             gens.append(fn(n0, nn, ws, sk))
         alive = list(range(len(gens)))
+        handles = [st.cuda_stream for st in streams]
         first = True
-        while alive:
-            for i in list(alive):
-                if first and i > 0 and self.lane_stagger:
-                    continue                      # lane 1 starts one item late: its convolution meets lane 0's normalisation
-                with torch.cuda.stream(streams[i]):
+        try:
+            while alive:
+                for i in list(alive):
+                    if first and i > 0 and self.lane_stagger:
+                        continue                      # lane 1 starts one item late: its convolution meets lane 0's normalisation
+                    # the lane's launches name their stream directly (no torch op runs inside a lane)
+                    nat.set_stream_override(handles[i])
                     try:
                         next(gens[i])
                     except StopIteration:
                         alive.remove(i)
-            first = False
+                first = False
+        finally:
+            nat.set_stream_override(None)
         for st in streams:
             main.wait_stream(st)
         nat.call_plain("lnn_set_cu_budget", 0)
@@ -603,7 +615,7 @@ class UNetEngine:
                     ldx = 1 if item.x is None else item.x.ld
                     C = item.cout
                     V = item.z.V
-                    mean, rstd = item.mean[n0 * C:], item.rstd[n0 * C:]
+                    mean, rstd = _Ptr(item.mean, n0 * C), _Ptr(item.rstd, n0 * C)
                     if not item.iso:
                         # per-axis kernel / stride from the plans: generic-geometry kernel, statistics as a separate pass
                         self._probed("fwd", item, lambda: nat.call(
@@ -632,7 +644,7 @@ class UNetEngine:
                         self._probed("in_fwd", item, lambda: nat.call(
                             "lnn_instnorm_lrelu_seg_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
                             self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, self.pview(seg.w),
-                            logits[self.segs.index(seg)][n0:], self.K))
+                            at(logits[self.segs.index(seg)], n0), self.K))
                         fused_segs.add(id(seg))
                     else:
                         self._probed("in_fwd", item, lambda: nat.call(
@@ -653,7 +665,7 @@ class UNetEngine:
                 else:
                     if id(item) not in fused_segs:
                         w = self.pview(item.w) if sw is None else sw[u]
-                        nat.call("lnn_seg1x1_fwd", at(item.x, n0), item.x.ld, w, logits[u][n0:], nn, item.x.V, item.cin, self.K)
+                        nat.call("lnn_seg1x1_fwd", at(item.x, n0), item.x.ld, w, at(logits[u], n0), nn, item.x.V, item.cin, self.K)
                     u += 1
                 yield
 
@@ -752,13 +764,14 @@ class UNetEngine:
                     dl = dls[seg_u]
                     if dl is None:
                         if not item.gx_has_prior:
+                            assert not multi, "two-lane mode: every full-resolution head has a gradient (deep-supervision weight > 0)"
                             item.gx.buf[n0:n0 + nn].zero_()
                         continue
                     if fuse_seg:
                         pending[id(item.x_block)] = (item, dl)
                         continue
                     gw = self.pview(item.w, self.grad).view(self.K, item.cin)
-                    nat.call("lnn_seg1x1_bwd", at(item.x, n0), item.x.ld, self.pview(item.w), dl[n0:], at(item.gx, n0),
+                    nat.call("lnn_seg1x1_bwd", at(item.x, n0), item.x.ld, self.pview(item.w), at(dl, n0), at(item.gx, n0),
                              item.gx.ld, gw, nn, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0, ws)
                 elif skip_body:
                     continue
@@ -768,22 +781,22 @@ class UNetEngine:
                         seg, dl = pending.pop(id(item))
                         self._probed("in_bwd", item, lambda: nat.call(
                             "lnn_instnorm_lrelu_seg_bwd", at(item.y, n0), at(item.gz, n0) if seg.gx_has_prior else None,
-                            item.gz.ld, self.pview(seg.w), dl[n0:], self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
-                            nn, V, K, item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta),
+                            item.gz.ld, self.pview(seg.w), at(dl, n0), self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
+                            nn, V, K, _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta),
                             LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
                     elif item.cin_k == 1 and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
                         # the first block has no data gradient: only the sums of its normalisation backward are taken here,
                         # dy is rebuilt tile by tile inside the weight gradient below (lnn_conv3d_wgrad_c1_in_bwd)
                         self._probed("in_bwd", item, lambda: nat.call(
                             "lnn_instnorm_lrelu_bwd_sums", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                            item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                            _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
                             self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
                         D, H, W = item.in_dims
 
                         def first_wgrad(item=item, K=K, D=D, H=H, W=W):
                             det = self._det_scratch()
                             nat.call("lnn_conv3d_wgrad_c1_in_bwd", at(self.image, n0), at(item.y, n0), at(item.gz, n0), item.gz.ld,
-                                     self._pn(item.panel), nn, D, H, W, K, item.mean[n0 * K:], item.rstd[n0 * K:],
+                                     self._pn(item.panel), nn, D, H, W, K, _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K),
                                      self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, ws, det,
                                      0 if det is None else det.numel())
                             if per_layer_unpack:
@@ -795,7 +808,7 @@ class UNetEngine:
                     else:
                         self._probed("in_bwd", item, lambda: nat.call(
                             "lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                            item.mean[n0 * K:], item.rstd[n0 * K:], self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                            _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
                             self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
                             self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws))
                     yield                          # (two lanes: between the normalisation backward and the MFMA kernels)

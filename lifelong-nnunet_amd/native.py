@@ -147,18 +147,42 @@ def _ptr(t):
     return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
 
 
+_stream_override = None      # two-lane mode: the engine names the lane's stream itself (a torch.cuda.stream() context per launch costs 10+ us)
+
+
+def set_stream_override(handle):
+    global _stream_override
+    _stream_override = handle
+
+
 def stream_handle():
+    if _stream_override is not None:
+        return _stream_override
     import torch
     return torch.cuda.current_stream().cuda_stream
 
 
+_fn_cache = {}
+
+
 def call(name, *args):
-    """Invoke ``lnn_<name>`` on torch's current stream; tensors are passed as device pointers."""
-    h = lib()
-    fn = getattr(h, name)
-    rc = fn(stream_handle(), *[_ptr(a) if (a is None or hasattr(a, "data_ptr")) else a for a in args])
+    """Invoke ``lnn_<name>`` on torch's current stream; tensors (anything with ``data_ptr``) are passed as device pointers.
+    Host cost matters: a training step is ~270 calls (540 in two-lane mode) and must stay ahead of the GPU."""
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(lib(), name)
+    conv = []
+    for a in args:
+        c = a.__class__
+        if c is int or c is float or a is None:
+            conv.append(a)
+        elif hasattr(a, "data_ptr"):
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    rc = fn(stream_handle(), *conv)
     if rc != 0:
-        raise RuntimeError(f"{name} failed ({rc}): {h.lnn_last_error().decode()}")
+        raise RuntimeError(f"{name} failed ({rc}): {lib().lnn_last_error().decode()}")
 
 
 def call_plain(name, *args):
