@@ -196,6 +196,21 @@ int lnn_instnorm_lrelu_bwd_sums(lnn_stream_t s, const void* y_h, const void* dz_
 int lnn_conv3d_wgrad_c1_in_bwd(lnn_stream_t s, const void* x_h, const void* y_h, const void* dz_h, int ld_dz, float* dwp, int N,
                                int D, int H, int W, int K, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, float slope, const double* ws, float* parts, long parts_elems);
+/* Pass 1 of lnn_instnorm_lrelu_bwd taken in the epilogue of the data gradient that PRODUCES dz (ConvDropoutNormNonlin pairs of a
+ * StackedConvLayers stage, test_MultiHead_Module.py:287-291: block 0 = conv, instnorm, lrelu -> block 1 = conv ...; the backward of
+ * block 1's convolution writes dL/dz of block 0).  lnn_conv3d_dgrad_in_bwd_sums = lnn_conv3d_dgrad_ws(stride 1, no accumulate) into
+ * dx, followed by lnn_instnorm_lrelu_bwd_sums(u, dx, ...) for the block whose convolution output is u (dense [N][V][C] fp16,
+ * untouched): same outputs (dx, ws sums, dgamma / dbeta (+)=).  For 32 -> 32 channels on long z columns (the highest resolution)
+ * the reduce is fused into the z-streaming data-gradient kernel (dz is reduced from the registers it is stored from, u arrives by
+ * direct-to-LDS loads beside the input planes): dz and u are not read a second time (-4 of the 10 B per element the backward of
+ * the normalisation moves); other shapes run the two calls.  lnn_instnorm_lrelu_bwd_apply is pass 2 alone (dy in place over y
+ * from the sums in ws).  ws: >= lnn_instnorm_ws_doubles(N, C), the same workspace for both calls. */
+int lnn_conv3d_dgrad_in_bwd_sums(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int Di,
+                                 int Hi, int Wi, int C, int K, const void* u_h, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, float slope, float* dgamma, float* dbeta,
+                                 float grad_unscale, double* ws, float* splitk_ws, long splitk_elems);
+int lnn_instnorm_lrelu_bwd_apply(lnn_stream_t s, void* y_h, const void* dz_h, int ld_dz, int N, long V, int C, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, float slope, double* ws);
 
 /* ------------------------------------------------------------------------------------------------
  * seg_outputs[u]: nn.Conv3d 1x1x1, no bias (test_MultiHead_Module.py:427-431).

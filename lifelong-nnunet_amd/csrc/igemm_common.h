@@ -28,6 +28,13 @@ struct ConvParams {
     int accumulate;
     float* stats_pws = nullptr;   // v9 only: fused InstanceNorm statistics partials [2][stats_nblk][N][M] (see igemm_conv_v9.hip)
     int stats_nblk = 0;
+    // v9 data gradient only: pass 1 of the InstanceNorm + LeakyReLU backward of the block that produced this layer's input, taken in
+    // the epilogue (igemm_conv_v9.hip, EPI = 2).  red_u = that block's convolution output [N][Do][Ho][Wo][red_ld], M channels;
+    // partials of sum g and sum g u land in stats_pws like the statistics
+    const half_t* red_u = nullptr;
+    int red_ld = 0;
+    const float *red_mean = nullptr, *red_rstd = nullptr, *red_gamma = nullptr, *red_beta = nullptr;
+    float red_slope = 0.f;
     int ksplit = 1;               // v7 only: the 16-channel chunk loop of a unit is split over ksplit blocks which write fp32 partial
     float* scratch = nullptr;     //   sums to scratch[part][voxel][Mpad]; lnn_launch_splitk_finalize adds the slices and converts
     unsigned long long* dbg;   // optional phase-cycle accumulators (LNN_DEBUG_PHASES), null in production
@@ -51,9 +58,12 @@ int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name);
 // v9 (igemm_conv_v9.hip): z-streaming, register-resident weights, direct-to-LDS input ring (C = 32 / 64, M % 32 == 0)
 bool lnn_conv_s1_v9_supported(const ConvParams& p);
 int lnn_conv_s1_v9_stats_slots(const ConvParams& p);
+bool lnn_conv_s1_v9_red_supported(const ConvParams& p);      // a fused-reduce instance (EPI = 2) exists for this shape
 // norm_act.hip: mean / rstd from per-slot partial sums pws[a][slot][n*C + c] (the finalize half of lnn_instnorm_stats)
 int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name);
 int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd);
+int lnn_launch_in_bwd_sums_raw(hipStream_t s, const float* pws, int nslots, int N, int C, const float* mean, const float* rstd,
+                               double* ws, float* dgamma, float* dbeta, float unscale);
 int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name);
 // single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,
 // all eight output parity classes per block

@@ -473,6 +473,55 @@ extern "C" int lnn_conv3d_dgrad_ws(lnn_stream_t s, const void* dy, int ld_dy, co
     return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, stride, accumulate, splitk_ws, splitk_elems);
 }
 
+// Data gradient of a stride-1 3x3x3 convolution whose input was produced by an InstanceNorm + LeakyReLU block, TOGETHER with pass 1
+// of that block's backward (sum g, sum g xhat per (sample, channel), the affine gradients): afterwards dx holds dL/dz of the block
+// and ws its sums, exactly as after lnn_conv3d_dgrad_ws + lnn_instnorm_lrelu_bwd_sums(u, dx, ...); lnn_instnorm_lrelu_bwd_apply (or
+// the first layer's fused weight gradient) is the second half.  Where a fused instance exists (igemm_conv_v9.hip EPI = 2: 32 -> 32
+// channels on long z columns, the highest resolution) the reduce rides the data gradient's epilogue and dz / u are not read again;
+// everywhere else this IS the two calls.  u = the block's convolution output (dense, C channels), untouched.
+static int g_last_dgrad_reduce_fused = 0;
+extern "C" int lnn_debug_last_dgrad_reduce_fused(void) { return g_last_dgrad_reduce_fused; }
+
+extern "C" int lnn_conv3d_dgrad_in_bwd_sums(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N,
+                                            int Di, int Hi, int Wi, int C, int K, const void* u, const float* mean, const float* rstd,
+                                            const float* gamma, const float* beta, float slope, float* dgamma, float* dbeta,
+                                            float grad_unscale, double* ws, float* splitk_ws, long splitk_elems) {
+    hipStream_t s = (hipStream_t)s_;
+    LNN_REQUIRE(u && lnn_aligned16(u) && mean && rstd && gamma && beta && ws, "lnn_conv3d_dgrad_in_bwd_sums: null / misaligned parameter");
+    const long V = (long)Di * Hi * Wi;
+    ConvParams p{};
+    p.x = (const half_t*)dy; p.y = (half_t*)dx; p.ld_x = ld_dy; p.ld_y = ld_dx; p.N = N;
+    p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Do = Di; p.Ho = Hi; p.Wo = Wi; p.C = K; p.M = C; p.os = 1;
+    p.Ld = Di; p.Lh = Hi; p.Lw = Wi; p.pad_lo = 1;
+    p.red_ld = C;
+    static int no_fuse = -1;
+    if (no_fuse < 0) { const char* e = getenv("LNN_NO_FUSED_IN_BWD_REDUCE"); no_fuse = (e && e[0] == '1') ? 1 : 0; }
+    const bool fused = !no_fuse && wp && dx && dy && lnn_aligned16(dx) && lnn_aligned16(dy) && use_v9(p) && lnn_conv_s1_v9_red_supported(p) &&
+                       !lnn_gen_prefers(LNN_GEN_OP_CONV_S1, (long)N * V);
+    g_last_dgrad_reduce_fused = fused ? 1 : 0;
+    if (!fused) {
+        if (int e = conv3d_dgrad_impl(s_, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, 1, 0, splitk_ws, splitk_elems)) return e;
+        return lnn_instnorm_lrelu_bwd_sums(s_, u, dx, ld_dx, N, V, C, mean, rstd, gamma, beta, slope, dgamma, dbeta, grad_unscale, ws);
+    }
+    LNN_REQUIRE(lnn_aligned16(wp), "lnn_conv3d_dgrad_in_bwd_sums: weight panel misaligned");
+    if (int e = check_act(dy, ld_dy, K, "lnn_conv3d_dgrad_in_bwd_sums(dy)")) return e;
+    if (int e = check_act(dx, ld_dx, C, "lnn_conv3d_dgrad_in_bwd_sums(dx)")) return e;
+    p.wp = (const half_t*)wp; p.bias = nullptr;
+    p.Mpad = lnn_round_up(C, 32); p.KCpad = lnn_round_up(K, 16); p.wtaps = 27;
+    p.taps.ntaps = 27;
+    for (int t = 0; t < 27; ++t) {           // as conv3d_dgrad_impl: tap offset d' = 2 - d uses slot d
+        const int dz = t / 9, dyy = (t / 3) % 3, dxx = t % 3;
+        p.taps.pos_off[t] = (unsigned short)((dz * 10 + dyy) * 10 + dxx);
+        p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
+    }
+    p.dbg = g_dbg;
+    float* pws = reinterpret_cast<float*>(ws + (size_t)N * C * 3);           // the region lnn_instnorm_lrelu_bwd_sums uses
+    p.stats_pws = pws;
+    p.red_u = (const half_t*)u; p.red_mean = mean; p.red_rstd = rstd; p.red_gamma = gamma; p.red_beta = beta; p.red_slope = slope;
+    if (int e = lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad_in_bwd_sums(s1,v9,reduce)")) return e;
+    return lnn_launch_in_bwd_sums_raw(s, pws, p.stats_nblk, N, C, mean, rstd, ws, dgamma, dbeta, grad_unscale);
+}
+
 extern "C" int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx_a, void* dx_b, int ld_dx,
                                     int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate) {
     if (int e = check_cat(dx_b, c_a, C, 1, "lnn_conv3d_dgrad_cat")) return e;

@@ -42,7 +42,7 @@ struct IC { static constexpr int value = V; };
 // moving LDS accesses across the wait / the raw s_barrier that follows it.
 template <int N, bool LGKM>
 __device__ __forceinline__ void wait_vm() {
-    static_assert(N >= 0 && N <= 6, "extend the table");
+    static_assert(N >= 0 && N <= 8, "extend the table");
     if constexpr (LGKM) {
         if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
@@ -51,6 +51,8 @@ __device__ __forceinline__ void wait_vm() {
         if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+        if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     } else {
         if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -59,6 +61,8 @@ __device__ __forceinline__ void wait_vm() {
         if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
 }
 
@@ -67,6 +71,7 @@ __device__ __forceinline__ void wait_vm() {
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voffset, 0, 0, 0);
 }
+
 
 __device__ __forceinline__ void lane_voxel9(int v, int& r, int& x) {   // see igemm_conv_v2.hip
     if (v < 4) { r = 0; x = v; }
@@ -96,23 +101,42 @@ struct V9 {
     static constexpr int QN = 4 / NFIN;                      // accumulator quads a finalising wave owns
     static constexpr int EXB = NF * NMB * NFIN * (NCK - 1) * QN * 1024;   // one partial-sum exchange buffer
     static constexpr int LDS = R * PLANE + 2 * EXB;
+    // fused normalisation-backward reduce (EPI = 2, NCK = 2): per plane every wave brings 16 bytes per lane of u
+    static constexpr int UD = 1, UW = 1024, UB = 8 * UW;
+    static constexpr int LDS_RED = LDS + R * UB + 2 * 32 * NMB * 4;
 };
 
 struct V9Launch {
     int items, S, L, tiles_y, tiles_x, nslots, ipx;
 };
 
-// STATS: the epilogue also accumulates sum / sum of squares of the STORED (fp16-rounded) outputs per (sample, channel) --
-// the InstanceNorm statistics pass of the next op (norm_act.hip:in_stats_kernel) without re-reading the tensor.  Partials
-// go to p.stats_pws[a][slot][n][c] (a = 0 sum, 1 sum of squares; slot = block * NF + footprint: every slot row is owned by
-// one wave, so the accumulation is a plain read-modify-write and the result is deterministic).
-template <int NCK_, int NMB_, int NF_, bool STATS>
+// EPI = 1 (statistics): the epilogue also accumulates sum / sum of squares of the STORED (fp16-rounded) outputs per (sample,
+// channel) -- the InstanceNorm statistics pass of the next op (norm_act.hip:in_stats_kernel) without re-reading the tensor.
+// Partials go to p.stats_pws[a][slot][n][c] (a = 0 sum, 1 sum of squares; slot = block * NF + footprint: every slot row is owned
+// by one wave, so the accumulation is a plain read-modify-write and the result is deterministic).
+// EPI = 2 (data gradient only; round 4): the output is dL/dz of an InstanceNorm + LeakyReLU block whose convolution output u
+// (p.red_u) is still in memory, and the epilogue takes pass 1 of that block's backward (norm_act.hip:in_lrelu_bwd_reduce_kernel)
+// with it: g = dz * lrelu'(a u + b) (a = gamma rstd, b = beta - a mean; dz = the STORED fp16 value), partials of sum g and
+// sum g u in the same slot rows (norm_act.hip:in_lrelu_bwd_sums_kernel with raw_mean turns sum g u into sum g xhat in fp64).  u's
+// tile of an output plane rides the input ring: each wave fetches the 16 bytes per lane it will need by ONE direct-to-LDS load next
+// to the input plane that is consumed in the step that stores this output plane -- no registers held across steps, the same
+// counted waits.  No bias in this mode (a data gradient has none).  Instantiated for 32 input channels only (NCK = 2, where a lane
+// stores 8 consecutive channels): +2.5 % on the data gradient against a 0.145 ms reduce pass; the 64-channel variant (8 bytes per
+// lane by two 4-byte direct loads, 32 cache lines each) cost the kernel +28 % -- as much as the pass it removes -- and was dropped
+// (profiles/r04_fused_in_bwd_reduce.txt).
+template <int NCK_, int NMB_, int NF_, int EPI>
 __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvParams p, const V9Launch q) {
     using K = V9<NCK_, NMB_, NF_>;
+    constexpr bool STATS = EPI == 1, RED = EPI == 2;
     constexpr int NCK = K::NCK, NMB = K::NMB, NFX = K::NFX, PXS = K::PXS, PY = K::PY, PX = K::PX;
     constexpr int GSLAB = K::GSLAB, PLANE = K::PLANE, DPW = K::DPW, D = K::D, R = K::R, QN = K::QN, EXB = K::EXB, NFIN = K::NFIN;
+    static_assert(!RED || NCK == 2, "fused normalisation-backward reduce: every wave finalises 8 consecutive channels per lane");
+    constexpr int UW = K::UW, UB = K::UB;                     // bytes of u per wave / per ring slot
+    constexpr int DPT = DPW + (RED ? K::UD : 0);              // direct-to-LDS loads per wave and plane (the unit of the counted waits)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const exch = smem + R * PLANE;
+    char* const uring = exch + 2 * EXB;                       // RED: [R][8 waves][UW]
+    float* const abl = reinterpret_cast<float*>(uring + R * UB);   // RED: a[32 NMB], b[32 NMB] of the item's (sample, channel block)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             }
 #pragma unroll
             for (int i = 0; i < 4 * QN; ++i) biasv[i] = 0.f;
-            if (p.bias && fin) {
+            if (!RED && p.bias && fin) {
                 // the channels of this lane's own accumulator quads: quad qq, register i -> m0 + 8 QN ck + 8 qq + 4 hk + i
 #pragma unroll
                 for (int i = 0; i < 4 * QN; ++i) biasv[i] = p.bias[m0 + 8 * QN * ck + 8 * (i >> 2) + 4 * hk + (i & 3)];
@@ -215,9 +239,19 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         }
 
         // ---- per-item lane offsets ----
-        float ssum[4 * QN], ssq[4 * QN];
+        float ssum[4 * QN], ssq[4 * QN];      // STATS: sum y, sum y^2;  RED: sum g, sum g u (of the lane's 4 QN output channels)
 #pragma unroll
         for (int i = 0; i < 4 * QN; ++i) ssum[i] = ssq[i] = 0.f;
+        if constexpr (RED) {
+            // mask constants of this item's (sample, 32 NMB channels): written after the previous item's closing barrier, read
+            // from step 3 on (the prologue's barrier lies between)
+            if (tid < 32 * NMB) {
+                const int c = 32 * NMB * mg + tid;
+                const float a = p.red_gamma[c] * p.red_rstd[n * p.M + c];
+                abl[tid] = a;
+                abl[32 * NMB + tid] = p.red_beta[c] - a * p.red_mean[n * p.M + c];
+            }
+        }
         int dvoff[DPW];
 #pragma unroll
         for (int k = 0; k < DPW; ++k) {
@@ -226,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             const bool ok = dpk[k] >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             dvoff[k] = ok ? drel[k] + (y0 * p.Wi + x0) * p.ld_x * 2 : (int)0x80000000;
         }
-        int svoff;
+        int svoff, uvoff = 0;
         half_t* yten;
         {
             const int oy = y0 + 4 * fyi + vr, ox = x0 + 8 * fxi + vx;
@@ -235,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             yten = part2 ? p.y2 : p.y;
             const int ch = (part2 ? m0 - p.msplit : m0) + (NCK == 2 ? 16 * ck + 8 * hk : 8 * ck + 4 * hk);
             svoff = ok ? ((oy * p.Wo + ox) * p.ld_y + ch) * 2 : (int)0x80000000;
+            if constexpr (RED) uvoff = ok ? ((oy * p.Wo + ox) * p.red_ld + m0 + 16 * ck + 8 * hk) * 2 : (int)0x80000000;
         }
 
         // running plane pointers / ring offsets (scalar): no multiplications in the plane loop
@@ -244,7 +279,10 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         for (int k = 0; k < DPW; ++k) din[k] = gten[k] + ((long)n * p.Di + (zs0 - 1)) * in_plane;
         const int tp_lo = zs0 >= 1 ? 0 : 1;                            // planes tp in [tp_lo, tp_hi) lie inside the volume
         const int tp_hi = min(T, p.Di - (zs0 - 1));
-        int dtp = 0, dslot_off = 0;
+        int dtp = 0, dslot_off = 0, duo = 0;
+        // RED: u of the output plane that the step consuming input plane dtp stores (z = zs0 + dtp - 3; real for dtp in [3, T])
+        const long u_plane = (long)p.Ho * p.Wo * p.red_ld;
+        const half_t* uin = RED ? p.red_u + ((long)n * p.Do + (zs0 - 3)) * u_plane : nullptr;
         auto dma = [&]() {                  // next plane of this item (input z = zs0 - 1 + dtp) -> next ring slot
             const bool zok = dtp >= tp_lo && dtp < tp_hi;
             const int nrec = zok ? (int)in_plane_bytes : 0;
@@ -255,6 +293,13 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 dma16(rs, smem + dslot_off + j * 1024, dvoff[k]);
                 din[k] += in_plane;
             }
+            if constexpr (RED) {
+                const int urec = (dtp >= 3 && dtp <= T) ? (int)((unsigned)p.Ho * p.Wo * p.red_ld * 2u) : 0;
+                __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)uin, 0, urec, 0x00020000);
+                dma16(ru, uring + duo + wave * UW, uvoff);
+                uin += u_plane;
+                duo = duo + UB == R * UB ? 0 : duo + UB;
+            }
             ++dtp;
             dslot_off = dslot_off + PLANE == R * PLANE ? 0 : dslot_off + PLANE;
         };
@@ -263,11 +308,34 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         // Split in two so that the LDS reads are in flight while the first MFMAs of the step issue.
         half_t* optr = yten + ((long)n * p.Do + (zs0 - 3)) * out_plane;      // plane of tprev = -1
         floatx4 pv[(NCK - 1) * QN];
+        uint4v ur = {0, 0, 0, 0};            // RED: this lane's channels of u at its voxel of the plane being stored
+        int ruo = 0;
         auto fin_load = [&](int tprev) {
             if (!fin) return;
             const char* eb = exch + (tprev & 1) * EXB + rbase;
 #pragma unroll
             for (int s = 0; s < (NCK - 1) * QN; ++s) pv[s] = *reinterpret_cast<const floatx4*>(eb + s * 1024);
+            if constexpr (RED) ur = *reinterpret_cast<const uint4v*>(uring + ruo + wave * UW + lane * 16);
+        };
+        // RED: g = dz lrelu'(a u + b) of NE channels (dz, u: packed fp16 pairs, channel order), sums into ssum / ssq
+        auto red_acc = [&](auto NE_, const unsigned* dzp, const unsigned* up, int choff) {
+            constexpr int NE = decltype(NE_)::value;
+            const float* at = abl + choff;
+#pragma unroll
+            for (int e4 = 0; e4 < NE; e4 += 4) {
+                const floatx4 a4 = *reinterpret_cast<const floatx4*>(at + e4);
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(at + 32 * NMB + e4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = e4 + i;
+                    const half2v dh = __builtin_bit_cast(half2v, dzp[e >> 1]), uh = __builtin_bit_cast(half2v, up[e >> 1]);
+                    const float dzf = (float)dh[e & 1], uf = (float)uh[e & 1];
+                    const float pre = __builtin_fmaf(a4[i], uf, b4[i]);
+                    const float g = pre > 0.f ? dzf : dzf * p.red_slope;
+                    ssum[e] += g;
+                    ssq[e] = __builtin_fmaf(g, uf, ssq[e]);
+                }
+            }
         };
         auto fin_store = [&](int tprev) {
             if (!fin) return;
@@ -285,10 +353,14 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 // lane l holds channels {4hk..4hk+3} of both quads, lane l+32 the other four of each: pack to fp16 and
                 // exchange halves (vdst = quad 0, src = quad 1) so that every lane ends with 8 consecutive channels
                 // (lanes < 32: [own quad 0 | upper's quad 0], lanes >= 32: [lower's quad 1 | own quad 1]) -> ONE 16-byte store
-                const half2v a0 = {(half_t)(fin[0] + biasv[0]), (half_t)(fin[1] + biasv[1])};
-                const half2v a1 = {(half_t)(fin[2] + biasv[2]), (half_t)(fin[3] + biasv[3])};
-                const half2v b0 = {(half_t)(fin[4] + biasv[4]), (half_t)(fin[5] + biasv[5])};
-                const half2v b1 = {(half_t)(fin[6] + biasv[6]), (half_t)(fin[7] + biasv[7])};
+                if constexpr (!RED) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) fin[i] += biasv[i];
+                }
+                const half2v a0 = {(half_t)fin[0], (half_t)fin[1]};
+                const half2v a1 = {(half_t)fin[2], (half_t)fin[3]};
+                const half2v b0 = {(half_t)fin[4], (half_t)fin[5]};
+                const half2v b1 = {(half_t)fin[6], (half_t)fin[7]};
                 if constexpr (STATS) {
                     const float r[8] = {(float)a0[0], (float)a0[1], (float)a1[0], (float)a1[1],
                                         (float)b0[0], (float)b0[1], (float)b1[0], (float)b1[1]};
@@ -303,6 +375,12 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
                 const uint4v o = {s0[0], s1[0], s0[1], s1[1]};
                 __builtin_amdgcn_raw_buffer_store_b128(o, rs, svoff, 0, 0);
+                if constexpr (RED) {
+                    if (ov) {                         // (wave-uniform) after the swap a lane holds channels 16 ck + 8 hk + [0, 8) in order
+                        const unsigned dzp[4] = {o[0], o[1], o[2], o[3]}, up[4] = {ur[0], ur[1], ur[2], ur[3]};
+                        red_acc(IC<8>{}, dzp, up, 32 * mb + 16 * ck + 8 * hk);
+                    }
+                }
             } else {
                 half4 o4;
 #pragma unroll
@@ -327,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         // ---- prologue: first D planes in flight, planes 0 and 1 landed ----
 #pragma unroll
         for (int tp = 0; tp < D; ++tp) dma();
-        wait_vm<(D - 2) * DPW, false>();
+        wait_vm<(D - 2) * DPT, false>();
         __builtin_amdgcn_s_barrier();
         b[0] = ldb(0, 0);
         b[1] = ldb(0, 1);
@@ -350,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 }
             }
             ro = rn;
+            if constexpr (RED) ruo = ruo + UB == R * UB ? 0 : ruo + UB;
             // publish the completed accumulator: own quads stay in registers, the rest goes to the waves that finalise them
             constexpr int c = (U + 2) % 3;
 #pragma unroll
@@ -361,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
                 const floatx4 w = {acc[c][4 * a], acc[c][4 * a + 1], acc[c][4 * a + 2], acc[c][4 * a + 3]};
                 *reinterpret_cast<floatx4*>(eb + wb[a]) = w;
             }
-            wait_vm<(D - 2) * DPW, true>();
+            wait_vm<(D - 2) * DPT, true>();
             __builtin_amdgcn_s_barrier();
         };
 
@@ -374,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             step(IC<1>{}, t + 1);
             step(IC<2>{}, t + 2);
         }
-        if constexpr (STATS) {
+        if constexpr (STATS || RED) {
             // this wave's 32 voxel lanes per half-wave hold the same channels: butterfly over the half, then lanes 0 / 32
             // add the item's sums to the wave's own slot row (out-of-volume voxel columns contribute nothing)
             const bool lane_ok = fin && svoff != (int)0x80000000;
@@ -386,7 +465,8 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64); }
                 if (fin && (lane & 31) == 0) {
-                    const int ch = m0 + 8 * QN * ck + 8 * (i >> 2) + 4 * hk + (i & 3);
+                    // STATS sums the accumulator layout (before the half-wave swap), RED the stored one (after it)
+                    const int ch = RED ? m0 + 8 * QN * ck + 4 * QN * hk + i : m0 + 8 * QN * ck + 8 * (i >> 2) + 4 * hk + (i & 3);
                     prow0[ch] += a;
                     prow0[astride + ch] += b2;
                 }
@@ -399,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
 
 int g_v9_zseg = 0;     // lnn_debug_set_v9_zseg (parity tests): 0 = automatic
 
-template <class K, bool STATS>
+template <class K, int EPI>
 int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
     const int tiles_y = lnn_cdiv(p.Lh, K::FY), tiles_x = lnn_cdiv(p.Lw, K::FX);
     const int mgroups = p.M / (32 * K::NMB);
@@ -426,16 +506,18 @@ int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
     q.nslots = G / 8;
     if (q.nslots > q.ipx) q.nslots = q.ipx;
     const int grid = q.nslots * 8;
+    constexpr int lds = EPI == 2 ? K::LDS_RED : K::LDS;
+    static_assert(lds <= 160 * 1024, "LDS of a CU");
     static bool attr_set = false;     // per instantiation; idempotent attribute of the code object
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (STATS) {
+    if (EPI != 0) {
         p.stats_nblk = grid * K::NF;
         hipMemsetAsync(p.stats_pws, 0, sizeof(float) * 2 * (size_t)p.stats_nblk * p.N * p.M, s);
     }
-    hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, STATS>), dim3(grid), dim3(512), K::LDS, s, p, q);
+    hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, EPI>), dim3(grid), dim3(512), lds, s, p, q);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }
@@ -487,22 +569,34 @@ int lnn_conv_s1_v9_stats_slots(const ConvParams& p) {
     return (v9_num_cu() / 8 * 8 < 8 ? 8 : v9_num_cu() / 8 * 8) * nf;
 }
 
+// the data-gradient shape that feeds an InstanceNorm backward at the highest resolution: 32 -> 32
+bool lnn_conv_s1_v9_red_supported(const ConvParams& p) {
+    if (!lnn_conv_s1_v9_supported(p) || p.bias || p.msplit != 0x7fffffff) return false;
+    if (p.red_ld % 8 != 0 || p.red_ld < p.M || (double)p.Ho * p.Wo * p.red_ld * 2.0 >= 2147483648.0) return false;
+    if (lnn_conv_s1_v9_stats_slots(p) > 1024) return false;
+    return p.C == 32 && p.M % 64 != 0;
+}
+
 int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name) {
     const int num_cu = v9_num_cu();
+    if (p.red_u) {
+        LNN_REQUIRE(p.stats_pws && lnn_conv_s1_v9_red_supported(p), "%s: no fused-reduce instance for this shape", name);
+        return launch_v9<V9<2, 1, 4>, 2>(s, p, num_cu, name);
+    }
     if (p.C == 128) {
-        if (p.stats_pws) return launch_v9<V9<8, 1, 1>, true>(s, p, num_cu, name);
-        return launch_v9<V9<8, 1, 1>, false>(s, p, num_cu, name);
+        if (p.stats_pws) return launch_v9<V9<8, 1, 1>, 1>(s, p, num_cu, name);
+        return launch_v9<V9<8, 1, 1>, 0>(s, p, num_cu, name);
     }
     if (p.stats_pws) {
         // 32 -> 64 (the data-gradient shape of the top decoder conv) never feeds an InstanceNorm: no STATS instance for it
-        if (p.C == 32) return launch_v9<V9<2, 1, 4>, true>(s, p, num_cu, name);
-        if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>, true>(s, p, num_cu, name);
-        return launch_v9<V9<4, 1, 2>, true>(s, p, num_cu, name);
+        if (p.C == 32) return launch_v9<V9<2, 1, 4>, 1>(s, p, num_cu, name);
+        if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>, 1>(s, p, num_cu, name);
+        return launch_v9<V9<4, 1, 2>, 1>(s, p, num_cu, name);
     }
     if (p.C == 32) {
-        if (p.M % 64 == 0) return launch_v9<V9<2, 2, 2>, false>(s, p, num_cu, name);
-        return launch_v9<V9<2, 1, 4>, false>(s, p, num_cu, name);
+        if (p.M % 64 == 0) return launch_v9<V9<2, 2, 2>, 0>(s, p, num_cu, name);
+        return launch_v9<V9<2, 1, 4>, 0>(s, p, num_cu, name);
     }
-    if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>, false>(s, p, num_cu, name);
-    return launch_v9<V9<4, 1, 2>, false>(s, p, num_cu, name);
+    if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>, 0>(s, p, num_cu, name);
+    return launch_v9<V9<4, 1, 2>, 0>(s, p, num_cu, name);
 }

@@ -30,6 +30,10 @@ int lnn_debug_set_v9_zseg(int segments);
  * 1 = every layer the generic kernels support.  Process-wide. */
 int lnn_debug_set_gen_mode(int mode);
 
+/* Parity tests only: 1 when the last lnn_conv3d_dgrad_in_bwd_sums call ran the fused epilogue (z-streaming kernel, EPI = 2), 0 when it
+ * ran the two separate calls. */
+int lnn_debug_last_dgrad_reduce_fused(void);
+
 #ifdef __cplusplus
 }
 #endif

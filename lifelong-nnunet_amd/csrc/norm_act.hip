@@ -386,8 +386,11 @@ __global__ __launch_bounds__(NT) void in_lrelu_bwd_reduce_kernel(const half_t* _
 // call and channel (bit-reproducible for any batch size; the atomic only serves two sample lanes adding from two streams,
 // and two operands commute).  NC = N * C, grid = ceil(C / 16).
 // (n, c) totals of pass 1 and the affine gradients of FEB channels per block: shared by the plain and the seg-head variant
+// raw_mean / raw_rstd (both or neither): the second partial is sum g * u of the UN-normalised convolution output u (the reduce fused
+// into the data gradient that produced dz, igemm_conv_v9.hip EPI = 2): sum g xhat = rstd (sum g u - mean sum g), taken here in fp64
 __device__ __forceinline__ void in_bwd_sums_block(const float* pws, int nblk, int N, int C, int blk, double* red, double* ws,
-                                                  float* dgamma, float* dbeta, float unscale) {
+                                                  float* dgamma, float* dbeta, float unscale, const float* raw_mean = nullptr,
+                                                  const float* raw_rstd = nullptr) {
     const int ii = threadIdx.x % FEB, sl = threadIdx.x / FEB;
     const int c = blk * FEB + ii, NC = N * C;
     double g0 = 0, g1 = 0;
@@ -406,6 +409,10 @@ __device__ __forceinline__ void in_bwd_sums_block(const float* pws, int nblk, in
         reduce_slices<FSL, 4>(o, red);
         if (c < C && sl == 0) {
             const long i0 = (long)n * C + c;
+            if (raw_mean) {
+                o[1] = (double)raw_rstd[i0] * (o[1] - (double)raw_mean[i0] * o[0]);
+                if (two) o[3] = (double)raw_rstd[i0 + C] * (o[3] - (double)raw_mean[i0 + C] * o[2]);
+            }
             ws[i0 * 3 + 0] = o[0]; ws[i0 * 3 + 1] = o[1];
             g0 += o[0]; g1 += o[1];
             if (two) {
@@ -419,9 +426,9 @@ __device__ __forceinline__ void in_bwd_sums_block(const float* pws, int nblk, in
     if (dbeta) atomicAdd(dbeta + c, (float)(g0 * unscale));
 }
 __global__ void in_lrelu_bwd_sums_kernel(const float* pws, int nblk, int NC, int C, double* ws, float* dgamma, float* dbeta,
-                                         float unscale) {
+                                         float unscale, const float* raw_mean, const float* raw_rstd) {
     __shared__ double red[4 * 256];
-    in_bwd_sums_block(pws, nblk, NC / C, C, blockIdx.x, red, ws, dgamma, dbeta, unscale);
+    in_bwd_sums_block(pws, nblk, NC / C, C, blockIdx.x, red, ws, dgamma, dbeta, unscale, raw_mean, raw_rstd);
 }
 
 // pass 2: dy = gamma*rstd*(g - s1/V - xhat*s2/V), in place over y; DBIAS: db partial = sum dy (the conv-bias gradient; it is
@@ -780,6 +787,15 @@ int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, in
     return LNN_OK;
 }
 
+// the sums half of pass 1 over partials that a fused producer epilogue left in ws' partial region (slot rows as the statistics)
+int lnn_launch_in_bwd_sums_raw(hipStream_t s, const float* pws, int nslots, int N, int C, const float* mean, const float* rstd,
+                               double* ws, float* dgamma, float* dbeta, float unscale) {
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, FEB)), dim3(256), 0, s, pws, nslots, N * C, C, ws, dgamma, dbeta,
+                       unscale, mean, rstd);
+    LNN_CHECK_LAUNCH("lnn_conv3d_dgrad_in_bwd_sums(sums)");
+    return LNN_OK;
+}
+
 // [N*C*3 doubles: s1, s2, (unused)] [2 * MAX_BLOCKS * N * C floats: per-block partial sums]
 extern "C" size_t lnn_instnorm_ws_doubles(int N, int C) { return (size_t)N * C * 3 + (size_t)MAX_BLOCKS * N * C; }
 
@@ -850,7 +866,7 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
                        mean, rstd, gamma, beta, slope, pws, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(reduce)");
     hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, FEB)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
-                       grad_unscale);
+                       grad_unscale, (const float*)nullptr, (const float*)nullptr);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(sums)");
     if (dbias) {
         hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<true>), grid, dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, V, C, mean,
@@ -908,6 +924,21 @@ extern "C" int lnn_instnorm_lrelu_seg_bwd(lnn_stream_t s_, void* y, const void* 
     return LNN_OK;
 }
 
+// Pass 2 of the backward alone: dy = gamma rstd (g - s1/V - xhat s2/V) in place over y, from the sums a pass 1 left in ws
+// (lnn_instnorm_lrelu_bwd_sums or lnn_conv3d_dgrad_in_bwd_sums).
+extern "C" int lnn_instnorm_lrelu_bwd_apply(lnn_stream_t s_, void* y, const void* dz, int ld_dz, int N, long V, int C,
+                                            const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                                            double* ws) {
+    hipStream_t s = (hipStream_t)s_;
+    if (int e = check_common(y, N, V, C, "lnn_instnorm_lrelu_bwd_apply")) return e;
+    LNN_REQUIRE(dz != nullptr && lnn_aligned16(dz) && ld_dz >= C && ld_dz % 8 == 0, "lnn_instnorm_lrelu_bwd_apply: bad dz / ld_dz");
+    LNN_REQUIRE(mean && rstd && gamma && beta && ws, "lnn_instnorm_lrelu_bwd_apply: null parameter");
+    hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<false>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz,
+                       V, C, mean, rstd, gamma, beta, slope, ws, (float*)nullptr, in_nt_flag());
+    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_apply");
+    return LNN_OK;
+}
+
 // Pass 1 of the backward alone (reduce + sums): ws[(n * C + c) * 3 + {0, 1}] = sum g, sum g * xhat and the affine gradients; y is
 // not touched.  For the first block, whose pass 2 lives inside its weight gradient (lnn_conv3d_wgrad_c1_in_bwd).
 extern "C" int lnn_instnorm_lrelu_bwd_sums(lnn_stream_t s_, const void* y, const void* dz, int ld_dz, int N, long V, int C,
@@ -923,7 +954,7 @@ extern "C" int lnn_instnorm_lrelu_bwd_sums(lnn_stream_t s_, const void* y, const
                        mean, rstd, gamma, beta, slope, pws, in_nt_flag());
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(reduce)");
     hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, dim3(lnn_cdiv(C, FEB)), dim3(256), 0, s, pws, nblk, N * C, C, ws, dgamma, dbeta,
-                       grad_unscale);
+                       grad_unscale, (const float*)nullptr, (const float*)nullptr);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd_sums(sums)");
     return LNN_OK;
 }

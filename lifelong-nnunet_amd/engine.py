@@ -93,6 +93,7 @@ class ConvBlock:
     wp_dgrad: int = 0
     panel: int = 0
     in_dims: tuple = ()
+    x_block: object = None         # the ConvBlock whose output IS this block's only input (second block of a stage): its gz = gx
 
     @property
     def iso(self):
@@ -310,6 +311,7 @@ class UNetEngine:
                 b0.cin_k = 1 if self.c1_path else self.cin_pad
             b1 = new_block(f"conv_blocks_context.{d}.blocks.1", feats[d], feats[d], one, kernels[d], b0.z, b0.gz, False,
                            skip, gskip, dims[d])
+            b1.x_block = b0
             x, gx, cin = b1.z, b1.gz, feats[d]
         # ---- bottleneck: Sequential(Stacked(1 strided conv), Stacked(1 conv))  (test_MultiHead_Module.py:394-415)
         nb = num_pool
@@ -317,6 +319,7 @@ class UNetEngine:
                        dims[nb - 1])
         b1 = new_block(f"conv_blocks_context.{nb}.1.blocks.0", feats[nb], feats[nb], one, kernels[nb], b0.z, b0.gz, False, None, None,
                        dims[nb])
+        b1.x_block = b0
         x, gx, cdown = b1.z, b1.gz, feats[nb]
         # ---- decoder
         for u in range(num_pool):
@@ -339,6 +342,7 @@ class UNetEngine:
                 b0.x2, b0.gx2 = Act(self.cat[u][1], 0, cs), Act(self.gcat[u][1], 0, cs)
             b1 = new_block(f"conv_blocks_localization.{u}.1.blocks.0", cs, cs, one, kernels[-(u + 1)], b0.z, b0.gz, False, None, None,
                            dims[d])
+            b1.x_block = b0
             seg = SegHead(f"seg_outputs.{u}", cs, x=b1.z, gx=b1.gz, gx_has_prior=(u < num_pool - 1))
             seg.x_block = b1
             seg.w = arena.by_name[f"seg_outputs.{u}.weight"]
@@ -463,6 +467,9 @@ class UNetEngine:
         self.fuse_seg_bwd = os.environ.get("LNN_NO_FUSED_SEG_BWD", "0") != "1"
         # first block: pass 2 of its InstanceNorm backward rebuilt inside its weight gradient (dy never written): A/B switch
         self.fuse_first_bwd = os.environ.get("LNN_NO_FUSED_FIRST_BWD", "0") != "1"
+        # second block of a stage: pass 1 of the FIRST block's InstanceNorm backward rides the data gradient that produces its dL/dz
+        # (lnn_conv3d_dgrad_in_bwd_sums; fused inside the z-streaming kernel where an instance exists): A/B switch
+        self.fuse_in_bwd_reduce = os.environ.get("LNN_NO_FUSED_IN_BWD_REDUCE", "0") != "1"
         # measurement hook (bench.py): {"layer": <block prefix>} -> the forward conv / data-gradient / weight-gradient calls of
         # that block are bracketed with timing events ON THE STREAM THEY LAUNCH ON, appended to probe["fwd" | "dgrad" | "wgrad"]
         self.probe = None
@@ -752,6 +759,7 @@ class UNetEngine:
         def lane(n0, nn, ws, splitk_ws):
             seg_u = len(self.segs)
             pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
+            presummed = set()     # id(block): pass 1 of its normalisation backward was taken by the data gradient that produced its dL/dz
             for item in reversed(self.order):
                 if progress is not None and item is not self.order[-1]:
                     # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
@@ -785,12 +793,14 @@ class UNetEngine:
                             nn, V, K, _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta),
                             LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
                     elif item.cin_k == 1 and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
-                        # the first block has no data gradient: only the sums of its normalisation backward are taken here,
-                        # dy is rebuilt tile by tile inside the weight gradient below (lnn_conv3d_wgrad_c1_in_bwd)
-                        self._probed("in_bwd", item, lambda: nat.call(
-                            "lnn_instnorm_lrelu_bwd_sums", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                            _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
-                            self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
+                        # the first block has no data gradient: only the sums of its normalisation backward are taken here (or were,
+                        # by the data gradient of the block behind it), dy is rebuilt tile by tile inside the weight gradient below
+                        # (lnn_conv3d_wgrad_c1_in_bwd)
+                        if id(item) not in presummed:
+                            self._probed("in_bwd", item, lambda: nat.call(
+                                "lnn_instnorm_lrelu_bwd_sums", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
+                                _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta),
+                                LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
                         D, H, W = item.in_dims
 
                         def first_wgrad(item=item, K=K, D=D, H=H, W=W):
@@ -805,6 +815,11 @@ class UNetEngine:
                         on_side(lambda: self._probed("wgrad", item, first_wgrad))
                         yield
                         continue
+                    elif id(item) in presummed:
+                        self._probed("in_bwd", item, lambda: nat.call(
+                            "lnn_instnorm_lrelu_bwd_apply", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
+                            _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                            ws))
                     else:
                         self._probed("in_bwd", item, lambda: nat.call(
                             "lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
@@ -847,6 +862,17 @@ class UNetEngine:
                             "lnn_conv3d_dgrad_g", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
                             nn, D, H, W, C, K, *item.kernel, *item.strides, 1 if item.gx_accumulate else 0, splitk_ws,
                             splitk_ws.numel()))
+                    elif (self.fuse_in_bwd_reduce and item.x_block is not None and item.stride == 1 and item.gx2 is None
+                          and not item.gx_accumulate and not self.numeric_conv_bias_grad):
+                        # dL/dz of the stage's first block AND pass 1 of its normalisation backward (ws is this lane's; nothing
+                        # between here and that block's turn in the loop uses it)
+                        xb = item.x_block
+                        self._probed("dgrad", item, lambda: nat.call(
+                            "lnn_conv3d_dgrad_in_bwd_sums", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
+                            nn, D, H, W, C, K, at(xb.y, n0), _Ptr(xb.mean, n0 * C), _Ptr(xb.rstd, n0 * C), self.pview(xb.gamma),
+                            self.pview(xb.beta), LRELU_SLOPE, self.pview(xb.gamma, self.grad), self.pview(xb.beta, self.grad), 1.0, ws,
+                            splitk_ws, splitk_ws.numel()))
+                        presummed.add(id(xb))
                     elif item.gx2 is not None:
                         self._probed("dgrad", item, lambda: nat.call(
                             "lnn_conv3d_dgrad_cat", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0),

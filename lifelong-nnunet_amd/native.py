@@ -52,6 +52,8 @@ SIGNATURES = {
     "lnn_instnorm_lrelu_seg_bwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _f, _p]),
     "lnn_instnorm_lrelu_seg_bwd_ws_doubles": (_sz, [_i, _i]),
     "lnn_instnorm_lrelu_bwd_sums": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _f, _p]),
+    "lnn_conv3d_dgrad_in_bwd_sums": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _p, _l]),
+    "lnn_instnorm_lrelu_bwd_apply": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p]),
     "lnn_conv3d_wgrad_c1_in_bwd": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _l]),
     "lnn_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),
     "lnn_seg1x1_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _l, _i, _i, _i, _f, _p]),
@@ -105,6 +107,7 @@ SIGNATURES = {
     "lnn_debug_force_down2_kernel": (_i, [_i]),
     "lnn_debug_set_v9_zseg": (_i, [_i]),
     "lnn_debug_set_gen_mode": (_i, [_i]),
+    "lnn_debug_last_dgrad_reduce_fused": (_i, []),
     "lnn_set_cu_budget": (_i, [_i]),
     # generic geometry (kernel extent 1 / 3 and stride 1 / 2 per axis; transposed convolutions with kernel == stride)
     "lnn_conv3d_fwd_g": (_i, [_p, _p, _i, _p, _p, _p, _i] + [_i] * 12 + [_p, _l]),

@@ -162,3 +162,80 @@ def test_c2_training_steps_are_finite_and_learn():
         losses.append(lv)
     assert losses[-1] < losses[0]
     assert float((net.arena.theta - theta0).abs().max()) > 0
+
+
+@pytest.mark.parametrize("C,dims", [(32, (D, H, W))])
+def test_fused_norm_backward_reduce_at_bench_shapes(C, dims):
+    """The data-gradient shape of configs[1] whose epilogue takes pass 1 of the preceding block's InstanceNorm backward
+    (igemm_conv_v9.hip, EPI = 2), at its real size and with the AUTOMATIC kernel choice: the fused call must actually be fused
+    there, reproduce lnn_conv3d_dgrad_ws bit for bit, and its (sample, channel) sums must equal both the separate reduce pass and an
+    fp64 evaluation of sum g / sum g xhat from the stored tensors."""
+    d, h, w_ = dims
+    K, V = C, d * h * w_
+    u = _randh((N, d, h, w_, C), 21, 1.5) + 0.25
+    dy = _randh((N, d, h, w_, K), 22, 0.5)
+    g = torch.Generator(device=DEV).manual_seed(23)
+    wt = torch.randn((K, C, 3, 3, 3), generator=g, device=DEV) * 0.05
+    gamma = 1 + 0.3 * torch.randn(C, generator=g, device=DEV); gamma[::7] *= -1
+    beta = 0.2 * torch.randn(C, generator=g, device=DEV)
+    wp = pack_conv_dgrad(wt)
+    mean, rstd = torch.empty(N * C, device=DEV), torch.empty(N * C, device=DEV)
+    nws = nat.query("lnn_instnorm_ws_doubles", N, C)
+    ws0 = torch.zeros(nws, dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", u, N, V, C, 1e-5, mean, rstd, ws0)
+    out = []
+    for fused in (True, False):
+        dx = torch.empty((N, d, h, w_, C), dtype=torch.float16, device=DEV)
+        ws = torch.zeros(nws, dtype=torch.float64, device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        if fused:
+            nat.call("lnn_conv3d_dgrad_in_bwd_sums", dy, K, wp, dx, C, N, d, h, w_, C, K, u, mean, rstd, gamma, beta, 0.01, dg, db, 1.0, ws,
+                     None, 0)
+            assert nat.lib().lnn_debug_last_dgrad_reduce_fused() == 1
+        else:
+            nat.call("lnn_conv3d_dgrad_ws", dy, K, wp, dx, C, N, d, h, w_, C, K, 1, 0, None, 0)
+            nat.call("lnn_instnorm_lrelu_bwd_sums", u, dx, C, N, V, C, mean, rstd, gamma, beta, 0.01, dg, db, 1.0, ws)
+        out.append((dx, ws[:N * C * 3].view(N, C, 3)[..., :2].clone(), dg, db))
+    (dx1, s1, dg1, db1), (dx0, s0, dg0, db0) = out
+    assert torch.equal(dx0, dx1)
+    # fp64 reference of the sums, one sample at a time (plumbing: torch on the device)
+    ref = torch.empty_like(s0)
+    for n in range(N):
+        xh = (u[n].reshape(V, C).double() - mean.view(N, C)[n].double()) * rstd.view(N, C)[n].double()
+        gg = dx0[n].reshape(V, C).double() * torch.where(gamma.double() * xh + beta.double() > 0, 1.0, 0.01)
+        ref[n, :, 0] = gg.sum(0); ref[n, :, 1] = (gg * xh).sum(0)
+        del xh, gg
+    scale = ref.abs().amax(dim=(0, 1))
+    for s in (s0, s1):
+        assert float(((s - ref).abs() / scale).max()) < 1e-5, ((s - ref).abs() / scale).amax(dim=(0, 1))
+    assert float((dg1 - dg0).abs().max()) <= 1e-5 * float(dg0.abs().max()) and float((db1 - db0).abs().max()) <= 1e-5 * float(db0.abs().max())
+
+
+def test_c2_backward_is_the_same_with_and_without_the_fused_reduce():
+    """One configs[1] backward with the engine's fused data-gradient + normalisation-reduce calls and one with the separate passes
+    (the round-3 path): every parameter gradient agrees to summation order (the fused epilogue only changes the order in which the
+    per-(sample, channel) sums of pass 1 are added)."""
+    from lifelong_nnunet_amd.losses import DC_and_CE_loss, MultipleOutputLoss2, ds_loss_weights
+    from lifelong_nnunet_amd.network import Generic_UNet
+    from lifelong_nnunet_amd.optim import FusedSGD
+    from lifelong_nnunet_amd.synthetic import make_patch_batch
+    net = Generic_UNet(1, 32, 3, 5, patch_size=(D, H, W), batch_size=N, device=DEV)
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), ds_loss_weights(5))
+    opt = FusedSGD(net, 1e-2, weight_decay=3e-5)
+    data, tgts = make_patch_batch(N, (D, H, W), 5, seed=4321)
+    data, tgts = data.to(DEV), [t.to(DEV) for t in tgts]
+    grads = []
+    for fuse in (True, False):
+        eng = net.engine_for(data)
+        eng.fuse_in_bwd_reduce = fuse
+        opt.zero_grad()
+        l = loss_fn(net(data), tgts)
+        (l * 1024.0).backward()
+        torch.cuda.synchronize()
+        grads.append(net.arena.grad.double().clone())
+    g1, g0 = grads
+    assert float(g0.norm()) > 0
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-4, float((g1 - g0).norm() / g0.norm())
+    for slot in net.arena.slots:
+        a, b = g1[slot.offset:slot.offset + slot.numel], g0[slot.offset:slot.offset + slot.numel]
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-6 * float(g0.norm()), slot.name

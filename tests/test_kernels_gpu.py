@@ -639,6 +639,65 @@ def test_convT_dgrad_streaming_kernel(N, C, K, D, H, W):
         nat.lib().lnn_debug_force_down2_kernel(-1)
 
 
+@pytest.mark.parametrize("zseg", [0, 3])
+@pytest.mark.parametrize("N,C,D,H,W", [(2, 32, 9, 8, 17), (1, 32, 37, 5, 21), (3, 32, 4, 4, 8), (2, 64, 6, 10, 9), (1, 64, 13, 12, 7),
+                                       (1, 128, 5, 6, 10)])
+def test_dgrad_with_fused_norm_backward_reduce(N, C, D, H, W, zseg):
+    """lnn_conv3d_dgrad_in_bwd_sums == lnn_conv3d_dgrad_ws + lnn_instnorm_lrelu_bwd_sums on the block whose output the convolution
+    consumed: dL/dz bit for bit, the (sample, channel) sums and the affine gradients to summation order -- with the z-streaming
+    kernel forced the reduce rides its epilogue for 32 -> 32 channels (ragged footprints, z segments, negative gamma); 64 / 128
+    channels have no fused instance and run the two calls -- and lnn_instnorm_lrelu_bwd_apply on those sums gives dL/dy of autograd."""
+    K = C
+    g = torch.Generator().manual_seed(11)
+    u = q16(_rand((N, C, D, H, W), 1) * 1.5 + 0.3).requires_grad_(True)           # convolution output of the stage's first block
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)); gamma[::5] *= -1.0
+    gamma = gamma.requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    w = _rand((K, C, 3, 3, 3), 2, 0.1)
+    z = F.leaky_relu(F.instance_norm(u, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    z.retain_grad()
+    y2 = F.conv3d(z, w, None, padding=1)
+    dy = _rand(y2.shape, 4)
+    y2.backward(dy)
+    V = D * H * W
+    ub, _ = to_cl_h(u.detach())
+    dyb, _ = to_cl_h(dy)
+    wp = pack_conv_dgrad(w.to(DEV))
+    mean = torch.empty(N * C, device=DEV); rstd = torch.empty(N * C, device=DEV)
+    nws = nat.query("lnn_instnorm_ws_doubles", N, C)
+    ws0 = torch.zeros(nws, dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", ub, N, V, C, 1e-5, mean, rstd, ws0)
+    ga, be = gamma.detach().to(DEV), beta.detach().to(DEV)
+    res = []
+    try:
+        assert nat.lib().lnn_debug_force_conv_kernel(9) == 0
+        assert nat.lib().lnn_debug_set_v9_zseg(zseg) == 0
+        for fused in (False, True):
+            dx = torch.full((N, D, H, W, C + 8), 7.0, dtype=torch.float16, device=DEV)
+            ws = torch.zeros(nws, dtype=torch.float64, device=DEV)
+            dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
+            if fused:
+                nat.call("lnn_conv3d_dgrad_in_bwd_sums", dyb, K, wp, dx, C + 8, N, D, H, W, C, K, ub, mean, rstd, ga, be, 0.01, dg, db,
+                         0.5, ws, None, 0)
+                assert nat.lib().lnn_debug_last_dgrad_reduce_fused() == (1 if C == 32 else 0)
+            else:
+                nat.call("lnn_conv3d_dgrad_ws", dyb, K, wp, dx, C + 8, N, D, H, W, C, K, 1, 0, None, 0)
+                nat.call("lnn_instnorm_lrelu_bwd_sums", ub, dx, C + 8, N, V, C, mean, rstd, ga, be, 0.01, dg, db, 0.5, ws)
+            res.append((dx, ws[:N * C * 3].view(N * C, 3)[:, :2].clone(), dg, db, ws))
+    finally:
+        nat.lib().lnn_debug_set_v9_zseg(0)
+        nat.lib().lnn_debug_force_conv_kernel(-1)
+    (dx0, s0, dg0, db0, _), (dx1, s1, dg1, db1, ws1) = res
+    assert torch.equal(dx0[..., :C], dx1[..., :C]) and bool((dx1[..., C:] == 7.0).all())
+    assert rel_err(from_cl_h(dx1, C), z.grad) < 3e-3
+    scale = s0.abs().max(0).values
+    assert float(((s0 - s1).abs() / scale).max()) < 2e-5, ((s0 - s1).abs() / scale).max(0)
+    assert rel_err(dg1.cpu(), dg0.cpu()) < 2e-5 and rel_err(db1.cpu(), db0.cpu()) < 2e-5
+    assert rel_err(dg1.cpu(), 0.5 * gamma.grad) < 2e-3 and rel_err(db1.cpu(), 0.5 * beta.grad) < 2e-3
+    nat.call("lnn_instnorm_lrelu_bwd_apply", ub, dx1, C + 8, N, V, C, mean, rstd, ga, be, 0.01, ws1)
+    assert rel_err(from_cl_h(ub, C), u.grad) < 3e-3             # dy in place over u
+
+
 @pytest.mark.parametrize("C", [32, 128])
 @pytest.mark.parametrize("zseg", [2, 3, 5])
 def test_v9_z_segments(zseg, C):

@@ -109,8 +109,27 @@ def main():
                       (lambda: nat.call("lnn_conv3d_fwd", x, C, wf, b, y, K, N, D, H, W, C, K, s)),
                "dgrad": lambda: nat.call("lnn_conv3d_dgrad_ws", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0, ws, ws.numel()),
                "wgrad": lambda: nat.call("lnn_conv3d_wgrad", x, C, dy, K, panel, N, D, H, W, C, K, s)}
+        if s == 1 and C == K:
+            # the stage's second block: its data gradient with / without pass 1 of the first block's normalisation backward in the epilogue
+            V = D * H * W
+            u = (torch.randn((N, D, H, W, C), device=dev) * 0.5).half()
+            mean, rstd = torch.zeros(N * C, device=dev), torch.ones(N * C, device=dev)
+            gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            wsd = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, C), dtype=torch.float64, device=dev)
+            fns["dgrad_red"] = lambda: nat.call("lnn_conv3d_dgrad_in_bwd_sums", dy, K, wd, dx, C, N, D, H, W, C, K, u, mean, rstd, gamma, beta,
+                                                0.01, dg, db, 1.0, wsd, ws, ws.numel())
+
+            def two_calls():
+                nat.call("lnn_conv3d_dgrad_ws", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0, ws, ws.numel())
+                nat.call("lnn_instnorm_lrelu_bwd_sums", u, dx, C, N, V, C, mean, rstd, gamma, beta, 0.01, dg, db, 1.0, wsd)
+            fns["dgrad_sums"] = two_calls
+            fns["in_apply"] = lambda: nat.call("lnn_instnorm_lrelu_bwd_apply", u, dx, C, N, V, C, mean, rstd, gamma, beta, 0.01, wsd)
+            fns["in_bwd"] = lambda: nat.call("lnn_instnorm_lrelu_bwd", u, dx, C, N, V, C, mean, rstd, gamma, beta, 0.01, dg, db, None, 1.0, wsd)
         out = []
         for k in a.which.split(","):
+            if k not in fns:
+                continue
             fn = fns[k]
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
