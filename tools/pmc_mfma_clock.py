@@ -63,7 +63,7 @@ def main(src, src_clock, dst):
                     "frac_of_2p5_pflops": round(busy * ghz / 2.4, 3)})
     out.sort(key=lambda r: -r["mean_us"] * r["dispatches"])
     pick = lambda k, g: max((r for r in out if r["kernel"] == k and r["grid_x"] == g), key=lambda r: r["mean_us"], default=None)
-    fam = {"fwd": pick("conv_s1_v9<4,1,2,stats=1>", 131072), "dgrad": pick("conv_s1_v9<2,2,2,stats=0>", 131072),
+    fam = {"fwd": pick("conv_s1_v9<4,1,2,epi=1>", 131072), "dgrad": pick("conv_s1_v9<2,2,2,epi=0>", 131072),
            "wgrad": pick("wgrad_s1_v5", 131072)}     # the launches of conv_blocks_localization.4.0 (bench.py's roofline block)
     json.dump({"note": __doc__.split("usage")[0].strip(), "so_sha256": so_sha256(), "families": fam, "kernels": out},
               open(dst, "w"), indent=1)
