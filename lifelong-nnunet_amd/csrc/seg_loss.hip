@@ -182,6 +182,40 @@ __device__ __forceinline__ void softmax_regs(const float (&x)[KMAX], int K, floa
     lse = mx + logf(s);
 }
 
+// The same softmax with the hardware transcendentals (round 4: the Dice + CE forward issued 111 VALU operations per voxel, 12 per
+// accurate expf, 10 per IEEE division, 8 per logf -- the kernel was bound by them at 2.9 TB/s):
+//   exp(d) = 2^(d log2 e) by v_exp_f32, with the rounding error of the product d * log2(e) (one fma) and the low word of log2(e) fed
+//   back through 2^(t + e) ~= 2^t (1 + e ln 2): ~1 ulp like expf, 5 operations;  1 / s = v_rcp_f32 + one Newton step;
+//   log(s) = v_log_f32(s) ln 2 (s in [1, K]: absolute error ~1e-7).
+__device__ __forceinline__ float exp_le0(float d) {
+    const float t = d * 1.44269504088896341f;
+    float e = __builtin_fmaf(d, 1.44269504088896341f, -t);
+    e = __builtin_fmaf(d, 1.92596299112661746e-8f, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, e * 0.69314718055994531f, r);
+}
+template <int KT>
+__device__ __forceinline__ void softmax_regs_hw(const float (&x)[KMAX], int K, float (&p)[KMAX], float& lse) {
+    constexpr int KK = KT > 0 ? KT : KMAX;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+        if (KT > 0 || k < K) mx = fmaxf(mx, x[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+        if (KT > 0 || k < K) {
+            p[k] = exp_le0(x[k] - mx);
+            s += p[k];
+        }
+    float inv = __builtin_amdgcn_rcpf(s);
+    inv = __builtin_fmaf(__builtin_fmaf(-s, inv, 1.f), inv, inv);
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+        if (KT > 0 || k < K) p[k] *= inv;
+    lse = __builtin_fmaf(__builtin_amdgcn_logf(s), 0.69314718055994531f, mx);
+}
+
 // KT: compile-time channel count (0 = runtime K); VEC = 4: four consecutive voxels per thread through 16-byte loads (V % 4 == 0)
 // -- the scalar one-voxel-per-iteration version ran at 1.4 TB/s
 template <int KT, int VEC>
@@ -193,9 +227,12 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
     const int n = blockIdx.y;
     const float* ln = logits + (long)n * K * V;
     const float* yn = labels + (long)n * V;
-    float acc[NA];
+    // per class: A = sum p y (tp), B = sum p, C = #{y} (integer): fp = B - A, fn = C - A at the end (3 accumulations per class and
+    // voxel instead of 3 products + 3 accumulations)
+    float accA[KK], accB[KK], ce = 0.f;
+    int cnt[KK];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    for (int k = 0; k < KK; ++k) { accA[k] = accB[k] = 0.f; cnt[k] = 0; }
     auto load = [&](long v, float (&xv)[KMAX][VEC], float (&yv)[VEC]) {
 #pragma unroll
         for (int k = 0; k < KK; ++k)
@@ -222,27 +259,37 @@ __global__ __launch_bounds__(NT) void dice_ce_fwd_kernel(const float* __restrict
             float x[KMAX], p[KMAX], lse;
 #pragma unroll
             for (int k = 0; k < KK; ++k) x[k] = xv[k][e];
-            softmax_regs<KT>(x, K, p, lse);
+            softmax_regs_hw<KT>(x, K, p, lse);
             const int lab = (int)yv[e];
+            float xl = lse;                         // a label outside [0, K) adds nothing to the cross-entropy
 #pragma unroll
             for (int k = 0; k < KK; ++k)
                 if (KT > 0 || k < K) {
-                    const float y = (k == lab) ? 1.f : 0.f;
-                    acc[k * 3 + 0] += p[k] * y;
-                    acc[k * 3 + 1] += p[k] * (1.f - y);
-                    acc[k * 3 + 2] += (1.f - p[k]) * y;
-                    if (k == lab) acc[3 * KK] += lse - x[k];
+                    const bool hit = k == lab;
+                    accA[k] += hit ? p[k] : 0.f;
+                    accB[k] += p[k];
+                    cnt[k] += hit ? 1 : 0;
+                    xl = hit ? x[k] : xl;
                 }
+            ce += lse - xl;
         }
     };
-    // (two voxel groups per iteration -- 8 loads in flight instead of 4 -- measured SLOWER, 51 vs 46 us: the ~80 VALU operations per
-    // voxel bound this kernel, not the loads; profiles/r04_reduction_variants.txt)
+    // (two voxel groups per iteration -- 8 loads in flight instead of 4 -- measured SLOWER, 51 vs 46 us, while the kernel still issued
+    // 111 VALU operations per voxel; profiles/r04_reduction_variants.txt)
     const long step = (long)gridDim.x * NT * VEC;
     for (long v = ((long)blockIdx.x * NT + threadIdx.x) * VEC; v < V; v += step) {
         float xa[KMAX][VEC], ya[VEC];
         load(v, xa, ya);
         consume(xa, ya);
     }
+    float acc[NA];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+        acc[k * 3 + 0] = accA[k];
+        acc[k * 3 + 1] = accB[k] - accA[k];
+        acc[k * 3 + 2] = (float)cnt[k] - accA[k];
+    }
+    acc[3 * KK] = ce;
     block_sum<NA>(acc, sm);
     if (threadIdx.x == 0) {
         // partials [n][value 0 .. 3 KMAX][block]: the finalize kernel reads one value's partials as a contiguous run
@@ -281,14 +328,15 @@ __device__ void dice_ce_loss_from_totals(const double* ws, int N, int K, long V,
 // one 256-thread block: totals of the per-block partials (fp64, fixed order), then the loss.  Each of the N * (3K + 1) totals
 // is summed by ONE wave (lanes stride the blocks, butterfly at the end); the first version walked the totals one after the other
 // with a block-wide tree per total: 20 x 8 barriers = 28 us per deep-supervision level.
-__global__ __launch_bounds__(NT) void dice_ce_finalize_kernel(double* ws, int nblk, int N, int K, long V, int batch_dice,
+constexpr int FIN_NT = 1024;      // 16 waves: the 20 totals of (N = 2, K = 3) in two rounds
+__global__ __launch_bounds__(FIN_NT) void dice_ce_finalize_kernel(double* ws, int nblk, int N, int K, long V, int batch_dice,
                                                               float smooth, float* out, float weight, float* total, int accumulate) {
     extern __shared__ double ce_part[];               // N doubles (dynamic: any batch size up to LNN_DICE_CE_MAX_BATCH)
     constexpr int W = 3 * KMAX + 1;
     const float* pws = reinterpret_cast<const float*>(ws + (long)N * K * 3 + 2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_n = 3 * K + 1;                      // tp/fp/fn of every class, then the CE sum
-    for (int j = wave; j < N * per_n; j += NT / 64) {
+    for (int j = wave; j < N * per_n; j += FIN_NT / 64) {
         const int n = j / per_n, jj = j % per_n;
         const int i = jj < 3 * K ? jj : 3 * KMAX;
         double s = 0;
@@ -373,7 +421,7 @@ __global__ __launch_bounds__(NT) void dice_ce_bwd_kernel(const float* __restrict
             float x[KMAX], p[KMAX], lse;
 #pragma unroll
             for (int k = 0; k < KK; ++k) x[k] = xv[k][e];
-            softmax_regs<KT>(x, K, p, lse);
+            softmax_regs_hw<KT>(x, K, p, lse);
             const int lab = (int)yv[e];
             float a[KMAX], dot = 0.f;
 #pragma unroll
@@ -664,9 +712,12 @@ static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* l
     LNN_REQUIRE(K >= 2 && K <= KMAX, "lnn_dice_ce_fwd: K=%d unsupported (2..%d)", K, KMAX);
     LNN_REQUIRE(N >= 1 && N <= LNN_DICE_CE_MAX_BATCH, "lnn_dice_ce_fwd: batch %d unsupported (1..%d)", N, LNN_DICE_CE_MAX_BATCH);
     // 1024 blocks per launch at most: the per-block reduction of 3K + 1 values and the finalize pass scale with the block count
-    // (measured at 2 x 3 x 160x192x160, profiles/r04_reduction_variants.txt: 256 blocks 57 us, 512 / 1024 46 us, 2048 59 us)
+    // (measured at 2 x 3 x 160x192x160, profiles/r04_reduction_variants.txt: with the 111-operation inner loop 256 blocks per sample 57 us,
+    // 512 / 1024 46 us, 2048 59 us; with the hardware-transcendental loop 256 per sample 31.9 us, 512 34.0, 1024 39.4)
     int nblk = vox_blocks(V);
-    const int cap = 1024 / N > 1 ? 1024 / N : 1;
+    static int cap_env = -1;          // LNN_DCE_BLOCKS: blocks per sample (A/B measurements; tools/microbench_reductions.py)
+    if (cap_env < 0) { const char* e = getenv("LNN_DCE_BLOCKS"); cap_env = e ? atoi(e) : 0; }
+    const int cap = cap_env > 0 ? (cap_env < 1024 ? cap_env : 1024) : (512 / N > 1 ? 512 / N : 1);
     if (nblk > cap) nblk = cap;
     const bool vec = (V & 3) == 0 && lnn_aligned16(logits) && lnn_aligned16(labels);
 #define LNN_DCE_FWD(KT, VEC) hipLaunchKernelGGL((dice_ce_fwd_kernel<KT, VEC>), dim3(nblk, N), dim3(NT), 0, s, logits, labels, K, V, ws, N)
@@ -674,7 +725,7 @@ static int dice_ce_fwd_impl(lnn_stream_t s_, const float* logits, const float* l
     else { if (K == 3) LNN_DCE_FWD(3, 1); else if (K == 2) LNN_DCE_FWD(2, 1); else if (K == 4) LNN_DCE_FWD(4, 1); else LNN_DCE_FWD(0, 1); }
 #undef LNN_DCE_FWD
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd");
-    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(NT), N * sizeof(double), s, ws, nblk, N, K, V, batch_dice, smooth, out_loss, weight,
+    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(FIN_NT), N * sizeof(double), s, ws, nblk, N, K, V, batch_dice, smooth, out_loss, weight,
                        total, accumulate);
     LNN_CHECK_LAUNCH("lnn_dice_ce_fwd(finalize)");
     return LNN_OK;
