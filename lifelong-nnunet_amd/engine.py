@@ -535,8 +535,10 @@ class UNetEngine:
     # persistent MFMA kernels size their grids for ``lane_cus`` CUs (lnn_set_cu_budget) -- a persistent 8-wave block owns its CU's
     # registers, so only CUs it does not occupy can run the other lane's HBM-bound normalisation / loss-side kernels.  Measured
     # on one conv + one normalisation pass (profiles/r04_overlap_probe.txt): a 192-CU grid costs the conv 7 % (the part is
-    # power-limited) and hides the other sample's normalisation pass almost completely.  Round 1's two-lane mode had no CU
-    # budget and lost 1.5 %.
+    # power-limited) and hides the other sample's normalisation pass almost completely.  Over the WHOLE step the mode loses 4 % at
+    # every budget from 112 to 256 CUs (profiles/r04_lanes_ab.txt: the lanes overlap 91 % of the time, but a half-chip N = 1 MFMA
+    # kernel takes 1.9x the whole-chip N = 2 one -- the convolutions are bound by the matrix pipes of all CUs): OFF by default, kept
+    # for re-measurement (LNN_SAMPLE_LANES=1).
     def _lanes(self):
         if not self.sample_lanes or self.N < 2:
             return [(0, self.N)]
@@ -586,9 +588,9 @@ class UNetEngine:
                 first = False
         finally:
             nat.set_stream_override(None)
+            nat.call_plain("lnn_set_cu_budget", 0)
         for st in streams:
             main.wait_stream(st)
-        nat.call_plain("lnn_set_cu_budget", 0)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, seg_weights: Optional[List[torch.Tensor]] = None, body: bool = True):
