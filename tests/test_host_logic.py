@@ -592,3 +592,28 @@ def test_load_checkpoint_written_by_the_reference_classes(golden_dir):
     assert sorted(out["optimizer_state_dict"]["state"].keys()) == meta["optimizer_state_indices"]
     assert all(torch.equal(out["optimizer_state_dict"]["state"][i]["momentum_buffer"], opt_state[i]["momentum_buffer"])
                for i in meta["optimizer_state_indices"])
+
+
+@pytest.mark.parametrize("pools,kernels", [(None, None),
+                                           ([[1, 2, 2], [2, 2, 2]], [[1, 3, 3], [3, 3, 3], [3, 3, 3]])])
+def test_backward_plan_invariants_of_the_fused_normalisation_reduce(pools, kernels):
+    """The engine's plan (built on the CPU: no kernel runs) -- what the fused data-gradient + normalisation-reduce call of the backward
+    relies on: the second block of every stage consumes exactly the first block's output (its gx IS that block's gz, written once, no
+    concatenation), the pair is adjacent in the execution order (the reduce leaves its sums in the lane's workspace; nothing may run
+    between the data gradient of block 1 and the apply pass of block 0), and every other block has no such partner."""
+    net = Generic_UNet(2, 8, 3, 2, patch_size=(8, 16, 16), batch_size=2, device='cpu', pool_op_kernel_sizes=pools,
+                       conv_kernel_sizes=kernels)
+    eng = net.engine_for(torch.zeros(2, 2, 8, 16, 16))
+    order = list(eng.order)
+    partners = 0
+    for blk in eng.blocks:
+        xb = blk.x_block
+        if xb is None:
+            continue
+        partners += 1
+        assert blk.gx is xb.gz and blk.x is xb.z and blk.gx2 is None and blk.x2 is None and not blk.gx_accumulate
+        assert tuple(blk.strides) == (1, 1, 1) and blk.cin == xb.cout and blk.in_dims == tuple(xb.y.shape[1:4])
+        assert order.index(blk) == order.index(xb) + 1
+    assert partners == len(eng.blocks) // 2
+    firsts = [b for b in eng.blocks if b.x_block is None]
+    assert all(not any(o.x_block is b for o in firsts) for b in firsts)
