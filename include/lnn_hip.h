@@ -164,7 +164,8 @@ int lnn_instnorm_lrelu_fwd(lnn_stream_t s, const void* y_h, void* z_h, int ld_z,
                            float slope);
 /* lnn_instnorm_lrelu_fwd + lnn_seg1x1_fwd of the same activation in one pass (decoder blocks that feed a seg_outputs head,
  * generic_ViT_UNet.py:263-264): logits (N,K,V) fp32 = seg_w (K,C) . z, computed from the fp16-rounded z the kernel writes.
- * K <= 8, C/8 a power of two <= 64; other shapes: call the two functions. */
+ * K <= 8, C/8 a power of two <= 64; other shapes: call the two functions.  z may be NULL: only the logits are written (the last
+ * decoder block of a training step: its normalised tensor has no other reader, the head's backward rebuilds it from y). */
 int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s, const void* y, void* z, int ld_z, int N, long V, int C, const float* mean,
                                const float* rstd, const float* gamma, const float* beta, float slope, const float* seg_w,
                                float* logits, int K);
@@ -443,11 +444,6 @@ int lnn_convT3d_k2s2_fwd_ws(lnn_stream_t s, const void* x, int ld_x, const void*
                             int W, int C, int K, float* splitk_ws, long splitk_elems);
 int lnn_convT3d_k2s2_dgrad_ws(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int D,
                               int H, int W, int C, int K, int accumulate, float* splitk_ws, long splitk_elems);
-
-/* Launch configuration (process-wide, set before enqueueing; not thread-safe): the persistent MFMA kernels size their grids for `cus`
- * CUs instead of the whole device (0 = all).  The two-lane engine uses it so that one sample's InstanceNorm / loss-side kernels run on
- * the CUs the other sample's convolution leaves free (no counterpart in the reference: its kernels come from MIOpen / cuDNN). */
-int lnn_set_cu_budget(int cus);
 
 /* fp32 <-> fp16 helpers for the image input (N,1,D,H,W f32 -> fp16, same memory order when C == 1) */
 int lnn_cast_f32_to_h(lnn_stream_t s, const float* src, void* dst_h, long n);

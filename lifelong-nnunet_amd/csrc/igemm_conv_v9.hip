@@ -541,13 +541,11 @@ bool lnn_conv_s1_v9_supported(const ConvParams& p) {
     return true;
 }
 
-// lnn_set_cu_budget: the persistent MFMA kernels (this one, the stride-1 / stride-2 weight gradients, the streaming stride-2 conv)
-// size their grids for this many CUs instead of all of them, so that kernels of ANOTHER stream find free CUs next to them -- a
-// persistent 8-wave block owns its CU's register file, nothing co-schedules with it (profiles/r04_overlap_probe.txt: a 192-CU grid
-// costs the conv 7 %, the part is power-limited, and hides an InstanceNorm pass of the other sample almost completely).  0 = all.
+// lnn_debug_set_cu_budget (measurements only): the persistent MFMA kernels (this one, the stride-1 / stride-2 weight gradients, the
+// streaming stride-2 conv) size their grids for this many CUs instead of all of them.  0 = all.
 static int g_cu_budget = 0;
-extern "C" int lnn_set_cu_budget(int cus) {
-    LNN_REQUIRE(cus >= 0 && cus <= 4096, "lnn_set_cu_budget: %d out of range", cus);
+extern "C" int lnn_debug_set_cu_budget(int cus) {
+    LNN_REQUIRE(cus >= 0 && cus <= 4096, "lnn_debug_set_cu_budget: %d out of range", cus);
     g_cu_budget = cus;
     return LNN_OK;
 }

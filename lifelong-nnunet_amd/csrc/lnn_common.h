@@ -18,8 +18,8 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define LNN_WAVE 64
 
 void lnn_set_error(const char* fmt, ...);
-// CUs the persistent MFMA kernels size their grids for: the device's CU count, or the budget set by lnn_set_cu_budget (two-lane
-// mode: the other lane's memory-bound kernels run on the CUs left free)
+// CUs the persistent MFMA kernels size their grids for: the device's CU count, or the budget set by lnn_debug_set_cu_budget
+// (measurements only)
 int lnn_cu_budget(int device_cus);
 
 #define LNN_REQUIRE(cond, ...)                 \

@@ -34,6 +34,10 @@ int lnn_debug_set_gen_mode(int mode);
  * ran the two separate calls. */
 int lnn_debug_last_dgrad_reduce_fused(void);
 
+/* Measurements only: the persistent MFMA kernels size their grids for `cus` CUs instead of the whole device (0 = all) -- read at
+ * launch time, so set / launch / reset brackets individual launches (tools/, profiles/r04_overlap_probe.txt).  Process-wide. */
+int lnn_debug_set_cu_budget(int cus);
+
 #ifdef __cplusplus
 }
 #endif

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __re
             for (int k = 0; k < SEG_KMAX; ++k)
                 if (k < K) pk[k] += zf * w[k][e];
         }
-        *reinterpret_cast<half8*>(zp + v * ld_z) = o;
+        if (z) *reinterpret_cast<half8*>(zp + v * ld_z) = o;        // (kernel-uniform: z == nullptr -> logits only)
         for (int m = 1; m < rm.C8; m <<= 1) {
 #pragma unroll
             for (int k = 0; k < SEG_KMAX; ++k)
@@ -831,7 +831,7 @@ extern "C" int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s_, const void* y, void* 
                                           const float* seg_w, float* logits, int K) {
     hipStream_t s = (hipStream_t)s_;
     if (int e = check_common(y, N, V, C, "lnn_instnorm_lrelu_seg_fwd")) return e;
-    LNN_REQUIRE(z != nullptr && lnn_aligned16(z) && ld_z >= C && ld_z % 8 == 0, "lnn_instnorm_lrelu_seg_fwd: bad z / ld_z");
+    LNN_REQUIRE(z == nullptr || (lnn_aligned16(z) && ld_z >= C && ld_z % 8 == 0), "lnn_instnorm_lrelu_seg_fwd: bad z / ld_z");
     LNN_REQUIRE(mean && rstd && gamma && beta && seg_w && logits, "lnn_instnorm_lrelu_seg_fwd: null parameter");
     const int C8 = C >> 3;
     LNN_REQUIRE(K >= 1 && K <= SEG_KMAX && (C8 & (C8 - 1)) == 0 && C8 <= 64,

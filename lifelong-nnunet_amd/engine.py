@@ -350,6 +350,14 @@ class UNetEngine:
             order.append(seg)
             x, gx, cdown = b1.z, b1.gz, cs
         self.order = order
+        # resolution level of every item (0 = full resolution; a transposed convolution counts at the level it writes)
+        self._level = {}
+        for item in order:
+            pre = item.prefix.split(".")
+            if pre[0] == "conv_blocks_context":
+                self._level[id(item)] = int(pre[1])
+            else:                       # conv_blocks_localization.u / tu.u / seg_outputs.u sit at encoder depth num_pool - 1 - u
+                self._level[id(item)] = num_pool - 1 - int(pre[1])
         # decoder blocks whose output feeds a seg head directly (the head follows its block in execution order)
         self._seg_after = {id(seg.x_block): seg for seg in self.segs}
 
@@ -448,12 +456,13 @@ class UNetEngine:
         self.splitk_ws = torch.zeros(need, dtype=torch.float32, device=dev)
         self.packed_version = -1
         self.unused_heads: List[str] = []
-        self._side = None
-        self._lstreams, self._lws, self._lsplitk = [], [], []
-        # two-lane mode (see _fork): opt-in until it is measured on the whole step
-        self.sample_lanes = os.environ.get("LNN_SAMPLE_LANES", "0") == "1"
-        self.lane_cus = int(os.environ.get("LNN_LANE_CUS", "192"))
-        self.lane_stagger = os.environ.get("LNN_LANE_STAGGER", "1") == "1"
+        self._sides = {}
+        # A/B switches of round 5 (measurements only; see backward / forward)
+        d = os.environ.get("LNN_WGRAD_DEFER", "")
+        self._defer = tuple(int(v) for v in d.split(",")) if d else None
+        self.lazy_top_z = os.environ.get("LNN_NO_LAZY_TOP_Z", "0") != "1"
+        self._top_block = self.segs[-1].x_block
+        self._top_z_valid = False
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
@@ -529,69 +538,6 @@ class UNetEngine:
             return _Ptr(obj.buf, n0 * obj.V * obj.ld + obj.off)
         return _Ptr(obj, n0 * obj.stride(0)) if n0 else obj
 
-    # ------------------------------------------------------------------------------------------ sample lanes
-    # Patches are independent through the whole network (InstanceNorm is per sample).  Two-lane mode (``sample_lanes``, round 4):
-    # the batch is processed as two halves on two HIP streams, their launches enqueued ALTERNATELY item by item, and the
-    # persistent MFMA kernels size their grids for ``lane_cus`` CUs (lnn_set_cu_budget) -- a persistent 8-wave block owns its CU's
-    # registers, so only CUs it does not occupy can run the other lane's HBM-bound normalisation / loss-side kernels.  Measured
-    # on one conv + one normalisation pass (profiles/r04_overlap_probe.txt): a 192-CU grid costs the conv 7 % (the part is
-    # power-limited) and hides the other sample's normalisation pass almost completely.  Over the WHOLE step the mode loses 4 % at
-    # every budget from 112 to 256 CUs (profiles/r04_lanes_ab.txt: the lanes overlap 91 % of the time, but a half-chip N = 1 MFMA
-    # kernel takes 1.9x the whole-chip N = 2 one -- the convolutions are bound by the matrix pipes of all CUs): OFF by default, kept
-    # for re-measurement (LNN_SAMPLE_LANES=1).
-    def _lanes(self):
-        if not self.sample_lanes or self.N < 2:
-            return [(0, self.N)]
-        h = self.N // 2
-        return [(0, h), (h, self.N - h)]
-
-    def _lane_streams(self, n):
-        while len(self._lstreams) < n:
-            self._lstreams.append(torch.cuda.Stream(device=self.device))
-            self._lws.append(torch.zeros_like(self.ws))
-            # every lane runs on its own stream: the split-K scratch of the small deep layers must not be shared either
-            self._lsplitk.append(self.splitk_ws if not self._lsplitk else torch.zeros_like(self.splitk_ws))
-        return self._lstreams[:n]
-
-    def _fork(self, fn):
-        """``fn(n0, nn, ws, splitk_ws)`` is a GENERATOR that enqueues one item of the plan per step.  One lane: run it through.  Two
-        lanes: one generator per lane, each on its own stream (own workspaces), advanced alternately so that the two lanes' launches
-        interleave on the host as they are meant to on the chip; joined before returning."""
-        lanes = self._lanes()
-        if len(lanes) == 1:
-            for _ in fn(0, self.N, self.ws, self.splitk_ws):
-                pass
-            return
-        nat.call_plain("lnn_set_cu_budget", self.lane_cus)
-        main = torch.cuda.current_stream()
-        streams = self._lane_streams(len(lanes))
-        ev = torch.cuda.Event()
-        ev.record(main)
-        gens = []
-        for (n0, nn), st, ws, sk in zip(lanes, streams, self._lws, self._lsplitk):
-            st.wait_event(ev)
-            gens.append(fn(n0, nn, ws, sk))
-        alive = list(range(len(gens)))
-        handles = [st.cuda_stream for st in streams]
-        first = True
-        try:
-            while alive:
-                for i in list(alive):
-                    if first and i > 0 and self.lane_stagger:
-                        continue                      # lane 1 starts one item late: its convolution meets lane 0's normalisation
-                    # the lane's launches name their stream directly (no torch op runs inside a lane)
-                    nat.set_stream_override(handles[i])
-                    try:
-                        next(gens[i])
-                    except StopIteration:
-                        alive.remove(i)
-                first = False
-        finally:
-            nat.set_stream_override(None)
-            nat.call_plain("lnn_set_cu_budget", 0)
-        for st in streams:
-            main.wait_stream(st)
-
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, seg_weights: Optional[List[torch.Tensor]] = None, body: bool = True):
         """x: (N,1,D,H,W) float32 on the device.  Returns logits per decoder level u (low-res first, as
@@ -610,76 +556,89 @@ class UNetEngine:
                 nat.call("lnn_image_to_cl_h", x.contiguous(), self.image, N, self.in_channels, x[0, 0].numel(), self.cin_pad)
         logits = [torch.empty((N, self.K) + seg.x.dims, device=self.device) for seg in self.segs]
         sw = None if seg_weights is None else [w.contiguous() for w in seg_weights]
-        at = self._at
-
-        def lane(n0, nn, ws, splitk_ws):
-            u = 0
-            fused_segs = set()
-            for item in self.order:
-                if isinstance(item, ConvBlock):
-                    if not body:
-                        continue
-                    D, H, W = item.in_dims
-                    xin = at(self.image, n0) if item.x is None else at(item.x, n0)
-                    ldx = 1 if item.x is None else item.x.ld
-                    C = item.cout
-                    V = item.z.V
-                    mean, rstd = _Ptr(item.mean, n0 * C), _Ptr(item.rstd, n0 * C)
-                    if not item.iso:
-                        # per-axis kernel / stride from the plans: generic-geometry kernel, statistics as a separate pass
-                        self._probed("fwd", item, lambda: nat.call(
-                            "lnn_conv3d_fwd_g", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C, nn, D, H, W,
-                            item.cin_k, C, *item.kernel, *item.strides, splitk_ws, splitk_ws.numel()))
-                        nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
-                    elif self.fuse_in_stats:
-                        # conv + InstanceNorm statistics in one call (the z-streaming kernel sums in its epilogue)
-                        self._probed("fwd", item, lambda: nat.call(
-                            "lnn_conv3d_fwd_in_stats", xin, None if item.x2 is None else at(item.x2, n0), ldx,
-                            item.x.C if item.x2 is not None else 0, self._wp(item.wp_fwd), self.pview(item.b),
-                            at(item.y, n0), nn, D, H, W, item.cin_k, C, item.stride, IN_EPS, mean, rstd, ws,
-                            splitk_ws, splitk_ws.numel()))
-                    else:
-                        if item.x2 is not None:
-                            nat.call("lnn_conv3d_fwd_cat", xin, at(item.x2, n0), ldx, item.x.C, self._wp(item.wp_fwd),
-                                     self.pview(item.b), at(item.y, n0), C, nn, D, H, W, item.cin_k, C)
-                        else:
-                            nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), at(item.y, n0), C,
-                                     nn, D, H, W, item.cin_k, C, item.stride)
-                        nat.call("lnn_instnorm_stats", at(item.y, n0), nn, V, C, IN_EPS, mean, rstd, ws)
-                    yield                      # (two lanes: the other lane's next launch goes between the conv and its normalisation)
-                    seg = self._seg_after.get(id(item))
-                    if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
-                        # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y
-                        self._probed("in_fwd", item, lambda: nat.call(
-                            "lnn_instnorm_lrelu_seg_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
-                            self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, self.pview(seg.w),
-                            at(logits[self.segs.index(seg)], n0), self.K))
-                        fused_segs.add(id(seg))
-                    else:
-                        self._probed("in_fwd", item, lambda: nat.call(
-                            "lnn_instnorm_lrelu_fwd", at(item.y, n0), at(item.z, n0), item.z.ld, nn, V, C, mean, rstd,
-                            self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE))
-                elif isinstance(item, UpBlock):
-                    if not body:
-                        continue
-                    D, H, W = item.x.dims
-                    if item.iso:
-                        self._probed("fwd", item, lambda: nat.call(
-                            "lnn_convT3d_k2s2_fwd_ws", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
-                            item.y.ld, nn, D, H, W, item.cin, item.cout, splitk_ws, splitk_ws.numel()))
-                    else:
-                        self._probed("fwd", item, lambda: nat.call(
-                            "lnn_convT3d_fwd_g", at(item.x, n0), item.x.ld, self._wp(item.wp_fwd), at(item.y, n0),
-                            item.y.ld, nn, D, H, W, item.cin, item.cout, *item.strides, splitk_ws, splitk_ws.numel()))
+        ws, splitk_ws = self.ws, self.splitk_ws
+        u = 0
+        fused_segs = set()
+        for item in self.order:
+            if isinstance(item, ConvBlock):
+                if not body:
+                    continue
+                D, H, W = item.in_dims
+                xin = self.image if item.x is None else item.x
+                ldx = 1 if item.x is None else item.x.ld
+                C = item.cout
+                V = item.z.V
+                mean, rstd = item.mean, item.rstd
+                if not item.iso:
+                    # per-axis kernel / stride from the plans: generic-geometry kernel, statistics as a separate pass
+                    self._probed("fwd", item, lambda: nat.call(
+                        "lnn_conv3d_fwd_g", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), item.y, C, N, D, H, W,
+                        item.cin_k, C, *item.kernel, *item.strides, splitk_ws, splitk_ws.numel()))
+                    nat.call("lnn_instnorm_stats", item.y, N, V, C, IN_EPS, mean, rstd, ws)
+                elif self.fuse_in_stats:
+                    # conv + InstanceNorm statistics in one call (the z-streaming kernel sums in its epilogue)
+                    self._probed("fwd", item, lambda: nat.call(
+                        "lnn_conv3d_fwd_in_stats", xin, item.x2, ldx,
+                        item.x.C if item.x2 is not None else 0, self._wp(item.wp_fwd), self.pview(item.b),
+                        item.y, N, D, H, W, item.cin_k, C, item.stride, IN_EPS, mean, rstd, ws,
+                        splitk_ws, splitk_ws.numel()))
                 else:
-                    if id(item) not in fused_segs:
-                        w = self.pview(item.w) if sw is None else sw[u]
-                        nat.call("lnn_seg1x1_fwd", at(item.x, n0), item.x.ld, w, at(logits[u], n0), nn, item.x.V, item.cin, self.K)
-                    u += 1
-                yield
-
-        self._fork(lane)
+                    if item.x2 is not None:
+                        nat.call("lnn_conv3d_fwd_cat", xin, item.x2, ldx, item.x.C, self._wp(item.wp_fwd),
+                                 self.pview(item.b), item.y, C, N, D, H, W, item.cin_k, C)
+                    else:
+                        nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), item.y, C,
+                                 N, D, H, W, item.cin_k, C, item.stride)
+                    nat.call("lnn_instnorm_stats", item.y, N, V, C, IN_EPS, mean, rstd, ws)
+                seg = self._seg_after.get(id(item))
+                if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
+                    # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y.  The
+                    # LAST block's normalised tensor has no other reader in a training step (the head's backward rebuilds it from
+                    # y, lnn_instnorm_lrelu_seg_bwd): it is not written (0.63 GB at the top level of the 160x192x160 plan) and
+                    # produced on demand by materialise_top_z() for the callers that read it (multi-head evaluation, body=False)
+                    lazy = item is self._top_block and self.lazy_top_z
+                    self._probed("in_fwd", item, lambda: nat.call(
+                        "lnn_instnorm_lrelu_seg_fwd", item.y, None if lazy else item.z, item.z.ld, N, V, C, mean, rstd,
+                        self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, self.pview(seg.w),
+                        logits[self.segs.index(seg)], self.K))
+                    fused_segs.add(id(seg))
+                    if item is self._top_block:
+                        self._top_z_valid = not lazy
+                else:
+                    self._probed("in_fwd", item, lambda: nat.call(
+                        "lnn_instnorm_lrelu_fwd", item.y, item.z, item.z.ld, N, V, C, mean, rstd,
+                        self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE))
+                    if item is self._top_block:
+                        self._top_z_valid = True
+            elif isinstance(item, UpBlock):
+                if not body:
+                    continue
+                D, H, W = item.x.dims
+                if item.iso:
+                    self._probed("fwd", item, lambda: nat.call(
+                        "lnn_convT3d_k2s2_fwd_ws", item.x, item.x.ld, self._wp(item.wp_fwd), item.y,
+                        item.y.ld, N, D, H, W, item.cin, item.cout, splitk_ws, splitk_ws.numel()))
+                else:
+                    self._probed("fwd", item, lambda: nat.call(
+                        "lnn_convT3d_fwd_g", item.x, item.x.ld, self._wp(item.wp_fwd), item.y,
+                        item.y.ld, N, D, H, W, item.cin, item.cout, *item.strides, splitk_ws, splitk_ws.numel()))
+            else:
+                if id(item) not in fused_segs:
+                    if item.x_block is self._top_block:
+                        self.materialise_top_z()
+                    w = self.pview(item.w) if sw is None else sw[u]
+                    nat.call("lnn_seg1x1_fwd", item.x, item.x.ld, w, logits[u], N, item.x.V, item.cin, self.K)
+                u += 1
         return logits
+
+    def materialise_top_z(self):
+        """The normalised output of the last decoder block, if the forward skipped writing it (see forward)."""
+        if self._top_z_valid:
+            return
+        b = self._top_block
+        nat.call("lnn_instnorm_lrelu_fwd", b.y, b.z, b.z.ld, self.N, b.z.V, b.cout, b.mean, b.rstd,
+                 self.pview(b.gamma), self.pview(b.beta), LRELU_SLOPE)
+        self._top_z_valid = True
 
     def conv_outputs(self, logits):
         """name -> (N,C,D,H,W) strided VIEW of the output of every conv / transposed conv / seg head of the LAST forward,
@@ -713,31 +672,52 @@ class UNetEngine:
     def backward(self, dlogits: List[Optional[torch.Tensor]], skip_body: bool = False, progress=None):
         """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.
         Accumulates parameter gradients into the flat arena ``self.grad`` (scaled like dlogits)."""
+        N = self.N
         self.gpanels.zero_()
         self.unused_heads = [seg.w.name for seg, dl in zip(self.segs, dlogits) if dl is None]
         dls = [None if dl is None else dl.contiguous() for dl in dlogits]
-        at = self._at
+        ws, splitk_ws = self.ws, self.splitk_ws
         # Weight gradients are off the critical path of backward (they only have to be final before the optimiser /
         # the all-reduce): they go to a SIDE HIP stream right after the layer's dL/dy exists.
         main = torch.cuda.current_stream()
         # data parallel (progress given): the weight gradients stay on the side stream; a layer's panel is folded into the
         # gradient arena there too, and the all-reduce of every bucket that became final is launched FROM the side stream
         # (parallel.GradAllReducer.progress): two streams share the chip, as in the single-GPU plan
-        multi = len(self._lanes()) > 1
-        assert not (multi and (progress is not None or self.deterministic_wgrad)), \
-            "two-lane mode (LNN_SAMPLE_LANES=1) is single-GPU and uses the atomic weight-gradient panels"
-        # two lanes: each lane runs its weight gradients on its own stream (the OTHER lane is what overlaps with them)
-        side = self._side_stream() if (self.overlap_wgrad and not multi) else None
+        side = self._side_stream() if self.overlap_wgrad else None
+        # Deferred weight gradients (LNN_WGRAD_DEFER="L,F", measurement switch): the weight gradients of the decoder levels <= L
+        # (the big MFMA-bound launches at the start of backward) are held back and released on a SECOND side stream when the
+        # main stream reaches decoder level F -- next to the latency-bound kernels of the bottom of the U instead of next to the
+        # MFMA-bound data gradients of their own level
+        defer = self._defer if (side is not None and progress is None and not self.deterministic_wgrad) else None
+        side2 = self._side_stream(1) if defer is not None else None
+        held = []
 
-        def on_side(fn):
+        def on_side(fn, level=None, decoder=False):
             if side is None:
                 fn()
                 return
             ev = torch.cuda.Event()
             ev.record(main)
+            if defer is not None and decoder and level is not None and level <= defer[0] and not flushed[0]:
+                held.append((ev, fn))
+                return
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 fn()
+
+        flushed = [False]
+
+        def flush():
+            flushed[0] = True
+            if len(defer) > 2:
+                nat.call_plain("lnn_debug_set_cu_budget", defer[2])
+            for ev, fn in held:
+                side2.wait_event(ev)
+                with torch.cuda.stream(side2):
+                    fn()
+            if len(defer) > 2:
+                nat.call_plain("lnn_debug_set_cu_budget", 0)
+            held.clear()
 
         # the DP all-reduce overlaps with backward and needs every layer's gradient final as soon as its wgrad is:
         # per-layer unpack there; otherwise one batched unpack after the last wgrad
@@ -757,175 +737,176 @@ class UNetEngine:
                 nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), nt, C, K, K * nt, nt, 1, 1.0, 1)
 
         fuse_seg = self.fuse_seg_bwd and not skip_body and not self.numeric_conv_bias_grad and self.K <= 4
-
-        def lane(n0, nn, ws, splitk_ws):
-            seg_u = len(self.segs)
-            pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
-            presummed = set()     # id(block): pass 1 of its normalisation backward was taken by the data gradient that produced its dL/dz
-            for item in reversed(self.order):
-                if progress is not None and item is not self.order[-1]:
-                    # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
-                    # (weight gradients + their unpack) have run what is enqueued so far; a head that was deferred into
-                    # this block's call is not final yet: only what lies behind the head is
-                    wm_item = pending[id(item)][0] if id(item) in pending else item
-                    progress(self._watermark[id(wm_item)], side)
-                if isinstance(item, SegHead):
-                    seg_u -= 1
-                    dl = dls[seg_u]
-                    if dl is None:
-                        if not item.gx_has_prior:
-                            assert not multi, "two-lane mode: every full-resolution head has a gradient (deep-supervision weight > 0)"
-                            item.gx.buf[n0:n0 + nn].zero_()
-                        continue
-                    if fuse_seg:
-                        pending[id(item.x_block)] = (item, dl)
-                        continue
-                    gw = self.pview(item.w, self.grad).view(self.K, item.cin)
-                    nat.call("lnn_seg1x1_bwd", at(item.x, n0), item.x.ld, self.pview(item.w), at(dl, n0), at(item.gx, n0),
-                             item.gx.ld, gw, nn, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0, ws)
-                elif skip_body:
+        seg_u = len(self.segs)
+        pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
+        presummed = set()     # id(block): pass 1 of its normalisation backward was taken by the data gradient that produced its dL/dz
+        in_decoder = True
+        for item in reversed(self.order):
+            level = self._level[id(item)]
+            if isinstance(item, ConvBlock) and item.prefix.startswith("conv_blocks_context"):
+                in_decoder = False
+            if defer is not None and not flushed[0] and (not in_decoder or level >= defer[1]):
+                flush()
+            if progress is not None and item is not self.order[-1]:
+                # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
+                # (weight gradients + their unpack) have run what is enqueued so far; a head that was deferred into
+                # this block's call is not final yet: only what lies behind the head is
+                wm_item = pending[id(item)][0] if id(item) in pending else item
+                progress(self._watermark[id(wm_item)], side)
+            if isinstance(item, SegHead):
+                seg_u -= 1
+                dl = dls[seg_u]
+                if dl is None:
+                    if not item.gx_has_prior:
+                        item.gx.buf.zero_()
                     continue
-                elif isinstance(item, ConvBlock):
-                    V, K, C = item.z.V, item.cout, item.cin_k
-                    if id(item) in pending:
-                        seg, dl = pending.pop(id(item))
+                if fuse_seg:
+                    pending[id(item.x_block)] = (item, dl)
+                    continue
+                if item.x_block is self._top_block:
+                    self.materialise_top_z()
+                gw = self.pview(item.w, self.grad).view(self.K, item.cin)
+                nat.call("lnn_seg1x1_bwd", item.x, item.x.ld, self.pview(item.w), dl, item.gx,
+                         item.gx.ld, gw, N, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0, ws)
+            elif skip_body:
+                continue
+            elif isinstance(item, ConvBlock):
+                V, K, C = item.z.V, item.cout, item.cin_k
+                if id(item) in pending:
+                    seg, dl = pending.pop(id(item))
+                    self._probed("in_bwd", item, lambda: nat.call(
+                        "lnn_instnorm_lrelu_seg_bwd", item.y, item.gz if seg.gx_has_prior else None,
+                        item.gz.ld, self.pview(seg.w), dl, self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
+                        N, V, K, item.mean, item.rstd, self.pview(item.gamma), self.pview(item.beta),
+                        LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
+                elif item.cin_k == 1 and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
+                    # the first block has no data gradient: only the sums of its normalisation backward are taken here (or were,
+                    # by the data gradient of the block behind it), dy is rebuilt tile by tile inside the weight gradient below
+                    # (lnn_conv3d_wgrad_c1_in_bwd)
+                    if id(item) not in presummed:
                         self._probed("in_bwd", item, lambda: nat.call(
-                            "lnn_instnorm_lrelu_seg_bwd", at(item.y, n0), at(item.gz, n0) if seg.gx_has_prior else None,
-                            item.gz.ld, self.pview(seg.w), at(dl, n0), self.pview(seg.w, self.grad).view(self.K, seg.cin), self.K,
-                            nn, V, K, _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta),
+                            "lnn_instnorm_lrelu_bwd_sums", item.y, item.gz, item.gz.ld, N, V, K,
+                            item.mean, item.rstd, self.pview(item.gamma), self.pview(item.beta),
                             LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
-                    elif item.cin_k == 1 and self.fuse_first_bwd and not self.numeric_conv_bias_grad:
-                        # the first block has no data gradient: only the sums of its normalisation backward are taken here (or were,
-                        # by the data gradient of the block behind it), dy is rebuilt tile by tile inside the weight gradient below
-                        # (lnn_conv3d_wgrad_c1_in_bwd)
-                        if id(item) not in presummed:
-                            self._probed("in_bwd", item, lambda: nat.call(
-                                "lnn_instnorm_lrelu_bwd_sums", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                                _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta),
-                                LRELU_SLOPE, self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad), 1.0, ws))
-                        D, H, W = item.in_dims
-
-                        def first_wgrad(item=item, K=K, D=D, H=H, W=W):
-                            det = self._det_scratch()
-                            nat.call("lnn_conv3d_wgrad_c1_in_bwd", at(self.image, n0), at(item.y, n0), at(item.gz, n0), item.gz.ld,
-                                     self._pn(item.panel), nn, D, H, W, K, _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K),
-                                     self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, ws, det,
-                                     0 if det is None else det.numel())
-                            if per_layer_unpack:
-                                unpack(item)
-                        yield
-                        on_side(lambda: self._probed("wgrad", item, first_wgrad))
-                        yield
-                        continue
-                    elif id(item) in presummed:
-                        self._probed("in_bwd", item, lambda: nat.call(
-                            "lnn_instnorm_lrelu_bwd_apply", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                            _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
-                            ws))
-                    else:
-                        self._probed("in_bwd", item, lambda: nat.call(
-                            "lnn_instnorm_lrelu_bwd", at(item.y, n0), at(item.gz, n0), item.gz.ld, nn, V, K,
-                            _Ptr(item.mean, n0 * K), _Ptr(item.rstd, n0 * K), self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
-                            self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
-                            self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws))
-                    yield                          # (two lanes: between the normalisation backward and the MFMA kernels)
                     D, H, W = item.in_dims
-                    xin = at(self.image, n0) if item.x is None else at(item.x, n0)
-                    ldx = 1 if item.x is None else item.x.ld
 
-                    def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
-                        self._probed("wgrad", item, lambda: conv_wgrad_call(item, xin, ldx, K, C, D, H, W))
+                    def first_wgrad(item=item, K=K, D=D, H=H, W=W):
+                        det = self._det_scratch()
+                        nat.call("lnn_conv3d_wgrad_c1_in_bwd", self.image, item.y, item.gz, item.gz.ld,
+                                 self._pn(item.panel), N, D, H, W, K, item.mean, item.rstd,
+                                 self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, ws, det,
+                                 0 if det is None else det.numel())
                         if per_layer_unpack:
                             unpack(item)
+                    on_side(lambda: self._probed("wgrad", item, first_wgrad))
+                    continue
+                elif id(item) in presummed:
+                    self._probed("in_bwd", item, lambda: nat.call(
+                        "lnn_instnorm_lrelu_bwd_apply", item.y, item.gz, item.gz.ld, N, V, K,
+                        item.mean, item.rstd, self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, ws))
+                else:
+                    self._probed("in_bwd", item, lambda: nat.call(
+                        "lnn_instnorm_lrelu_bwd", item.y, item.gz, item.gz.ld, N, V, K,
+                        item.mean, item.rstd, self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE,
+                        self.pview(item.gamma, self.grad), self.pview(item.beta, self.grad),
+                        self.pview(item.b, self.grad) if self.numeric_conv_bias_grad else None, 1.0, ws))
+                D, H, W = item.in_dims
+                xin = self.image if item.x is None else item.x
+                ldx = 1 if item.x is None else item.x.ld
 
-                    def conv_wgrad_call(item, xin, ldx, K, C, D, H, W):
-                        det = self._det_scratch()
-                        if not item.iso:
-                            nat.call("lnn_conv3d_wgrad_g", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
-                                     *item.kernel, *item.strides, det, 0 if det is None else det.numel())
-                        elif item.x2 is not None and det is not None:
-                            nat.call("lnn_conv3d_wgrad_cat_det", xin, at(item.x2, n0), ldx, item.x.C, at(item.y, n0), K,
-                                     self._pn(item.panel), nn, D, H, W, C, K, det, det.numel())
-                        elif item.x2 is not None:
-                            nat.call("lnn_conv3d_wgrad_cat", xin, at(item.x2, n0), ldx, item.x.C, at(item.y, n0), K,
-                                     self._pn(item.panel), nn, D, H, W, C, K)
-                        elif det is not None:
-                            nat.call("lnn_conv3d_wgrad_det", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
-                                     item.stride, det, det.numel())
-                        else:
-                            nat.call("lnn_conv3d_wgrad", xin, ldx, at(item.y, n0), K, self._pn(item.panel), nn, D, H, W, C, K,
-                                     item.stride)
-                    on_side(conv_wgrad)
-                    yield
-                    if item.first or item.gx is None:
-                        pass                                   # the first convolution has no data gradient
-                    elif not item.iso:
-                        self._probed("dgrad", item, lambda: nat.call(
-                            "lnn_conv3d_dgrad_g", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
-                            nn, D, H, W, C, K, *item.kernel, *item.strides, 1 if item.gx_accumulate else 0, splitk_ws,
-                            splitk_ws.numel()))
-                    elif (self.fuse_in_bwd_reduce and item.x_block is not None and item.stride == 1 and item.gx2 is None
-                          and not item.gx_accumulate and not self.numeric_conv_bias_grad):
-                        # dL/dz of the stage's first block AND pass 1 of its normalisation backward (ws is this lane's; nothing
-                        # between here and that block's turn in the loop uses it)
-                        xb = item.x_block
-                        self._probed("dgrad", item, lambda: nat.call(
-                            "lnn_conv3d_dgrad_in_bwd_sums", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
-                            nn, D, H, W, C, K, at(xb.y, n0), _Ptr(xb.mean, n0 * C), _Ptr(xb.rstd, n0 * C), self.pview(xb.gamma),
-                            self.pview(xb.beta), LRELU_SLOPE, self.pview(xb.gamma, self.grad), self.pview(xb.beta, self.grad), 1.0, ws,
-                            splitk_ws, splitk_ws.numel()))
-                        presummed.add(id(xb))
-                    elif item.gx2 is not None:
-                        self._probed("dgrad", item, lambda: nat.call(
-                            "lnn_conv3d_dgrad_cat", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0),
-                            at(item.gx2, n0), item.gx.ld, item.gx.C, nn, D, H, W, C, K, 1 if item.gx_accumulate else 0))
+                def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
+                    self._probed("wgrad", item, lambda: conv_wgrad_call(item, xin, ldx, K, C, D, H, W))
+                    if per_layer_unpack:
+                        unpack(item)
+
+                def conv_wgrad_call(item, xin, ldx, K, C, D, H, W):
+                    det = self._det_scratch()
+                    if not item.iso:
+                        nat.call("lnn_conv3d_wgrad_g", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K,
+                                 *item.kernel, *item.strides, det, 0 if det is None else det.numel())
+                    elif item.x2 is not None and det is not None:
+                        nat.call("lnn_conv3d_wgrad_cat_det", xin, item.x2, ldx, item.x.C, item.y, K,
+                                 self._pn(item.panel), N, D, H, W, C, K, det, det.numel())
+                    elif item.x2 is not None:
+                        nat.call("lnn_conv3d_wgrad_cat", xin, item.x2, ldx, item.x.C, item.y, K,
+                                 self._pn(item.panel), N, D, H, W, C, K)
+                    elif det is not None:
+                        nat.call("lnn_conv3d_wgrad_det", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K,
+                                 item.stride, det, det.numel())
                     else:
-                        self._probed("dgrad", item, lambda: nat.call(
-                            "lnn_conv3d_dgrad_ws", at(item.y, n0), K, self._wp(item.wp_dgrad), at(item.gx, n0), item.gx.ld,
-                            nn, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0, splitk_ws,
-                            splitk_ws.numel()))
-                else:  # UpBlock
-                    D, H, W = item.x.dims
-                    C, K = item.cin, item.cout
+                        nat.call("lnn_conv3d_wgrad", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K,
+                                 item.stride)
+                on_side(conv_wgrad, level, in_decoder)
+                if item.first or item.gx is None:
+                    pass                                   # the first convolution has no data gradient
+                elif not item.iso:
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_conv3d_dgrad_g", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
+                        N, D, H, W, C, K, *item.kernel, *item.strides, 1 if item.gx_accumulate else 0, splitk_ws,
+                        splitk_ws.numel()))
+                elif (self.fuse_in_bwd_reduce and item.x_block is not None and item.stride == 1 and item.gx2 is None
+                      and not item.gx_accumulate and not self.numeric_conv_bias_grad):
+                    # dL/dz of the stage's first block AND pass 1 of its normalisation backward (nothing between here and that
+                    # block's turn in the loop uses ws)
+                    xb = item.x_block
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_conv3d_dgrad_in_bwd_sums", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
+                        N, D, H, W, C, K, xb.y, xb.mean, xb.rstd, self.pview(xb.gamma),
+                        self.pview(xb.beta), LRELU_SLOPE, self.pview(xb.gamma, self.grad), self.pview(xb.beta, self.grad), 1.0, ws,
+                        splitk_ws, splitk_ws.numel()))
+                    presummed.add(id(xb))
+                elif item.gx2 is not None:
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_conv3d_dgrad_cat", item.y, K, self._wp(item.wp_dgrad), item.gx,
+                        item.gx2, item.gx.ld, item.gx.C, N, D, H, W, C, K, 1 if item.gx_accumulate else 0))
+                else:
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_conv3d_dgrad_ws", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
+                        N, D, H, W, C, K, item.stride, 1 if item.gx_accumulate else 0, splitk_ws,
+                        splitk_ws.numel()))
+            else:  # UpBlock
+                D, H, W = item.x.dims
+                C, K = item.cin, item.cout
 
-                    def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
-                        self._probed("wgrad", item, lambda: up_wgrad_call(item, C, K, D, H, W))
-                        if per_layer_unpack:
-                            unpack(item)
+                def up_wgrad(item=item, C=C, K=K, D=D, H=H, W=W):
+                    self._probed("wgrad", item, lambda: up_wgrad_call(item, C, K, D, H, W))
+                    if per_layer_unpack:
+                        unpack(item)
 
-                    def up_wgrad_call(item, C, K, D, H, W):
-                        det = self._det_scratch()
-                        if not item.iso:
-                            nat.call("lnn_convT3d_wgrad_g", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
-                                     self._pn(item.panel), nn, D, H, W, C, K, *item.strides, det, 0 if det is None else det.numel())
-                        elif det is not None:
-                            nat.call("lnn_convT3d_k2s2_wgrad_det", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
-                                     self._pn(item.panel), nn, D, H, W, C, K, det, det.numel())
-                        else:
-                            nat.call("lnn_convT3d_k2s2_wgrad", at(item.x, n0), item.x.ld, at(item.gy, n0), item.gy.ld,
-                                     self._pn(item.panel), nn, D, H, W, C, K)
-                    on_side(up_wgrad)
-                    yield
-                    if item.iso:
-                        self._probed("dgrad", item, lambda: nat.call(
-                            "lnn_convT3d_k2s2_dgrad_ws", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
-                            item.gx.ld, nn, D, H, W, C, K, 0, splitk_ws, splitk_ws.numel()))
+                def up_wgrad_call(item, C, K, D, H, W):
+                    det = self._det_scratch()
+                    if not item.iso:
+                        nat.call("lnn_convT3d_wgrad_g", item.x, item.x.ld, item.gy, item.gy.ld,
+                                 self._pn(item.panel), N, D, H, W, C, K, *item.strides, det, 0 if det is None else det.numel())
+                    elif det is not None:
+                        nat.call("lnn_convT3d_k2s2_wgrad_det", item.x, item.x.ld, item.gy, item.gy.ld,
+                                 self._pn(item.panel), N, D, H, W, C, K, det, det.numel())
                     else:
-                        self._probed("dgrad", item, lambda: nat.call(
-                            "lnn_convT3d_dgrad_g", at(item.gy, n0), item.gy.ld, self._wp(item.wp_dgrad), at(item.gx, n0),
-                            item.gx.ld, nn, D, H, W, C, K, *item.strides, 0, splitk_ws, splitk_ws.numel()))
-                yield
-
-        self._fork(lane)
+                        nat.call("lnn_convT3d_k2s2_wgrad", item.x, item.x.ld, item.gy, item.gy.ld,
+                                 self._pn(item.panel), N, D, H, W, C, K)
+                on_side(up_wgrad, level, in_decoder)
+                if item.iso:
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_convT3d_k2s2_dgrad_ws", item.gy, item.gy.ld, self._wp(item.wp_dgrad), item.gx,
+                        item.gx.ld, N, D, H, W, C, K, 0, splitk_ws, splitk_ws.numel()))
+                else:
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_convT3d_dgrad_g", item.gy, item.gy.ld, self._wp(item.wp_dgrad), item.gx,
+                        item.gx.ld, N, D, H, W, C, K, *item.strides, 0, splitk_ws, splitk_ws.numel()))
+        if held:
+            flush()
         if side is not None:
             main.wait_stream(side)      # every weight gradient is final before anything downstream (norm, step)
+        if side2 is not None:
+            main.wait_stream(side2)
         if not per_layer_unpack and not skip_body:
             self.unpack_wgrads()
 
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+    def _side_stream(self, i=0):
+        st = self._sides.get(i)
+        if st is None:
+            st = self._sides[i] = torch.cuda.Stream(device=self.device)
+        return st
 
     # ------------------------------------------------------------------------------------------ stats
     def flops_per_patch(self):

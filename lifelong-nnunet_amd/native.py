@@ -108,7 +108,7 @@ SIGNATURES = {
     "lnn_debug_set_v9_zseg": (_i, [_i]),
     "lnn_debug_set_gen_mode": (_i, [_i]),
     "lnn_debug_last_dgrad_reduce_fused": (_i, []),
-    "lnn_set_cu_budget": (_i, [_i]),
+    "lnn_debug_set_cu_budget": (_i, [_i]),
     # generic geometry (kernel extent 1 / 3 and stride 1 / 2 per axis; transposed convolutions with kernel == stride)
     "lnn_conv3d_fwd_g": (_i, [_p, _p, _i, _p, _p, _p, _i] + [_i] * 12 + [_p, _l]),
     "lnn_conv3d_dgrad_g": (_i, [_p, _p, _i, _p, _p, _i] + [_i] * 13 + [_p, _l]),
@@ -150,17 +150,7 @@ def _ptr(t):
     return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
 
 
-_stream_override = None      # two-lane mode: the engine names the lane's stream itself (a torch.cuda.stream() context per launch costs 10+ us)
-
-
-def set_stream_override(handle):
-    global _stream_override
-    _stream_override = handle
-
-
 def stream_handle():
-    if _stream_override is not None:
-        return _stream_override
     import torch
     return torch.cuda.current_stream().cuda_stream
 
@@ -170,7 +160,7 @@ _fn_cache = {}
 
 def call(name, *args):
     """Invoke ``lnn_<name>`` on torch's current stream; tensors (anything with ``data_ptr``) are passed as device pointers.
-    Host cost matters: a training step is ~270 calls (540 in two-lane mode) and must stay ahead of the GPU."""
+    Host cost matters: a training step is ~270 calls and must stay ahead of the GPU."""
     fn = _fn_cache.get(name)
     if fn is None:
         fn = _fn_cache[name] = getattr(lib(), name)

@@ -1,0 +1,173 @@
+"""CPU dry run of the engine's launch plan: the C-ABI calls of one forward / backward are RECORDED instead of launched (the
+engine is built on CPU tensors, ``native.call`` and the HIP stream / event objects are stand-ins), so the control flow of
+``UNetEngine.forward`` / ``backward`` -- which kernel entry, which stream, in which order -- is checked without a GPU."""
+import pytest
+import torch
+
+from lifelong_nnunet_amd import engine as eng_mod
+from lifelong_nnunet_amd import native as nat
+from lifelong_nnunet_amd.engine import ConvBlock, UpBlock
+from lifelong_nnunet_amd.network import Generic_UNet
+
+
+class _FakeStream:
+    def __init__(self, name):
+        self.name = name
+        self.cuda_stream = 0
+
+    def wait_event(self, ev):
+        _REC.append(("wait_event", self.name, ev.stream))
+
+    def wait_stream(self, other):
+        _REC.append(("wait_stream", self.name, other.name))
+
+
+class _FakeEvent:
+    def __init__(self, *a, **k):
+        self.stream = None
+
+    def record(self, stream=None):
+        self.stream = (stream or _CUR[-1]).name
+
+
+class _StreamCtx:
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        _CUR.append(self.s)
+
+    def __exit__(self, *a):
+        _CUR.pop()
+
+
+_REC = []
+_CUR = [_FakeStream("main")]
+_NSTREAMS = [0]
+
+
+@pytest.fixture
+def dry(monkeypatch):
+    _REC.clear()
+    del _CUR[1:]
+    _NSTREAMS[0] = 0
+
+    def new_stream(device=None):
+        _NSTREAMS[0] += 1
+        return _FakeStream(f"side{_NSTREAMS[0]}")
+
+    def fake_call(name, *args):
+        _REC.append(("call", name, _CUR[-1].name, args))
+
+    monkeypatch.setattr(nat, "call", fake_call)
+    monkeypatch.setattr(nat, "call_plain", lambda name, *a: _REC.append(("plain", name, a)))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _CUR[-1])
+    monkeypatch.setattr(torch.cuda, "Stream", new_stream)
+    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: _StreamCtx(s))
+    return _REC
+
+
+def _engine(num_pool=3, patch=(16, 16, 16), defer=None):
+    net = Generic_UNet(1, 8, 3, num_pool, patch_size=patch, batch_size=2, device='cpu')
+    eng = net.engine_for(torch.zeros((2, 1) + patch))
+    eng._defer = defer
+    return net, eng
+
+
+def _calls(rec, prefix=None):
+    return [r for r in rec if r[0] == "call" and (prefix is None or r[1].startswith(prefix))]
+
+
+def test_forward_writes_no_normalised_tensor_for_the_last_block_and_materialises_it_on_demand(dry):
+    net, eng = _engine()
+    x = torch.zeros(2, 1, 16, 16, 16)
+    logits = eng.forward(x)
+    assert len(logits) == 3
+    segf = _calls(dry, "lnn_instnorm_lrelu_seg_fwd")
+    assert len(segf) == 3                                   # one fused normalise + head pass per decoder level
+    top = eng.segs[-1].x_block
+    zs = [c[3][1] for c in segf]                            # the z argument
+    assert zs[-1] is None and all(z is not None for z in zs[:-1]) and not eng._top_z_valid
+    # the plain normalisation pass never targets the top block in a training forward
+    assert all(c[3][0] is not top.y for c in _calls(dry, "lnn_instnorm_lrelu_fwd"))
+    # a second head evaluated on the stored body activations (LwF / multi-head validation) reads z: produced first, once
+    dry.clear()
+    w = [torch.zeros(3, s.cin, 1, 1, 1) for s in eng.segs]
+    eng.forward(x, seg_weights=w, body=False)
+    names = [c[1] for c in _calls(dry)]
+    assert names.count("lnn_instnorm_lrelu_fwd") == 1 and names.count("lnn_seg1x1_fwd") == 3
+    assert names.index("lnn_instnorm_lrelu_fwd") < len(names) - 1 - names[::-1].index("lnn_seg1x1_fwd")
+    mat = _calls(dry, "lnn_instnorm_lrelu_fwd")[0]
+    assert mat[3][0] is top.y and mat[3][1] is top.z and eng._top_z_valid
+    dry.clear()
+    eng.forward(x, seg_weights=w, body=False)
+    assert not _calls(dry, "lnn_instnorm_lrelu_fwd")
+    # a forward with explicit head weights takes the unfused path and writes z itself
+    dry.clear()
+    eng.forward(x, seg_weights=w, body=True)
+    assert eng._top_z_valid and not _calls(dry, "lnn_instnorm_lrelu_seg_fwd")
+    eng.lazy_top_z = False
+    dry.clear()
+    eng.forward(x)
+    assert _calls(dry, "lnn_instnorm_lrelu_seg_fwd")[-1][3][1] is top.z and eng._top_z_valid
+
+
+def _wgrads(rec):
+    return [c for c in _calls(rec) if "wgrad" in c[1] and "unpack" not in c[1]]
+
+
+@pytest.mark.parametrize("defer", [None, (0, 2), (1, 2), (1, 3), (0, 5), (1, 2, 128)])
+def test_backward_launches_every_weight_gradient_once_whatever_the_schedule(dry, defer):
+    net, eng = _engine(defer=defer)
+    x = torch.zeros(2, 1, 16, 16, 16)
+    logits = eng.forward(x)
+    dry.clear()
+    dls = [None] + [torch.zeros_like(l) for l in logits[1:]]
+    eng.backward(dls)
+    wg = _wgrads(dry)
+    nlayers = sum(isinstance(i, (ConvBlock, UpBlock)) for i in eng.order)
+    assert len(wg) == nlayers
+    assert len({id(c[3][[j for j, a in enumerate(c[3]) if isinstance(a, eng_mod._Ptr)][0]].t) for c in wg}) == 1      # all into the one panel arena
+    panels = sorted(c[3][[j for j, a in enumerate(c[3]) if isinstance(a, eng_mod._Ptr)][0]].off for c in wg)
+    assert panels == sorted(i.panel for i in eng.order if isinstance(i, (ConvBlock, UpBlock)))
+    assert all(c[2] != "main" for c in wg)                  # weight gradients never run on the main stream of the default plan
+    # nothing but weight gradients on the side streams; the main stream joins every side stream before the batched unpack
+    side_calls = [c for c in _calls(dry) if c[2] != "main"]
+    assert all("wgrad" in c[1] for c in side_calls)
+    joins = {r[2] for r in dry if r[0] == "wait_stream" and r[1] == "main"}
+    assert joins == {c[2] for c in wg}
+    last_join = max(i for i, r in enumerate(dry) if r[0] == "wait_stream")
+    unpack = [i for i, r in enumerate(dry) if r[0] == "call" and r[1] == "lnn_unpack_wgrad_batched"]
+    assert len(unpack) == 1 and unpack[0] > last_join
+    if defer is None:
+        assert {c[2] for c in wg} == {"side1"}
+        return
+    # deferred: the decoder's weight gradients of levels <= defer[0] run on the second side stream, enqueued after the main
+    # stream has reached decoder level defer[1] (or left the decoder), in their original order; everything else as before
+    held = [c for c in wg if c[2] == "side2"]
+    lv = {i.panel: eng._level[id(i)] for i in eng.order if isinstance(i, (ConvBlock, UpBlock))}
+    dec = {i.panel for i in eng.order if isinstance(i, (ConvBlock, UpBlock)) and not i.prefix.startswith("conv_blocks_context")}
+    pan = lambda c: c[3][[j for j, a in enumerate(c[3]) if isinstance(a, eng_mod._Ptr)][0]].off
+    expect = [i.panel for i in reversed(eng.order) if isinstance(i, (ConvBlock, UpBlock)) and i.panel in dec and lv[i.panel] <= defer[0]]
+    assert [pan(c) for c in held] == expect and len(held) > 0
+    first_held = min(i for i, r in enumerate(dry) if r[0] == "call" and r[2] == "side2")
+    # every main-stream launch of the decoder levels above the flush level precedes the first deferred launch
+    main_before = [r for r in dry[:first_held] if r[0] == "call" and r[2] == "main"]
+    assert len(main_before) > 0
+    if len(defer) > 2:
+        plain = [r for r in dry if r[0] == "plain"]
+        assert [r[2] for r in plain] == [(defer[2],), (0,)]
+    # each deferred launch waits for the event recorded on main when its dL/dy became final
+    waits = [r for r in dry if r[0] == "wait_event" and r[1] == "side2"]
+    assert len(waits) == len(held) and all(r[2] == "main" for r in waits)
+
+
+def test_backward_without_overlap_runs_on_one_stream(dry):
+    net, eng = _engine(defer=(1, 2))
+    eng.overlap_wgrad = False
+    x = torch.zeros(2, 1, 16, 16, 16)
+    logits = eng.forward(x)
+    dry.clear()
+    eng.backward([None] + [torch.zeros_like(l) for l in logits[1:]])
+    assert {c[2] for c in _calls(dry)} == {"main"} and not [r for r in dry if r[0].startswith("wait")]

@@ -2,7 +2,7 @@
 """Host-side cost of ENQUEUEING one C2 training step: the trainer runs with every C-ABI launch replaced by a no-op (torch's own
 small ops still run), so what is timed is Python + ctypes argument marshalling + torch glue -- the time the host needs per step
 whatever the GPU does.  A step is GPU-bound only while this stays below the GPU's step time.
-    python tools/host_overhead.py            (LNN_SAMPLE_LANES=1 for the two-lane mode)"""
+    python tools/host_overhead.py"""
 import os
 import sys
 import time
@@ -44,5 +44,5 @@ for _ in range(10):
 torch.cuda.synchronize()
 host = (time.perf_counter() - t0) / 10
 nat.call = orig
-print(f"lanes={os.environ.get('LNN_SAMPLE_LANES', '0')}: real step {real * 1e3:.2f} ms | host-only (launches stubbed) {host * 1e3:.2f} ms "
+print(f"real step {real * 1e3:.2f} ms | host-only (launches stubbed) {host * 1e3:.2f} ms "
       f"for {count[0] / 10:.0f} C-ABI calls per step = {host / (count[0] / 10) * 1e6:.1f} us per call")
