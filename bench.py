@@ -337,7 +337,8 @@ def regulariser_parity(tr, ext):
         keep = arena.grad.clone()
         arena.grad.zero_()
         tr.loss.update_network_params(iter(named))
-        pen = tr.loss._regulariser(tr.loss.ewc_lambda)
+        zero = torch.zeros((), device=arena.theta.device, requires_grad=True)     # the penalty alone: base loss 0
+        pen = tr.loss._regularised(zero, tr.loss.ewc_lambda)
         pen.backward()
         torch.cuda.synchronize()
         v_hip, g_hip = float(pen), float(arena.grad.double().norm())
@@ -365,6 +366,56 @@ def regulariser_parity(tr, ext):
                         "oracle.losses.lwf_distillation (CPU fp32)" % (T, "x".join(map(str, pred.shape))),
                 "kl_hip": v_hip, "kl_oracle": v_ref, "rel_err": rv, "gates": {"rel_err<=1e-4": rv <= 1e-4}}
     return None
+
+
+def iteration_parity(tr, ext, plans):
+    """Bench-size gate on the FULL loss of the continual-learning iteration (relative loss error <= 1e-4 beside
+    the c3 / c4 / c5 timings): one full-size patch (B = 1) of the trainer's own resident batches through the fp16 MFMA engine with
+    the trainer's weights after the timed steps and through the TRAINER'S loss object -- Dice+CE over the deep-supervision levels
+    + the live EWC penalty (deep_supervision.py:58-83) or + the LwF distillation KL of the stored logits pair
+    (deep_supervision.py:185-214) -- against the oracle's CPU fp32 forward of the same network on the same patch + the oracle's
+    restatement of the same terms."""
+    import torch
+    from oracle import losses as ol, train as otrain
+    from oracle.unet import OracleGenericUNet
+    batch = tr.tr_gen.items[0]
+    data = batch["data"][:1].float()
+    tgts = [t[:1].float() for t in batch["target"]]
+    K, npool = plans["num_classes"], plans["num_pool"]
+    dev = tr.network.device_
+    named = list(tr.network.named_parameters())
+    with torch.no_grad():
+        tr.network.eval()
+        out_g = tr.network(data.to(dev))
+        if ext in ("ewc", "rehearsal_ewc"):
+            tr.loss.update_network_params(iter(named))
+            loss_g = float(tr.loss(out_g, [t.to(dev) for t in tgts]))
+            tr.loss.update_network_params(tr.network.named_parameters())
+        else:
+            loss_g = float(tr.LwFloss(out_g, [t.to(dev) for t in tgts]))
+        tr.network.train()
+    del out_g
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    net = OracleGenericUNet(1, plans["base_num_features"], K, npool)
+    net.load_state_dict({k: v.detach().float().cpu() for k, v in tr.network.state_dict().items()})
+    with torch.no_grad():
+        out_o = net(data.cpu())
+        base = ol.multiple_output_loss(out_o, [t.cpu() for t in tgts], ol.ds_loss_weights(npool))
+        if ext in ("ewc", "rehearsal_ewc"):
+            cpu = [(n, p.detach().cpu()) for n, p in named]
+            fisher = {t: {n: v.detach().float().cpu() for n, v in d.items()} for t, d in tr.fisher.items()}
+            stars = {t: {n: v.detach().float().cpu() for n, v in d.items()} for t, d in tr.params.items()}
+            loss_o = float(base + ol.ewc_penalty(cpu, fisher, stars, tr.loss.ewc_lambda, first_task_only=True))
+            what = "Dice+CE over the deep-supervision levels + the EWC penalty of the first previous task"
+        else:
+            preds = [p.detach().float().cpu() for p in tr.LwFloss.pred_logits]
+            teach = [t.detach().float().cpu() for t in tr.LwFloss.target_logits]
+            loss_o = float(otrain.lwf_loss_value(base, preds, teach, tr.LwFloss.lwf_temperature))
+            what = "Dice+CE over the deep-supervision levels + the distillation KL of the last iteration's logits pair(s)"
+    rel = abs(loss_g - loss_o) / max(abs(loss_o), 1e-30)
+    return {"what": what + ": ONE %s patch (B = 1), the trainer's weights after the timed steps, fp16 MFMA engine + the trainer's "
+                           "loss object vs the oracle's CPU fp32 forward + restated terms" % "x".join(map(str, data.shape[2:])),
+            "loss_hip": loss_g, "loss_oracle": loss_o, "loss_rel_err": rel, "gates": {"loss_rel_err<=1e-4": rel <= 1e-4}}
 
 
 def build_trainer(workload, device, rank):
@@ -441,6 +492,10 @@ def other_workload(workload, args, device, rank):
             res["parity"] = regulariser_parity(tr, ext)
         except Exception as e:
             res["parity"] = {"error": repr(e)}
+        try:
+            res["parity"]["full_iteration"] = iteration_parity(tr, ext, plans)
+        except Exception as e:
+            res["parity"]["full_iteration"] = {"error": repr(e)}
     if ext == "lwf":          # the fix behind a flag: every head evaluated on the training batch (one batch, one body pass)
         tr.same_batch_predictions = True
         for _ in range(2):

@@ -138,6 +138,15 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
     char* const uring = exch + 2 * EXB;                       // RED: [R][8 waves][UW]
     float* const abl = reinterpret_cast<float*>(uring + R * UB);   // RED: a[32 NMB], b[32 NMB] of the item's (sample, channel block)
 
+    if constexpr (STATS || RED) {
+        // the block zeroes its own partial rows (the item epilogues below accumulate into them; rows of (sample, channel) pairs the
+        // block never visits stay zero for the finalize launch): no memset launch in front of the kernel.  Complete before the first
+        // barrier of the item loop lets another wave of the block read-modify-write a row.
+        const long astride = (long)p.stats_nblk * p.N * p.M;
+        float* const rows = p.stats_pws + (long)blockIdx.x * K::NF * p.N * p.M;
+        for (int i = threadIdx.x; i < K::NF * p.N * p.M; i += 512) { rows[i] = 0.f; rows[astride + i] = 0.f; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ck = wave % NCK, mb = (wave / NCK) % NMB, f = wave / (NCK * NMB);
@@ -514,8 +523,7 @@ int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
         attr_set = true;
     }
     if (EPI != 0) {
-        p.stats_nblk = grid * K::NF;
-        hipMemsetAsync(p.stats_pws, 0, sizeof(float) * 2 * (size_t)p.stats_nblk * p.N * p.M, s);
+        p.stats_nblk = grid * K::NF;          // (every launched block zeroes its own rows)
     }
     hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, EPI>), dim3(grid), dim3(512), lds, s, p, q);
     LNN_CHECK_LAUNCH(name);

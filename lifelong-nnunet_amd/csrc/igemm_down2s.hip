@@ -163,6 +163,15 @@ __global__ __launch_bounds__(512, 2) void igemm_down2s_kernel(const ConvParams p
     const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     const int xcd = blockIdx.x & 7, cu_slot = blockIdx.x >> 3;
+    if constexpr (STATS) {
+        // the block zeroes its own partial rows (the item epilogues below accumulate into them; rows of (sample, channel) pairs the
+        // block never visits stay zero for the finalize launch): no memset launch in front of the kernel.  Complete before the first
+        // barrier of the item loop lets another wave of the block read-modify-write a row.
+        const long astride = (long)p.stats_nblk * p.N * p.M;
+        float* const rows = p.stats_pws + (long)blockIdx.x * K::NF * p.N * p.M;
+        for (int i = threadIdx.x; i < K::NF * p.N * p.M; i += 512) { rows[i] = 0.f; rows[astride + i] = 0.f; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
 #pragma unroll 1
     for (int round = 0;; ++round) {
@@ -411,8 +420,7 @@ int launch_d2(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
         attr_set = true;
     }
     if (STATS) {
-        p.stats_nblk = grid * K::NF;
-        hipMemsetAsync(p.stats_pws, 0, sizeof(float) * 2 * (size_t)p.stats_nblk * p.N * p.M, s);
+        p.stats_nblk = grid * K::NF;          // (every launched block zeroes its own rows)
     }
     hipLaunchKernelGGL((igemm_down2s_kernel<K::NCK, K::NMB, K::NF, K::EXT, STATS>), dim3(grid), dim3(512), K::LDS, s, p, q);
     LNN_CHECK_LAUNCH(name);

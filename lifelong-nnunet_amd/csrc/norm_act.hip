@@ -240,24 +240,27 @@ __global__ __launch_bounds__(NT) void in_lrelu_fwd_kernel(const half_t* __restri
 // STAGED (C in [32, 512], V % 4 == 0; A/B variant, off by default): the K logits of the UNR * VPB consecutive voxels a block
 // handles per trip go through LDS and leave as 16-byte stores of complete runs instead of 64-byte pieces per wave-wide store.
 constexpr int SEG_KMAX = 8;
-template <bool STAGED>
+// KT: compile-time K (1..4: the runtime bound made every one of the 8 x SEG_KMAX products of a channel octet a scalar branch, the
+// kernel ran at 1.7 TB/s of reads with or without its store of z), 0 = runtime K <= SEG_KMAX.
+template <bool STAGED, int KT>
 __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __restrict__ y, half_t* __restrict__ z, int ld_z,
                                                               long V, int C, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float slope,
                                                               const float* __restrict__ segw, float* __restrict__ logits, int K) {
+    constexpr int KB = KT > 0 ? KT : SEG_KMAX;
     __shared__ __attribute__((aligned(16))) float lg[STAGED ? 2 * SEG_KMAX * UNR * 64 : 4];
     const RowMap rm = row_map(C);
     if (!STAGED && !rm.active) return;                 // (STAGED: C / 8 is a power of two, every thread is active)
     const int n = blockIdx.y;
-    float sc[8], sh[8], w[SEG_KMAX][8];
+    float sc[8], sh[8], w[KB][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = rm.c8 * 8 + e;
         sc[e] = gamma[c] * rstd[n * C + c];
         sh[e] = beta[c] - mean[n * C + c] * sc[e];
 #pragma unroll
-        for (int k = 0; k < SEG_KMAX; ++k) w[k][e] = k < K ? segw[k * C + c] : 0.f;
+        for (int k = 0; k < KB; ++k) w[k][e] = k < K ? segw[k * C + c] : 0.f;
     }
     const half_t* yp = y + (long)n * V * C + rm.c8 * 8;
     half_t* zp = z + (long)n * V * ld_z + rm.c8 * 8;
@@ -266,28 +269,26 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_fwd_kernel(const half_t* __re
     // the block's range is a multiple of VPB, so all C8 lanes of a voxel are in or out together
     auto one = [&](const half8& x, long v, float* stage) {
         half8 o;
-        float pk[SEG_KMAX];
+        float pk[KB];
 #pragma unroll
-        for (int k = 0; k < SEG_KMAX; ++k) pk[k] = 0.f;
+        for (int k = 0; k < KB; ++k) pk[k] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float t = (float)x[e] * sc[e] + sh[e];
             o[e] = (half_t)(t > 0.f ? t : t * slope);
             const float zf = (float)o[e];
 #pragma unroll
-            for (int k = 0; k < SEG_KMAX; ++k)
-                if (k < K) pk[k] += zf * w[k][e];
+            for (int k = 0; k < KB; ++k) pk[k] += zf * w[k][e];           // (w is zero beyond K)
         }
         if (z) *reinterpret_cast<half8*>(zp + v * ld_z) = o;        // (kernel-uniform: z == nullptr -> logits only)
         for (int m = 1; m < rm.C8; m <<= 1) {
 #pragma unroll
-            for (int k = 0; k < SEG_KMAX; ++k)
-                if (k < K) pk[k] += __shfl_xor(pk[k], m, 64);
+            for (int k = 0; k < KB; ++k) pk[k] += __shfl_xor(pk[k], m, 64);
         }
         if (rm.c8 == 0) {
 #pragma unroll
-            for (int k = 0; k < SEG_KMAX; ++k)
-                if (k < K) {
+            for (int k = 0; k < KB; ++k)
+                if (KT > 0 || k < K) {
                     if (stage) stage[k * (UNR * 64)] = pk[k];
                     else ln[(long)k * V + v] = pk[k];
                 }
@@ -843,10 +844,15 @@ extern "C" int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s_, const void* y, void* 
     static int want_staged = -1;
     if (want_staged < 0) { const char* e = getenv("LNN_SEG_FWD_STAGED"); want_staged = (e && e[0] == '1') ? 1 : 0; }
     const bool staged = want_staged && C8 >= 4 && (V & 3) == 0 && lnn_aligned16(logits);
-    if (staged) hipLaunchKernelGGL((in_lrelu_seg_fwd_kernel<true>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z,
-                                   ld_z, V, C, mean, rstd, gamma, beta, slope, seg_w, logits, K);
-    else hipLaunchKernelGGL((in_lrelu_seg_fwd_kernel<false>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, (half_t*)z,
-                            ld_z, V, C, mean, rstd, gamma, beta, slope, seg_w, logits, K);
+#define LNN_SF(ST, KT) hipLaunchKernelGGL((in_lrelu_seg_fwd_kernel<ST, KT>), dim3(blocks_for(V, C), N), dim3(NT), 0, s, (const half_t*)y, \
+                                         (half_t*)z, ld_z, V, C, mean, rstd, gamma, beta, slope, seg_w, logits, K)
+    if (staged) LNN_SF(true, 0);
+    else if (K == 1) LNN_SF(false, 1);
+    else if (K == 2) LNN_SF(false, 2);
+    else if (K == 3) LNN_SF(false, 3);
+    else if (K == 4) LNN_SF(false, 4);
+    else LNN_SF(false, 0);
+#undef LNN_SF
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_seg_fwd");
     return LNN_OK;
 }

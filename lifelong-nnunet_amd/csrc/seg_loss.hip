@@ -38,6 +38,52 @@ __global__ __launch_bounds__(NT) void seg_fwd_kernel(const half_t* __restrict__ 
     }
 }
 
+// The same head with thread = (voxel, channel octet): the C/8 octets of a voxel are adjacent lanes of ONE wave (a group of G = the next
+// power of two >= C/8 lanes, 64 / G voxels per wave and pass), every lane loads 16 bytes (a voxel's channels are one contiguous run),
+// holds the K x 8 weights of its octet in registers and a butterfly over the group sums the K logits.  The voxel-per-thread kernel
+// above walks a voxel's channels in a dependent loop of strided 16-byte loads: on the low-resolution heads (320 channels x 1200
+// voxels) that is 40 round trips on ONE block per sample -- 92 us for 2 MFLOP (profiles/r05_step_timeline_before.txt); this one
+// spreads the (sample, voxel) pairs over the chip.  KT: compile-time K (1..4), 0 = runtime K <= KMAX.  C <= 512.
+template <int KT>
+__global__ __launch_bounds__(NT) void seg_fwd_wave_kernel(const half_t* __restrict__ z, int ld_z, const float* __restrict__ w,
+                                                          float* __restrict__ logits, long V, long NV, int C, int K, int G) {
+    constexpr int KB = KT > 0 ? KT : KMAX;
+    const int lane = threadIdx.x & 63, o = lane & (G - 1), g = lane / G, vpw = 64 / G, C8 = C >> 3;
+    const bool act = o < C8;
+    float wr[KB][8];
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[k][e] = (act && k < K) ? w[(long)k * C + o * 8 + e] : 0.f;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = (long)gridDim.x * (NT / 64);
+    for (long base = wave * vpw; base < NV; base += nwaves * vpw) {
+        const long nv = base + g;                           // (sample, voxel) pair of this lane's group
+        const bool ok = act && nv < NV;
+        float acc[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) acc[k] = 0.f;
+        if (ok) {
+            const half8 x = *reinterpret_cast<const half8*>(z + nv * ld_z + o * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float zf = (float)x[e];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) acc[k] = __builtin_fmaf(zf, wr[k][e], acc[k]);
+            }
+        }
+        for (int m = 1; m < G; m <<= 1) {
+#pragma unroll
+            for (int k = 0; k < KB; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
+        }
+        if (o == 0 && nv < NV) {
+            const long n = nv / V, v = nv - n * V;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k < K) logits[((long)n * K + k) * V + v] = acc[k];
+        }
+    }
+}
+
 // thread = (voxel lane, channel octet): dz = sum_k dl[k] w[k][c]; dw[k][c] partials in registers.
 template <int KG>
 __global__ __launch_bounds__(NT) void seg_bwd_kernel(const half_t* __restrict__ z, int ld_z, const float* __restrict__ w,
@@ -671,6 +717,19 @@ extern "C" int lnn_seg1x1_fwd(lnn_stream_t s_, const void* z, int ld_z, const fl
     LNN_REQUIRE(z && lnn_aligned16(z) && w && logits, "lnn_seg1x1_fwd: null/misaligned pointer");
     LNN_REQUIRE(C % 8 == 0 && ld_z >= C && ld_z % 8 == 0, "lnn_seg1x1_fwd: bad channel count / ld");
     LNN_REQUIRE(K >= 1 && K <= KMAX, "lnn_seg1x1_fwd: K=%d unsupported (max %d)", K, KMAX);
+    if (C <= 512) {
+        int G = 1;
+        while (G < C / 8) G <<= 1;
+        const long NV = (long)N * V, waves = (NV + 64 / G - 1) / (64 / G);
+        long blocks = (waves + NT / 64 - 1) / (NT / 64);
+        if (blocks > 2048) blocks = 2048;
+#define LNN_SEGW(KT) hipLaunchKernelGGL((seg_fwd_wave_kernel<KT>), dim3((unsigned)blocks), dim3(NT), 0, s, (const half_t*)z, ld_z, w, \
+                                        logits, V, NV, C, K, G)
+        if (K == 1) LNN_SEGW(1); else if (K == 2) LNN_SEGW(2); else if (K == 3) LNN_SEGW(3); else if (K == 4) LNN_SEGW(4); else LNN_SEGW(0);
+#undef LNN_SEGW
+        LNN_CHECK_LAUNCH("lnn_seg1x1_fwd(wave)");
+        return LNN_OK;
+    }
     hipLaunchKernelGGL(seg_fwd_kernel, dim3(vox_blocks(V), N), dim3(NT), (size_t)K * C * sizeof(float), s,
                        (const half_t*)z, ld_z, w, logits, V, C, K);
     LNN_CHECK_LAUNCH("lnn_seg1x1_fwd");

@@ -350,14 +350,6 @@ class UNetEngine:
             order.append(seg)
             x, gx, cdown = b1.z, b1.gz, cs
         self.order = order
-        # resolution level of every item (0 = full resolution; a transposed convolution counts at the level it writes)
-        self._level = {}
-        for item in order:
-            pre = item.prefix.split(".")
-            if pre[0] == "conv_blocks_context":
-                self._level[id(item)] = int(pre[1])
-            else:                       # conv_blocks_localization.u / tu.u / seg_outputs.u sit at encoder depth num_pool - 1 - u
-                self._level[id(item)] = num_pool - 1 - int(pre[1])
         # decoder blocks whose output feeds a seg head directly (the head follows its block in execution order)
         self._seg_after = {id(seg.x_block): seg for seg in self.segs}
 
@@ -458,8 +450,7 @@ class UNetEngine:
         self.unused_heads: List[str] = []
         self._sides = {}
         # A/B switches of round 5 (measurements only; see backward / forward)
-        d = os.environ.get("LNN_WGRAD_DEFER", "")
-        self._defer = tuple(int(v) for v in d.split(",")) if d else None
+        self.c1_wgrad_stream = os.environ.get("LNN_NO_C1_WGRAD_STREAM", "0") != "1"
         self.lazy_top_z = os.environ.get("LNN_NO_LAZY_TOP_Z", "0") != "1"
         self._top_block = self.segs[-1].x_block
         self._top_z_valid = False
@@ -684,40 +675,24 @@ class UNetEngine:
         # gradient arena there too, and the all-reduce of every bucket that became final is launched FROM the side stream
         # (parallel.GradAllReducer.progress): two streams share the chip, as in the single-GPU plan
         side = self._side_stream() if self.overlap_wgrad else None
-        # Deferred weight gradients (LNN_WGRAD_DEFER="L,F", measurement switch): the weight gradients of the decoder levels <= L
-        # (the big MFMA-bound launches at the start of backward) are held back and released on a SECOND side stream when the
-        # main stream reaches decoder level F -- next to the latency-bound kernels of the bottom of the U instead of next to the
-        # MFMA-bound data gradients of their own level
-        defer = self._defer if (side is not None and progress is None and not self.deterministic_wgrad) else None
-        side2 = self._side_stream(1) if defer is not None else None
-        held = []
+        # The first layer's weight gradient (HBM-bound: it streams dL/dz and y of the full-resolution block) gets a stream of its own:
+        # it is the last launch of backward and would otherwise queue BEHIND the MFMA-bound weight gradient of the second block
+        # while the main stream has nothing left to run (profiles/r05_step_timeline_before.txt: 0.83 ms of the step with one
+        # stream busy); side by side the two share a CU's registers and LDS (156 + 2 x 175 VGPRs per SIMD, 21 + 116 KB).  Single-GPU
+        # plan only: with the data-parallel exchange or the ordered (deterministic) reduction all weight gradients keep one stream.
+        side_c1 = self._side_stream(1) if (side is not None and self.c1_wgrad_stream and progress is None
+                                           and not self.deterministic_wgrad) else side
 
-        def on_side(fn, level=None, decoder=False):
-            if side is None:
+        def on_side(fn, st=None):
+            st = side if st is None else st
+            if st is None:
                 fn()
                 return
             ev = torch.cuda.Event()
             ev.record(main)
-            if defer is not None and decoder and level is not None and level <= defer[0] and not flushed[0]:
-                held.append((ev, fn))
-                return
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
                 fn()
-
-        flushed = [False]
-
-        def flush():
-            flushed[0] = True
-            if len(defer) > 2:
-                nat.call_plain("lnn_debug_set_cu_budget", defer[2])
-            for ev, fn in held:
-                side2.wait_event(ev)
-                with torch.cuda.stream(side2):
-                    fn()
-            if len(defer) > 2:
-                nat.call_plain("lnn_debug_set_cu_budget", 0)
-            held.clear()
 
         # the DP all-reduce overlaps with backward and needs every layer's gradient final as soon as its wgrad is:
         # per-layer unpack there; otherwise one batched unpack after the last wgrad
@@ -740,13 +715,7 @@ class UNetEngine:
         seg_u = len(self.segs)
         pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
         presummed = set()     # id(block): pass 1 of its normalisation backward was taken by the data gradient that produced its dL/dz
-        in_decoder = True
         for item in reversed(self.order):
-            level = self._level[id(item)]
-            if isinstance(item, ConvBlock) and item.prefix.startswith("conv_blocks_context"):
-                in_decoder = False
-            if defer is not None and not flushed[0] and (not in_decoder or level >= defer[1]):
-                flush()
             if progress is not None and item is not self.order[-1]:
                 # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
                 # (weight gradients + their unpack) have run what is enqueued so far; a head that was deferred into
@@ -798,7 +767,7 @@ class UNetEngine:
                                  0 if det is None else det.numel())
                         if per_layer_unpack:
                             unpack(item)
-                    on_side(lambda: self._probed("wgrad", item, first_wgrad))
+                    on_side(lambda: self._probed("wgrad", item, first_wgrad), side_c1)
                     continue
                 elif id(item) in presummed:
                     self._probed("in_bwd", item, lambda: nat.call(
@@ -836,7 +805,7 @@ class UNetEngine:
                     else:
                         nat.call("lnn_conv3d_wgrad", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K,
                                  item.stride)
-                on_side(conv_wgrad, level, in_decoder)
+                on_side(conv_wgrad)
                 if item.first or item.gx is None:
                     pass                                   # the first convolution has no data gradient
                 elif not item.iso:
@@ -884,7 +853,7 @@ class UNetEngine:
                     else:
                         nat.call("lnn_convT3d_k2s2_wgrad", item.x, item.x.ld, item.gy, item.gy.ld,
                                  self._pn(item.panel), N, D, H, W, C, K)
-                on_side(up_wgrad, level, in_decoder)
+                on_side(up_wgrad)
                 if item.iso:
                     self._probed("dgrad", item, lambda: nat.call(
                         "lnn_convT3d_k2s2_dgrad_ws", item.gy, item.gy.ld, self._wp(item.wp_dgrad), item.gx,
@@ -893,12 +862,12 @@ class UNetEngine:
                     self._probed("dgrad", item, lambda: nat.call(
                         "lnn_convT3d_dgrad_g", item.gy, item.gy.ld, self._wp(item.wp_dgrad), item.gx,
                         item.gx.ld, N, D, H, W, C, K, *item.strides, 0, splitk_ws, splitk_ws.numel()))
-        if held:
-            flush()
+        if progress is not None:
+            progress(0, side)           # the first layer's gradients are enqueued: the last bucket leaves from here too
         if side is not None:
             main.wait_stream(side)      # every weight gradient is final before anything downstream (norm, step)
-        if side2 is not None:
-            main.wait_stream(side2)
+        if side_c1 is not side:
+            main.wait_stream(side_c1)
         if not per_layer_unpack and not skip_body:
             self.unpack_wgrads()
 

@@ -154,14 +154,17 @@ class MultipleOutputLoss2(nn.Module):
 
 # ------------------------------------------------------------------------------------------------- EWC
 class _EWCPenaltyFunction(torch.autograd.Function):
-    """sum_tasks lambda/2 * sum F_t (theta - theta*_t)^2 over the flat arena; backward adds
-    g * lambda * F_t (theta - theta*_t) straight into the flat gradient arena."""
+    """base + sum_tasks lambda/2 * sum F_t (theta - theta*_t)^2 over the flat arena.  The node sits BETWEEN the segmentation
+    loss and the result -- ``base`` is its input -- so its backward is the FIRST node autograd runs: the penalty gradient
+    g * lambda * F_t (theta - theta*_t) is in the flat gradient arena before the network's backward starts, on the same
+    stream.  That order is what lets the data-parallel exchange start during backward (parallel.GradAllReducer.progress): every
+    bucket it sends already holds the penalty's share -- replica-identical, so sum / world preserves it."""
 
     @staticmethod
-    def forward(ctx, anchor, arena, fishers, stars, ewc_lambda, net=None, touched=()):
+    def forward(ctx, base, arena, fishers, stars, ewc_lambda, net=None, touched=()):
         ctx.net, ctx.touched = net, touched
         ws = torch.empty(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=arena.theta.device)
-        total = torch.zeros((), device=arena.theta.device)
+        total = base.detach().reshape(()).to(arena.theta.device, torch.float32)
         out = torch.empty(1, device=arena.theta.device)
         for f, s in zip(fishers, stars):
             nat.call("lnn_ewc_penalty_fwd", arena.theta, s, f, arena.size, float(ewc_lambda), out, ws)
@@ -171,15 +174,15 @@ class _EWCPenaltyFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        gdev = g.reshape(1).float().contiguous()
         for f, s in zip(ctx.fishers, ctx.stars):
-            nat.call("lnn_ewc_penalty_bwd", ctx.arena.theta, s, f, ctx.arena.size, ctx.lam, 1.0,
-                     g.reshape(1).float().contiguous(), ctx.arena.grad)
+            nat.call("lnn_ewc_penalty_bwd", ctx.arena.theta, s, f, ctx.arena.size, ctx.lam, 1.0, gdev, ctx.arena.grad)
         if ctx.net is not None:
             # these parameters now HAVE a gradient (torch: .grad is not None), also the zero-weight deep-supervision head
             # the network's own backward never touches: clip_grad_norm_ counts it and SGD steps it (weight decay, momentum,
             # the pull towards theta*) -- optim._ranges must not skip it
             ctx.net.penalty_grad_names = set(getattr(ctx.net, "penalty_grad_names", ())) | set(ctx.touched)
-        return None, None, None, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
 class MultipleOutputLossEWC(MultipleOutputLoss2):
@@ -223,11 +226,11 @@ class MultipleOutputLossEWC(MultipleOutputLoss2):
             self._flat[key] = (F, S)
         return self._flat[key]
 
-    def _regulariser(self, lam):
-        """sum over ``self.tasks`` of lam/2 * sum F_t (theta - theta*_t)^2, or None when nothing applies."""
+    def _regularised(self, base, lam):
+        """``base`` + sum over ``self.tasks`` of lam/2 * sum F_t (theta - theta*_t)^2 (``base`` itself when nothing applies)."""
         if len(self.tasks) == 0 or self.network_params is None:
-            return None
-        fishers, stars, arena, anchor, net, touched = [], [], None, None, None, set()
+            return base
+        fishers, stars, arena, net, touched = [], [], None, None, set()
         for task in self.tasks:
             # deep_supervision.py:65-66: the task loop is outermost and ``network_params`` is whatever the
             # trainer handed over -- a *generator* for the base EWC trainer (ewc/nnUNetTrainerEWC.py:140,247),
@@ -238,20 +241,17 @@ class MultipleOutputLossEWC(MultipleOutputLoss2):
             net = named[0][1]._lnn_net
             arena = net.arena
             touched |= {n for n, p in named if p.requires_grad and self._selected(n)}
-            anchor = next((p for _, p in named if p.requires_grad), named[0][1])
             F, S = self._flat_for(task, named, arena)
             fishers.append(F)
             stars.append(S)
         if not fishers:
-            return None
-        return _EWCPenaltyFunction.apply(anchor, arena, fishers, stars, lam, net, frozenset(touched))
+            return base
+        return _EWCPenaltyFunction.apply(base, arena, fishers, stars, lam, net, frozenset(touched))
 
     def forward(self, x, y, reg=True):
         loss = super().forward(x, y)
         if reg:
-            pen = self._regulariser(self.ewc_lambda)
-            if pen is not None:
-                loss = loss + pen
+            loss = self._regularised(loss, self.ewc_lambda)
         return loss
 
 
@@ -286,11 +286,7 @@ class MultipleOutputLossRW(MultipleOutputLossEWC):
         return self._flat[key]
 
     def forward(self, x, y):
-        loss = MultipleOutputLoss2.forward(self, x, y)
-        pen = self._regulariser(2.0 * self.ewc_lambda)
-        if pen is not None:
-            loss = loss + pen
-        return loss
+        return self._regularised(MultipleOutputLoss2.forward(self, x, y), 2.0 * self.ewc_lambda)
 
 
 # ------------------------------------------------------------------------------------------------- MiB

@@ -41,7 +41,6 @@ class GradAllReducer:
         self.stream = torch.cuda.Stream() if grad.is_cuda else None
         self.next = 0
         self._used = set()
-        self.defer = False
 
     @property
     def averaging_factor(self) -> float:
@@ -71,7 +70,7 @@ class GradAllReducer:
         and on ``stream`` has run.  ``stream``: the engine's weight-gradient side stream -- the bucket is all-reduced
         FROM that stream (after an event of the current one), so the exchange queues behind the weight gradients it
         needs and no third stream competes with the two that already share the chip."""
-        if not self.overlap or self.defer:
+        if not self.overlap:
             return
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= watermark:
             self._launch(*self.buckets[self.next], stream=stream)

@@ -46,8 +46,6 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
         self.loss = DC_and_CE_loss({'batch_dice': self.batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})
         self.loss = EWCLoss(self.loss, self.ds_loss_weights, self.ewc_lambda, self.fisher, self.params,
                             self.network.named_parameters())
-        if self.dp is not None:
-            self.dp.defer = True      # the penalty's gradient is added by a separate autograd node
 
     def reinitialize(self, task, print_loss_info=True):
         super().reinitialize(task, print_loss_info)

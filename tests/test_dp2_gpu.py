@@ -2,7 +2,8 @@
 device tensors by staging them through host memory), running the HIP trainers data-parallel (SURVEY.md 8e "Verification":
 N ranks on shards == 1 rank on the concatenated batch).  Covered with two ranks: ``engine.backward(progress=)`` with the
 watermark-driven bucket launches, the gradient average folded into the optimiser, the global-norm clip after the exchange,
-``batch_dice=True`` (tp/fp/fn exchange inside the loss), the EWC trainer's deferred exchange, its parity-mode Fisher
+``batch_dice=True`` (tp/fp/fn exchange inside the loss), the EWC trainer with a LIVE penalty of a previous task (its gradient is
+in the arena before the network's backward starts, so the exchange overlaps backward like the plain trainer's), its parity-mode Fisher
 (square of the ALL-REDUCED gradient) and ``fisher_mode='accumulate'`` (Fisher arenas all-reduced once per task).
 RCCL itself (``nccl`` backend) needs one device per rank: it is exercised at world size 1 in tests/test_dp_gpu.py and by
 the driver's multi-GPU bench."""
@@ -74,6 +75,15 @@ def _worker(rank, world, port, out):
         dist.broadcast_object_list(sd, src=0)                                   # same initial weights on every rank
         dp.network.load_state_dict(sd[0])
         dp.mh_network.update_after_iteration()
+        if ext == "ewc":
+            # a previous task "P" with a Fisher and anchor parameters (same numbers on every rank and on the reference): the penalty
+            # lambda/2 sum F (theta - theta*)^2 is live in every iteration below
+            gen = torch.Generator().manual_seed(11)
+            fi = {n: torch.rand(p.shape, generator=gen).to(DEV) for n, p in dp.network.named_parameters()}
+            st = {n: (sd[0][n].cpu() + 0.05 * torch.randn(p.shape, generator=gen)).to(DEV) for n, p in dp.network.named_parameters()}
+            dp.fisher["P"], dp.params["P"] = fi, st
+            dp.loss.update_ewc_params(dp.fisher, dp.params)
+            dp.loss.update_network_params(dp.network.named_parameters())
         launches = []
         orig = dp.dp._launch
         dp.dp._launch = lambda lo, hi, stream=None: (launches.append((lo, hi, stream is not None)), orig(lo, hi, stream))[1]
@@ -86,16 +96,22 @@ def _worker(rank, world, port, out):
             assert ref.dp is None
             ref.network.load_state_dict(sd[0])
             ref.mh_network.update_after_iteration()
+            if ext == "ewc":
+                ref.fisher["P"], ref.params["P"] = fi, st
+                ref.loss.update_ewc_params(ref.fisher, ref.params)
+                ref.loss.update_network_params(ref.network.named_parameters())
         ldp, lref = [], []
         for b in full[:2]:
             ldp.append(float(dp.run_iteration(iter([_shard(b, rank, 2)]), True)))
             if ref is not None:
                 lref.append(float(ref.run_iteration(iter([b]), True)))
         key = f"{ext}_bd{int(bd)}"
-        # every bucket exactly once per step, tail-first; with the deferred exchange (EWC) all of them after backward
+        # every bucket exactly once per step, tail-first, and every one of them launched from inside backward (progress), none
+        # left for finish() -- also with the EWC penalty live
         n_b = len(dp.dp.buckets)
         assert [l[:2] for l in launches[:n_b]] == dp.dp.buckets and len(launches) == 2 * n_b
         res[key + "_during_backward"] = sum(l[2] for l in launches)
+        res[key + "_launches"] = len(launches)
         th = dp.network.arena.theta.clone()
         gath = [torch.zeros_like(th) for _ in range(world)]
         dist.all_gather(gath, th)
@@ -109,6 +125,16 @@ def _worker(rank, world, port, out):
         if rank == 0:
             res[key + "_loss"] = max(abs(float(a) / world - b) / abs(b) for a, b in zip(lt, lref))
         if ext == "ewc":
+            if rank == 0:
+                zero = torch.zeros((), device=DEV, requires_grad=True)
+                ref.loss.update_network_params(ref.network.named_parameters())
+                res["ewc_penalty_live"] = float(ref.loss._regularised(zero, ref.loss.ewc_lambda).detach())
+                ref.loss.update_network_params(ref.network.named_parameters())
+            del dp.fisher["P"], dp.params["P"]                  # the Fisher checks below are those of a first task
+            dp.loss.update_ewc_params(dp.fisher, dp.params)
+            if rank == 0:
+                del ref.fisher["P"], ref.params["P"]
+                ref.loss.update_ewc_params(ref.fisher, ref.params)
             # parity-mode Fisher = square of the averaged gradient of the last after_train batch (EWC.py:252-310)
             dp.num_batches_per_epoch = 2
             dp.fisher["A"], dp.params["A"] = {}, {}
@@ -165,6 +191,7 @@ def test_two_ranks_on_one_gpu_match_the_single_rank_step():
         assert out[key + "_loss"] < 1e-4, (key, out)
         assert out[key + "_theta"] < 2e-5, (key, out)            # fp16 runs: order of the weight-gradient atomics / of the rank sum
         assert out[key + "_norm"] < 1e-3, (key, out)
-    assert out["sequential_bd0_during_backward"] > 0 and out["sequential_bd1_during_backward"] > 0
-    assert out["ewc_bd0_during_backward"] == 0                   # deferred: the penalty's autograd node adds to the arena after backward
+    for key in ("sequential_bd0", "sequential_bd1", "ewc_bd0"):
+        assert out[key + "_during_backward"] == out[key + "_launches"] > 0, (key, out)     # overlapped, also with the EWC penalty live
+    assert out["ewc_penalty_live"] > 0
     assert out["ewc_fisher_last_batch"] < 2e-2 and out["ewc_fisher_accumulate"] < 1e-4, out

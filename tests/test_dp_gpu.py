@@ -90,7 +90,7 @@ def test_forced_dp_step_equals_plain_step(nccl_world1):
     # buckets that became final during backward were launched from the engine's weight-gradient side stream
     eng = list(dp.network._engines.values())[0]
     during = [e for e in log if e[0] == "ar" and e[3] is not None]
-    assert during and all(e[3] is eng._side for e in during)
+    assert during and all(e[3] is eng._sides[0] for e in during)
 
 
 def test_batch_dice_and_accumulated_fisher_through_forced_dp(nccl_world1):

@@ -68,10 +68,9 @@ def dry(monkeypatch):
     return _REC
 
 
-def _engine(num_pool=3, patch=(16, 16, 16), defer=None):
+def _engine(num_pool=3, patch=(16, 16, 16)):
     net = Generic_UNet(1, 8, 3, num_pool, patch_size=patch, batch_size=2, device='cpu')
     eng = net.engine_for(torch.zeros((2, 1) + patch))
-    eng._defer = defer
     return net, eng
 
 
@@ -117,20 +116,21 @@ def _wgrads(rec):
     return [c for c in _calls(rec) if "wgrad" in c[1] and "unpack" not in c[1]]
 
 
-@pytest.mark.parametrize("defer", [None, (0, 2), (1, 2), (1, 3), (0, 5), (1, 2, 128)])
-def test_backward_launches_every_weight_gradient_once_whatever_the_schedule(dry, defer):
-    net, eng = _engine(defer=defer)
+@pytest.mark.parametrize("own_stream", [True, False])
+def test_backward_launches_every_weight_gradient_once(dry, own_stream):
+    net, eng = _engine()
+    eng.c1_wgrad_stream = own_stream
     x = torch.zeros(2, 1, 16, 16, 16)
     logits = eng.forward(x)
     dry.clear()
     dls = [None] + [torch.zeros_like(l) for l in logits[1:]]
     eng.backward(dls)
     wg = _wgrads(dry)
-    nlayers = sum(isinstance(i, (ConvBlock, UpBlock)) for i in eng.order)
-    assert len(wg) == nlayers
-    assert len({id(c[3][[j for j, a in enumerate(c[3]) if isinstance(a, eng_mod._Ptr)][0]].t) for c in wg}) == 1      # all into the one panel arena
-    panels = sorted(c[3][[j for j, a in enumerate(c[3]) if isinstance(a, eng_mod._Ptr)][0]].off for c in wg)
-    assert panels == sorted(i.panel for i in eng.order if isinstance(i, (ConvBlock, UpBlock)))
+    layers = [i for i in eng.order if isinstance(i, (ConvBlock, UpBlock))]
+    pan = lambda c: c[3][[j for j, a in enumerate(c[3]) if isinstance(a, eng_mod._Ptr)][0]]
+    assert len(wg) == len(layers)
+    assert len({id(pan(c).t) for c in wg}) == 1                                  # all into the one panel arena
+    assert sorted(pan(c).off for c in wg) == sorted(i.panel for i in layers)     # every layer's panel exactly once
     assert all(c[2] != "main" for c in wg)                  # weight gradients never run on the main stream of the default plan
     # nothing but weight gradients on the side streams; the main stream joins every side stream before the batched unpack
     side_calls = [c for c in _calls(dry) if c[2] != "main"]
@@ -140,34 +140,43 @@ def test_backward_launches_every_weight_gradient_once_whatever_the_schedule(dry,
     last_join = max(i for i, r in enumerate(dry) if r[0] == "wait_stream")
     unpack = [i for i, r in enumerate(dry) if r[0] == "call" and r[1] == "lnn_unpack_wgrad_batched"]
     assert len(unpack) == 1 and unpack[0] > last_join
-    if defer is None:
-        assert {c[2] for c in wg} == {"side1"}
-        return
-    # deferred: the decoder's weight gradients of levels <= defer[0] run on the second side stream, enqueued after the main
-    # stream has reached decoder level defer[1] (or left the decoder), in their original order; everything else as before
-    held = [c for c in wg if c[2] == "side2"]
-    lv = {i.panel: eng._level[id(i)] for i in eng.order if isinstance(i, (ConvBlock, UpBlock))}
-    dec = {i.panel for i in eng.order if isinstance(i, (ConvBlock, UpBlock)) and not i.prefix.startswith("conv_blocks_context")}
-    pan = lambda c: c[3][[j for j, a in enumerate(c[3]) if isinstance(a, eng_mod._Ptr)][0]].off
-    expect = [i.panel for i in reversed(eng.order) if isinstance(i, (ConvBlock, UpBlock)) and i.panel in dec and lv[i.panel] <= defer[0]]
-    assert [pan(c) for c in held] == expect and len(held) > 0
-    first_held = min(i for i, r in enumerate(dry) if r[0] == "call" and r[2] == "side2")
-    # every main-stream launch of the decoder levels above the flush level precedes the first deferred launch
-    main_before = [r for r in dry[:first_held] if r[0] == "call" and r[2] == "main"]
-    assert len(main_before) > 0
-    if len(defer) > 2:
-        plain = [r for r in dry if r[0] == "plain"]
-        assert [r[2] for r in plain] == [(defer[2],), (0,)]
-    # each deferred launch waits for the event recorded on main when its dL/dy became final
-    waits = [r for r in dry if r[0] == "wait_event" and r[1] == "side2"]
-    assert len(waits) == len(held) and all(r[2] == "main" for r in waits)
+    # the first layer's (HBM-bound) weight gradient has a stream of its own, next to the second block's MFMA-bound one
+    first = [c for c in wg if c[1] == "lnn_conv3d_wgrad_c1_in_bwd"]
+    assert len(first) == 1 and wg[-1] is first[0]
+    assert first[0][2] == ("side2" if own_stream else "side1") and {c[2] for c in wg[:-1]} == {"side1"}
+    # every side launch waits for an event recorded on main when its dL/dy (and, for the first layer, the sums in ws) were enqueued
+    waits = [r for r in dry if r[0] == "wait_event"]
+    assert len(waits) == len(wg) and all(r[2] == "main" for r in waits)
 
 
 def test_backward_without_overlap_runs_on_one_stream(dry):
-    net, eng = _engine(defer=(1, 2))
+    net, eng = _engine()
     eng.overlap_wgrad = False
     x = torch.zeros(2, 1, 16, 16, 16)
     logits = eng.forward(x)
     dry.clear()
     eng.backward([None] + [torch.zeros_like(l) for l in logits[1:]])
     assert {c[2] for c in _calls(dry)} == {"main"} and not [r for r in dry if r[0].startswith("wait")]
+
+
+def test_data_parallel_backward_reports_watermarks_down_to_zero(dry):
+    """With a ``progress`` callback (parallel.GradAllReducer.progress) every layer's panel is folded into the gradient arena on the
+    side stream right behind its weight gradient, the watermarks never move up, and the LAST call hands over offset 0 from inside
+    backward -- no bucket is left for finish().  All weight gradients (the first layer's too) keep ONE side stream here: the
+    exchange is launched from it."""
+    net, eng = _engine()
+    x = torch.zeros(2, 1, 16, 16, 16)
+    logits = eng.forward(x)
+    dry.clear()
+    marks = []
+    eng.backward([None] + [torch.zeros_like(l) for l in logits[1:]], progress=lambda wm, side: marks.append((wm, side.name, len(dry))))
+    assert marks[-1][0] == 0 and all(a[0] >= b[0] for a, b in zip(marks, marks[1:])) and {m[1] for m in marks} == {"side1"}
+    assert marks[0][0] <= eng.arena.size
+    calls = _calls(dry)
+    assert {c[2] for c in calls if "wgrad" in c[1]} == {"side1"}              # no second side stream
+    unp = [c for c in calls if c[1] == "lnn_unpack_wgrad"]
+    assert len(unp) == sum(isinstance(i, (ConvBlock, UpBlock)) for i in eng.order) and all(c[2] == "side1" for c in unp)
+    assert not [c for c in calls if c[1] == "lnn_unpack_wgrad_batched"]
+    # the final watermark is reported after the first layer's weight gradient and its unpack were enqueued
+    last_wgrad = max(i for i, r in enumerate(dry) if r[0] == "call" and r[1] == "lnn_unpack_wgrad")
+    assert marks[-1][2] > last_wgrad
