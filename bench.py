@@ -475,12 +475,14 @@ def other_workload(workload, args, device, rank):
     """One of the continual-learning configurations as extra keys of the same line (N = 1): same loop, same clock."""
     import torch
     tr, plans, ext, wl_desc, extra_cfg = build_trainer(workload, device, rank)
+    tr.defer_loss_fetch = True          # as the headline loop (see main)
     for _ in range(args.warmup):
         tr.run_iteration(tr.tr_gen, True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.run_iteration(tr.tr_gen, True)
+    loss = float(loss)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     B = plans["batch_size"]
@@ -578,6 +580,12 @@ def main():
     from lifelong_nnunet_amd import native as nat
     tr, plans, ext, wl_desc, extra_cfg = build_trainer(args.workload, device, rank)
 
+    # The iterations are enqueued the way the trainer's own epoch loop runs them (nnUNetTrainerMultiHead._run_epoch_loop): the
+    # loss / gradient-norm / found-inf triple of an iteration travels to the host asynchronously and is consumed when the NEXT
+    # iteration needs the loss scale -- no host synchronisation between two iterations.  Every loss is still fetched, the last one
+    # inside the timed region; `config.eager_loss_fetch` is the same loop with a synchronising fetch per iteration.
+    tr.defer_loss_fetch = True
+
     def step():
         return tr.run_iteration(tr.tr_gen, True)
 
@@ -586,6 +594,7 @@ def main():
         t0_ = time.perf_counter()
         for _ in range(nsteps):
             l_ = step()
+        l_ = float(l_)
         torch.cuda.synchronize()
         return time.perf_counter() - t0_, l_
 
@@ -604,6 +613,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    loss = float(loss)                  # the last iteration's loss has arrived (all earlier ones were consumed on the way)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -652,6 +662,14 @@ def main():
                    "conv_stack_frac_of_mfma_peak": patches_per_s / world * flops_patch / 1e12 / PEAK_MFMA_F16_TFLOPS},
     }
     out["config"].update(extra_cfg)
+    out["config"]["loss_fetch"] = "asynchronous: consumed by the next iteration's loss-scale decision (the trainer's epoch loop)"
+    if world == 1:
+        tr.defer_loss_fetch = False
+        timed(2)
+        dt_e, _ = timed(args.steps)
+        tr.defer_loss_fetch = True
+        out["config"]["eager_loss_fetch"] = {"ms_per_step": dt_e / args.steps * 1e3, "value": B * args.steps / dt_e,
+                                             "how": "run_iteration's default: one synchronising device-to-host copy per iteration"}
     if ext == "lwf":          # the fix behind a flag: every head evaluated on the training batch (one batch, one body pass)
         tr.same_batch_predictions = True
         timed(2)
@@ -704,15 +722,21 @@ def main():
         tj = committed_pmc("pmc_traffic.json", so_sha)
         if tj is not None:
             short = {"igemm_conv_fwd": "fwd", "igemm_conv_dgrad": "dgrad", "igemm_wgrad": "wgrad"}.get(dom_key, dom_key)
-            traffic = tj[1]["kernels"][short]["hbm_bytes_per_launch_corrected"]
-            traffic_note = f"profiles/{tj[0]} (so_sha256 matches the loaded library): " + tj[1]["note"]
+            try:
+                traffic = tj[1]["kernels"][short]["hbm_bytes_per_launch_corrected"]
+                traffic_note = f"profiles/{tj[0]} (so_sha256 matches the loaded library): " + tj[1].get("note", "")
+            except (KeyError, TypeError) as e:
+                traffic, traffic_note = None, f"profiles/{tj[0]} matches the loaded library but lacks {e!r}: traffic not quoted"
         else:
             traffic_note = "no committed PMC pass for this liblnn_hip.so (sha256 %s...): traffic not quoted" % so_sha[:12]
         cj = committed_pmc("pmc_mfma_clock.json", so_sha)
         if cj is not None:
-            clock = {k: {"clock_ghz": v["clock_ghz"], "mfma_busy_frac_in_cycles": v["mfma_busy_frac_in_cycles"]}
-                     for k, v in cj[1]["families"].items() if v}
-            clock["source"] = f"profiles/{cj[0]} (GRBM_GUI_ACTIVE / duration; SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles)"
+            try:
+                clock = {k: {"clock_ghz": v["clock_ghz"], "mfma_busy_frac_in_cycles": v["mfma_busy_frac_in_cycles"]}
+                         for k, v in cj[1]["families"].items() if v}
+                clock["source"] = f"profiles/{cj[0]} (GRBM_GUI_ACTIVE / duration; SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles)"
+            except (KeyError, TypeError, AttributeError) as e:
+                clock = {"error": f"profiles/{cj[0]} lacks {e!r}"}
         ach = dom["achieved_in_step"] or dom["achieved_isolated"]
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"] + " on " + kr["layer"], "achieved": ach,
                            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,

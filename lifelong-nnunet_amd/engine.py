@@ -428,8 +428,10 @@ class UNetEngine:
                 if tiles * -(-ch // 32) < 512:
                     need = max(need, 8 * vox * (-(-ch // 32) * 32))
 
-        def gen_need(vox, ch, classes=1, always=False):
-            if vox > 4096 and not always:                 # (isotropic layers above the threshold stay on the specialised kernels)
+        def gen_need(vox, ch, classes=1, always=False, limit=4096):
+            # ``limit``: the volume up to which the isotropic entry points hand this op to the generic kernels (lnn_gen_prefers,
+            # csrc/igemm_conv.hip: stride-1 / stride-2 convolutions <= 4096 voxels, transposed-conv data gradients <= 20000)
+            if vox > limit and not always:                # (isotropic layers above the threshold stay on the specialised kernels)
                 return 1
             mp = -(-ch // 32) * 32
             waves = classes * -(-(vox // classes) // 64) * -(-mp // 64)
@@ -444,7 +446,7 @@ class UNetEngine:
             need = max(need, gen_need(N * blk.z.V, blk.cout, 1, not blk.iso))                                     # forward
             need = max(need, gen_need(N * blk.in_dims[0] * blk.in_dims[1] * blk.in_dims[2], blk.cin_k, ncls, not blk.iso))   # data gradient
         for up in self.ups:
-            need = max(need, gen_need(N * up.y.V, up.cout, up.ntaps, not up.iso), gen_need(N * up.x.V, up.cin, 1, not up.iso))
+            need = max(need, gen_need(N * up.y.V, up.cout, up.ntaps, not up.iso), gen_need(N * up.x.V, up.cin, 1, not up.iso, 20000))
         self.splitk_ws = torch.zeros(need, dtype=torch.float32, device=dev)
         self.packed_version = -1
         self.unused_heads: List[str] = []

@@ -94,6 +94,58 @@ class GradScaler:
         self.growth_interval = d.get("growth_interval", self.growth_interval)
 
 
+class AsyncCtrl:
+    """{sum g^2, #non-finite, loss} of ONE enqueued step on its way to the host: a copy into pinned memory + an event, both on the
+    stream of the step.  ``get()`` waits for the event only (not for the device) and caches the three numbers."""
+
+    def __init__(self, host, event):
+        self._host, self._event, self._vals = host, event, None
+
+    def ready(self):
+        return self._vals is not None or self._event is None or self._event.query()
+
+    def get(self):
+        if self._vals is None:
+            if self._event is not None:
+                self._event.synchronize()
+            self._vals = self._host.numpy().copy()
+            self._host = self._event = None
+        return self._vals
+
+
+class DeferredLoss:
+    """The loss of an iteration whose device-to-host copy is still in flight (``run_iteration`` of a trainer with
+    ``defer_loss_fetch``: what its epoch loop uses -- the reference collects the per-iteration losses and takes their mean at the
+    end of the epoch, MH.py:655).  Converts like a number; the first conversion waits for the copy."""
+    __slots__ = ("_ctrl", "_v")
+
+    def __init__(self, ctrl):
+        self._ctrl, self._v = ctrl, None
+
+    def value(self):
+        if self._v is None:
+            import numpy as np
+            self._v = np.float32(self._ctrl.get()[2])
+            self._ctrl = None
+        return self._v
+
+    def __float__(self):
+        return float(self.value())
+
+    def __array__(self, dtype=None, copy=None):
+        import numpy as np
+        return np.asarray(self.value(), dtype=dtype)
+
+    def item(self):
+        return float(self.value())
+
+    def __repr__(self):
+        return repr(self.value())
+
+    def __format__(self, spec):
+        return format(float(self.value()), spec)
+
+
 class FusedSGD:
     """SGD(momentum=0.99, nesterov=True) over the flat arena with ``torch.optim.SGD``'s surface
     (``param_groups[0]['lr']``, ``zero_grad``, ``step``, ``state_dict``)."""
@@ -109,6 +161,8 @@ class FusedSGD:
         self._ctrl_valid = False
         self._ever_stepped = set()       # names the optimiser has stepped at least once (torch creates their momentum_buffer then)
         self._pending_stepped = None     # names of the last enqueued step, counted once its found-inf flag is known to be 0
+        self._async = None               # AsyncCtrl of the last enqueued step, if its control block was fetched without a sync
+        self._host_ring, self._ring_i = None, 0
 
     def zero_grad(self, set_to_none=False):
         self.net.arena.grad.zero_()
@@ -148,7 +202,11 @@ class FusedSGD:
         if self._pending_stepped is None:
             return
         if found_inf is None:
-            found_inf = bool(self.ctrl[1].item() > 0)
+            if self._async is not None:               # the step's control block is already on its way to the host
+                found_inf = bool(self._async.get()[1] > 0)
+            else:
+                found_inf = bool(self.ctrl[1].item() > 0)
+        self._async = None
         if not found_inf:
             self._ever_stepped.update(self._pending_stepped)
         self._pending_stepped = None
@@ -160,6 +218,26 @@ class FusedSGD:
         arr = self._ctrl_buf[:3].cpu().numpy()
         self._resolve_pending(bool(arr[1] > 0))
         return arr
+
+    def fetch_with_loss_async(self, loss):
+        """``fetch_with_loss`` without the host synchronisation: the three numbers are copied into pinned host memory on the step's
+        stream and an event marks their arrival; returns the AsyncCtrl.  The control block is rewritten by the NEXT step's norm
+        pass, which the stream orders behind this copy."""
+        dev = self._ctrl_buf.device
+        if dev.type != "cuda":
+            arr = self.fetch_with_loss(loss)
+            h = AsyncCtrl(torch.from_numpy(arr.copy()), None)
+            return h
+        if self._host_ring is None:
+            self._host_ring = [torch.empty(3, dtype=torch.float64).pin_memory() for _ in range(4)]
+        self._ctrl_buf[2:3].copy_(loss.detach().reshape(1))
+        host = self._host_ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % len(self._host_ring)
+        host.copy_(self._ctrl_buf[:3], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._async = h = AsyncCtrl(host, ev)
+        return h
 
     def read_ctrl(self):
         """(total_norm, found_inf) -- ONE host sync; call after the loss has been fetched anyway."""
@@ -192,6 +270,8 @@ class FusedSGD:
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, d):
+        # a step that was enqueued but whose found-inf flag nobody fetched belongs to the state being replaced
+        self._pending_stepped, self._async = None, None
         if "param_groups" not in d:                      # round-1 private format {"momentum": arena, "lr": float}
             self.net.arena.momentum.copy_(d["momentum"])
             self.param_groups[0]["lr"] = d["lr"]

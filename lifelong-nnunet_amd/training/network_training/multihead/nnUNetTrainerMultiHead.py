@@ -22,7 +22,7 @@ import torch
 from ....losses import DC_and_CE_loss, MultipleOutputLoss2, ds_loss_weights
 from ....multihead import MultiHead_Module
 from ....network import Generic_UNet
-from ....optim import FusedSGD, GradScaler
+from ....optim import DeferredLoss, FusedSGD, GradScaler
 from ....parallel import GradAllReducer
 from ....synthetic import SyntheticPatchGenerator
 
@@ -93,7 +93,13 @@ class nnUNetTrainerMultiHead:
         self.validation_results = dict()
         self.amp_grad_scaler = None
         self.dp: Optional[GradAllReducer] = None
-        self.last_grad_norm, self.last_found_inf = None, False
+        self._last_grad_norm, self._last_found_inf = None, False
+        # run_iteration(detach=True) returns the loss as a number on the host (MH.py:655).  With ``defer_loss_fetch`` it returns a
+        # DeferredLoss instead: the device-to-host copy of {loss, gradient norm, found-inf} is in flight and the GradScaler update of
+        # THIS iteration is applied when the next one asks for the scale -- the host never waits for the device between two
+        # iterations.  The epoch loop of run_training switches it on (it only needs the numbers at the end of the epoch).
+        self.defer_loss_fetch = False
+        self._pending_step = None
         if deterministic:
             torch.manual_seed(12345 + fold)      # the only seed constants the reference uses (MH.py:214,259)
             np.random.seed(12345 + fold)
@@ -192,8 +198,16 @@ class nnUNetTrainerMultiHead:
         self.maybe_update_lr(self.epoch)
         while self.epoch < self.max_num_epochs:
             self.network.train()
-            tr = [self.run_iteration(self.tr_gen, True) for _ in range(self.num_batches_per_epoch)]
-            self.all_tr_losses.append(float(np.mean(tr)))
+            # the epoch loop only needs the losses at the end of the epoch (upstream: train_losses_epoch.append(l); np.mean): the
+            # iterations run without a host synchronisation between them.  Subclasses whose run_iteration reads host-side state of
+            # the step it just enqueued are unaffected: last_grad_norm / last_found_inf resolve on access.
+            keep, self.defer_loss_fetch = self.defer_loss_fetch, True
+            try:
+                tr = [self.run_iteration(self.tr_gen, True) for _ in range(self.num_batches_per_epoch)]
+            finally:
+                self.defer_loss_fetch = keep
+            self._finish_pending_step()
+            self.all_tr_losses.append(float(np.mean([float(v) for v in tr])))
             with torch.no_grad():
                 self.network.eval()
                 va = []
@@ -227,6 +241,7 @@ class nnUNetTrainerMultiHead:
             self._bind_process_group(self.loss)
             l = self.loss(output, target)
         if do_backprop:
+            self._finish_pending_step()            # the previous iteration's found-inf flag decides this iteration's scale
             scale = self.amp_grad_scaler.get_scale()
             if self.dp is not None:
                 self.dp.begin()
@@ -249,12 +264,45 @@ class nnUNetTrainerMultiHead:
             return None
         if detach:
             if do_backprop:
+                if self.defer_loss_fetch:
+                    self._pending_step = self.optimizer.fetch_with_loss_async(l)
+                    return DeferredLoss(self._pending_step)
                 vals = self.optimizer.fetch_with_loss(l)          # {sum g^2, #non-finite, loss}: one copy launch + one D2H
-                self.last_grad_norm, self.last_found_inf = float(vals[0]) ** 0.5, bool(vals[1] > 0)
-                self.amp_grad_scaler.update(self.last_found_inf)
+                self._last_grad_norm, self._last_found_inf = float(vals[0]) ** 0.5, bool(vals[1] > 0)
+                self.amp_grad_scaler.update(self._last_found_inf)
                 return np.float32(vals[2])
             return l.detach().cpu().numpy()
         return l
+
+    def _finish_pending_step(self):
+        """Bookkeeping of an iteration whose numbers were fetched without a synchronisation (``defer_loss_fetch``): gradient norm,
+        found-inf flag, the optimiser's momentum-state record and the GradScaler update (MH.py:631 ``amp_grad_scaler.update()``)."""
+        h = self._pending_step
+        if h is None:
+            return
+        self._pending_step = None
+        vals = h.get()
+        self._last_grad_norm, self._last_found_inf = float(vals[0]) ** 0.5, bool(vals[1] > 0)
+        self.optimizer._resolve_pending(self._last_found_inf)
+        self.amp_grad_scaler.update(self._last_found_inf)
+
+    @property
+    def last_grad_norm(self):
+        self._finish_pending_step()
+        return self._last_grad_norm
+
+    @last_grad_norm.setter
+    def last_grad_norm(self, v):
+        self._last_grad_norm = v
+
+    @property
+    def last_found_inf(self):
+        self._finish_pending_step()
+        return self._last_found_inf
+
+    @last_found_inf.setter
+    def last_found_inf(self, v):
+        self._last_found_inf = v
 
     def _bind_process_group(self, loss):
         """The batch-Dice exchange inside DC_and_CE_loss must run over THIS trainer's ranks (``process_group``), not the

@@ -238,6 +238,10 @@ def test_instnorm_lrelu_seg_fwd_fused(N, C, K, V3):
     nat.call("lnn_instnorm_lrelu_seg_fwd", yb, z2, C + 8, N, V, C, mean, rstd, gamma, beta, 0.01, w, l2, K)
     assert torch.equal(z1, z2)
     assert float((l1 - l2).abs().max()) <= 2e-6 * float(l1.abs().max())
+    # z = NULL (the last decoder block of a training step: nobody reads its normalised tensor): the same logits, nothing else written
+    l3 = torch.full((N, K) + V3, 5.0, device=DEV)
+    nat.call("lnn_instnorm_lrelu_seg_fwd", yb, None, C + 8, N, V, C, mean, rstd, gamma, beta, 0.01, w, l3, K)
+    assert torch.equal(l3, l2)
 
 
 @pytest.mark.parametrize("N,K,D,H,W", [(2, 32, 9, 13, 17), (1, 32, 16, 16, 16), (3, 64, 5, 8, 9)])
@@ -363,6 +367,63 @@ def test_dice_ce_fwd_bwd(N, K, V3, batch_dice):
     dl = torch.zeros_like(lg)
     nat.call("lnn_dice_ce_bwd", lg, lb, N, K, V, batch_dice, 1e-5, ws, 1.5, torch.full((1,), 2.0, device=DEV), 1.0, dl)
     assert rel_err(dl.cpu(), 3.0 * logits.grad) < 1e-4
+
+
+@pytest.mark.parametrize("K", [2, 3, 5])
+def test_dice_ce_with_infinite_and_very_negative_logits(K):
+    """A logit of -inf (or -1e30) is a class of probability exactly 0: torch's softmax / log_softmax give a finite loss and a zero
+    gradient for that channel as long as the voxel's label is another class; the kernels' compensated hardware exp must do the same
+    (its residual term was inf - inf = NaN before round 5)."""
+    from oracle import losses
+    N, V3 = 2, (4, 8, 8)
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn((N, K) + V3, generator=g) * 2
+    labels = torch.randint(0, K, (N, 1) + V3, generator=g).float()
+    lab = labels[:, 0].long()
+    kill = torch.zeros_like(logits, dtype=torch.bool)
+    for k in range(K):                       # every 7th voxel: one channel that is NOT the label goes to -inf, the next 7th to -1e30
+        idx = ((torch.arange(lab.numel()).reshape(lab.shape) % 7) == 0) & (lab != k) & ~kill.any(1)
+        kill[:, k] |= idx
+    big = torch.zeros_like(kill)
+    big[:, 0] = ((torch.arange(lab.numel()).reshape(lab.shape) % 7) == 3) & (lab != 0) & ~kill.any(1)
+    logits[kill] = float("-inf")
+    logits[big] = -1e30
+    lg = logits.clone().requires_grad_(True)
+    ref = losses.dc_and_ce_loss(lg, labels, False)
+    ref.backward()
+    assert torch.isfinite(ref) and torch.isfinite(lg.grad).all()
+    V = V3[0] * V3[1] * V3[2]
+    dg, lb = logits.to(DEV), labels.to(DEV)
+    ws = torch.zeros(nat.query("lnn_dice_ce_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    out = torch.zeros(1, device=DEV)
+    nat.call("lnn_dice_ce_fwd", dg, lb, N, K, V, 0, 1e-5, out, ws)
+    assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))
+    dl = torch.full_like(dg, float("nan"))
+    nat.call("lnn_dice_ce_bwd", dg, lb, N, K, V, 0, 1e-5, ws, 1.0, torch.full((1,), 1.0, device=DEV), 1.0, dl)
+    assert torch.isfinite(dl).all() and rel_err(dl.cpu(), lg.grad) < 1e-4
+    assert float(dl.cpu()[kill].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,C,K,V3", [(2, 320, 3, (10, 12, 10)), (2, 320, 3, (5, 6, 5)), (1, 256, 3, (7, 5, 3)), (3, 32, 2, (9, 11, 5)),
+                                      (1, 8, 5, (4, 8, 8)), (2, 48, 4, (3, 7, 5)), (1, 512, 1, (2, 3, 5)), (1, 640, 3, (4, 4, 4)),
+                                      (2, 24, 8, (5, 5, 5))])
+def test_seg1x1_fwd_wave_kernel_shapes(N, C, K, V3):
+    """The 1x1x1 head forward with thread = (voxel, channel octet) (C <= 512; round 5): channel counts whose octet count is not a
+    power of two (320 -> 40 of 64 lanes, 48 -> 6 of 8, 24 -> 3 of 4), one octet (C = 8), runtime K > 4, ragged voxel counts, a
+    channel stride wider than C, and the voxel-per-thread kernel that still serves C > 512."""
+    z = _rand((N, C) + V3, 11)
+    w = torch.randn((K, C, 1, 1, 1), generator=torch.Generator().manual_seed(2)) * 0.2
+    ref = F.conv3d(q16(z), w)
+    V = V3[0] * V3[1] * V3[2]
+    zb, _ = to_cl_h(z)
+    wide = torch.zeros((N,) + V3 + (C + 16,), dtype=torch.float16, device=DEV)
+    wide[..., :C] = zb
+    wide[..., C:] = 77.0                                   # must never be read
+    wd = w.view(K, C).contiguous().to(DEV)
+    for buf, ld in ((zb, C), (wide, C + 16)):
+        logits = torch.full((N, K) + V3, 3.0, device=DEV)
+        nat.call("lnn_seg1x1_fwd", buf, ld, wd, logits, N, V, C, K)
+        assert rel_err(logits.cpu(), ref) < 1e-5
 
 
 def test_dice_ce_golden(golden_dir):

@@ -180,3 +180,46 @@ def test_data_parallel_backward_reports_watermarks_down_to_zero(dry):
     # the final watermark is reported after the first layer's weight gradient and its unpack were enqueued
     last_wgrad = max(i for i, r in enumerate(dry) if r[0] == "call" and r[1] == "lnn_unpack_wgrad")
     assert marks[-1][2] > last_wgrad
+
+
+def test_deferred_loss_fetch_keeps_the_grad_scaler_semantics(dry, monkeypatch):
+    """``defer_loss_fetch`` (what the epoch loop uses): run_iteration returns a DeferredLoss, the found-inf flag of iteration i is
+    consumed when iteration i + 1 asks for the loss scale -- the scale sequence is the one of the synchronising loop
+    (x 0.5 right after an overflowed iteration), and last_grad_norm / last_found_inf resolve on access."""
+    from lifelong_nnunet_amd import get_trainer_class
+    from lifelong_nnunet_amd.optim import DeferredLoss
+    plans = {"patch_size": (16, 16, 16), "batch_size": 2, "num_pool": 2, "base_num_features": 8, "num_classes": 3, "num_input_channels": 1}
+    overflow_at = {2}
+    scales = {}
+    for mode in ("eager", "deferred"):
+        tr = get_trainer_class("sequential")("seg_outputs", "A", plans=dict(plans), device="cpu")
+        tr.initialize(True, num_epochs=1)
+        tr.defer_loss_fetch = mode == "deferred"
+        it = [0]
+        ctrl = tr.optimizer._ctrl_buf
+
+        def fake_call(name, *args, it=it, ctrl=ctrl):
+            _REC.append(("call", name, _CUR[-1].name, args))
+            if name == "lnn_gradnorm_sumsq":          # the norm pass leaves {sum g^2, #non-finite}: an overflow in iteration 2
+                ctrl[0] = 4.0
+                ctrl[1] = 1.0 if it[0] in overflow_at else 0.0
+        monkeypatch.setattr(nat, "call", fake_call)
+        seen = []
+        for i in range(5):
+            it[0] = i
+            seen.append(tr.amp_grad_scaler.get_scale() if mode == "eager" else None)
+            l = tr.run_iteration(tr.tr_gen, True)
+            if mode == "deferred":
+                assert isinstance(l, DeferredLoss) and tr._pending_step is not None
+                # the scale this iteration USED is visible through the inverse it handed to the optimiser
+                seen[-1] = 1.0 / tr.last_inv_scale
+                if i == 3:
+                    assert tr.last_found_inf is False and tr.last_grad_norm == 2.0 and tr._pending_step is None    # resolves on access
+                float(l)
+            else:
+                assert not isinstance(l, DeferredLoss)
+        scales[mode] = seen + [tr.amp_grad_scaler.get_scale() if mode == "eager" else None]
+        if mode == "deferred":
+            tr._finish_pending_step()
+            scales[mode][-1] = tr.amp_grad_scaler.get_scale()
+    assert scales["eager"] == scales["deferred"] == [65536.0, 65536.0, 65536.0, 32768.0, 32768.0, 32768.0]

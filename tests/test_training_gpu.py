@@ -196,5 +196,6 @@ def test_fp16_step_is_bit_reproducible_with_deterministic_wgrad(B):
     t2, l2 = run(True)
     t0, l0 = run(False)
     assert torch.equal(t1, t2) and l1 == l2
-    assert float((t1 - t0).norm() / t0.norm()) < 1e-5
+    # (the atomic path's summation order differs from run to run: 2e-6 ... 1.6e-5 over rounds 2-5 on three steps with momentum 0.99)
+    assert float((t1 - t0).norm() / t0.norm()) < 5e-5
     assert np.allclose(l1, l0, rtol=1e-5)
