@@ -36,6 +36,16 @@ WORKLOADS = {       # BASELINE.json configs[...]: (plans, trainer extension, des
            "old head (reference semantics: one extra eval forward per head on its own batch, KL against the stored teacher logits)"),
     "c5": (_C2, "rehearsal_ewc", "BASELINE configs[4]: nnUNetTrainerRehearsalEWC.run_iteration on the second task "
            "(mixed-task batches from the fused case list + EWC penalty)"),
+    # the reference's second use case (README.md:73, Task005_Prostate): an ANISOTROPIC 3d_fullres plan -- two modalities, in-plane
+    # [1,3,3] kernels and [1,2,2] poolings in the first stages (nnUNetTrainerMultiHead.py:348-369 builds the network from these
+    # lists).  Shape of upstream's Task005 plan as recalled (patch 20x320x256, batch 2, 6 poolings); runs on the generic-geometry
+    # kernels (csrc/igemm_gen.hip): a measured number for that path, not a tuned one.
+    "prostate": ({"patch_size": (20, 320, 256), "batch_size": 2, "num_pool": 6, "base_num_features": 32, "num_classes": 3,
+                  "num_input_channels": 2, "synthetic_period": 2,
+                  "pool_op_kernel_sizes": [[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2], [1, 2, 2]],
+                  "conv_kernel_sizes": [[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]]},
+                 "sequential", "Task005_Prostate-shaped anisotropic 3d_fullres plan (2 modalities, [1,3,3] kernels / [1,2,2] poolings "
+                 "in the first stages): nnUNetTrainerSequential.run_iteration"),
 }
 
 
@@ -418,6 +428,35 @@ def iteration_parity(tr, ext, plans):
             "loss_hip": loss_g, "loss_oracle": loss_o, "loss_rel_err": rel, "gates": {"loss_rel_err<=1e-4": rel <= 1e-4}}
 
 
+def plain_loss_parity(tr, plans):
+    """Deep-supervised Dice+CE of ONE full-size patch (B = 1): fp16 MFMA engine with the trainer's weights vs the oracle's CPU fp32
+    forward of the same plan-built network (any plan: input channels, per-level poolings / kernel extents); gate 1e-4."""
+    import torch
+    from oracle import losses as ol
+    from oracle.unet import OracleGenericUNet
+    from lifelong_nnunet_amd.losses import DC_and_CE_loss, MultipleOutputLoss2, ds_loss_weights
+    batch = tr.tr_gen.items[0]
+    data = batch["data"][:1].float()
+    tgts = [t[:1].float() for t in batch["target"]]
+    npool = plans["num_pool"]
+    dev = tr.network.device_
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), ds_loss_weights(npool))
+    with torch.no_grad():
+        tr.network.eval()
+        loss_g = float(loss_fn(tr.network(data.to(dev)), [t.to(dev) for t in tgts]))
+        tr.network.train()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    net = OracleGenericUNet(plans["num_input_channels"], plans["base_num_features"], plans["num_classes"], npool,
+                            pool_op_kernel_sizes=plans.get("pool_op_kernel_sizes"), conv_kernel_sizes=plans.get("conv_kernel_sizes"))
+    net.load_state_dict({k: v.detach().float().cpu() for k, v in tr.network.state_dict().items()})
+    with torch.no_grad():
+        loss_o = float(ol.multiple_output_loss(net(data.cpu()), [t.cpu() for t in tgts], ol.ds_loss_weights(npool)))
+    rel = abs(loss_g - loss_o) / max(abs(loss_o), 1e-30)
+    return {"what": "deep-supervised Dice+CE of ONE %s patch (B = 1, %d channels), the trainer's weights after the timed steps: fp16 "
+                    "MFMA engine vs the oracle's CPU fp32 forward" % ("x".join(map(str, data.shape[2:])), data.shape[1]),
+            "loss_hip": loss_g, "loss_oracle": loss_o, "loss_rel_err": rel, "gates": {"loss_rel_err<=1e-4": rel <= 1e-4}}
+
+
 def build_trainer(workload, device, rank):
     """Trainer of one BASELINE.json configuration in the state its timed iteration needs (second task for the CL methods)."""
     import torch
@@ -489,7 +528,7 @@ def other_workload(workload, args, device, rank):
     res = {"workload": f"{wl_desc}, {'x'.join(map(str, plans['patch_size']))} patches, batch {B}", "value": B * args.steps / dt,
            "unit": "patches/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "loss": float(loss)}
     res.update(extra_cfg)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and ext in ("ewc", "rehearsal_ewc", "lwf"):
         try:
             res["parity"] = regulariser_parity(tr, ext)
         except Exception as e:
@@ -498,6 +537,15 @@ def other_workload(workload, args, device, rank):
             res["parity"]["full_iteration"] = iteration_parity(tr, ext, plans)
         except Exception as e:
             res["parity"]["full_iteration"] = {"error": repr(e)}
+    elif not args.no_cpu_baseline:
+        try:
+            res["parity"] = plain_loss_parity(tr, plans)
+        except Exception as e:
+            res["parity"] = {"error": repr(e)}
+    eng = list(tr.network._engines.values())[0]
+    fl, _ = eng.flops_per_patch()
+    res["conv_gflop_per_patch"] = fl / 1e9
+    res["conv_stack_frac_of_mfma_peak"] = res["value"] * fl / 1e12 / PEAK_MFMA_F16_TFLOPS
     if ext == "lwf":          # the fix behind a flag: every head evaluated on the training batch (one batch, one body pass)
         tr.same_batch_predictions = True
         for _ in range(2):
@@ -523,7 +571,7 @@ def main():
     ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
                     help="CPU baseline / parity patch: one full-size patch (~15 s of CPU work) or a 128^3 sub-patch")
     ap.add_argument("--other-workloads", default=None,
-                    help="comma list of further BASELINE configurations reported as extra keys (default: c3,c4,c5 with --workload c2 at N=1; 'none')")
+                    help="comma list of further configurations reported as extra keys (default: c3,c4,c5,prostate with --workload c2 at N=1; 'none')")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the gradient exchange: nccl (= RCCL over xGMI, one GPU per rank) or gloo "
                          "(stages device tensors through host memory; what lets N ranks share one GPU in the tests)")
@@ -768,7 +816,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     others = args.other_workloads
     if others is None:
-        others = "c3,c4,c5" if (args.workload == "c2" and world == 1 and not args.no_roofline) else "none"
+        others = "c3,c4,c5,prostate" if (args.workload == "c2" and world == 1 and not args.no_roofline) else "none"
     if rank == 0 and world == 1 and others != "none":
         del tr, eng
         import gc

@@ -409,6 +409,14 @@ class UNetEngine:
         self._pack_desc = torch.tensor(pk, dtype=torch.int64, device=dev)
         self._unpack_desc = torch.tensor(up, dtype=torch.int64, device=dev)
         self._pack_total, self._unpack_total = pk_total, up_total
+        # the same table in two parts -- the first block's panels / everything else -- for the overlapped re-pack of forward()
+        k0 = 1 if order[0].cin_k == 1 else 2
+        first0 = pk[k0][8] if len(pk) > k0 else pk_total
+        self._pack_desc_a = torch.tensor(pk[:k0], dtype=torch.int64, device=dev)
+        self._pack_total_a = first0
+        self._pack_desc_b = torch.tensor([r[:8] + [r[8] - first0] for r in pk[k0:]], dtype=torch.int64, device=dev) if len(pk) > k0 else None
+        self._pack_total_b = pk_total - first0
+        self._pack_event = None
         cmax = max(2 * f for f in feats)
         ws_doubles = max(nat.query("lnn_instnorm_ws_doubles", N, cmax), (nat.query("lnn_seg1x1_bwd_ws_floats", N, cmax) + 1) // 2,
                          nat.query("lnn_instnorm_lrelu_seg_bwd_ws_doubles", N, max(seg.cin for seg in self.segs)), 64)
@@ -453,6 +461,7 @@ class UNetEngine:
         self._sides = {}
         # A/B switches of round 5 (measurements only; see backward / forward)
         self.c1_wgrad_stream = os.environ.get("LNN_NO_C1_WGRAD_STREAM", "0") != "1"
+        self.pack_overlap = os.environ.get("LNN_NO_PACK_OVERLAP", "0") != "1"
         self.lazy_top_z = os.environ.get("LNN_NO_LAZY_TOP_Z", "0") != "1"
         self._top_block = self.segs[-1].x_block
         self._top_z_valid = False
@@ -513,11 +522,31 @@ class UNetEngine:
         return _Ptr(self.gpanels, off)
 
     # ------------------------------------------------------------------------------------------ pack
-    def pack_weights(self):
-        """fp32 parameter arena -> fp16 MFMA panels of every layer, one launch."""
-        nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc, self._pack_desc.shape[0],
-                 self._pack_total)
+    def pack_weights(self, overlap=False):
+        """fp32 parameter arena -> fp16 MFMA panels of every layer, one launch.  ``overlap`` (a training forward): the first block's
+        panels on the current stream, all others on a side stream next to the first block's HBM-bound kernels (image cast, C = 1
+        convolution, its normalisation pass); forward() waits for them in front of the second block."""
+        if overlap and self.pack_overlap and self._pack_desc_b is not None and self.theta.is_cuda:
+            nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc_a, self._pack_desc_a.shape[0],
+                     self._pack_total_a)
+            main, side = torch.cuda.current_stream(), self._side_stream(2)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc_b, self._pack_desc_b.shape[0],
+                         self._pack_total_b)
+                self._pack_event = torch.cuda.Event()
+                self._pack_event.record(side)
+        else:
+            nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc, self._pack_desc.shape[0],
+                     self._pack_total)
         self.packed_version = self.arena.version
+
+    def _await_pack(self):
+        if self._pack_event is not None:
+            torch.cuda.current_stream().wait_event(self._pack_event)
+            self._pack_event = None
 
     def unpack_wgrads(self):
         """fp32 wgrad panels of every layer += into the gradient arena (PyTorch layouts), one launch."""
@@ -541,7 +570,7 @@ class UNetEngine:
         assert tuple(x.shape) == (N, self.in_channels) + self.patch, \
             f"engine built for {(N, self.in_channels) + self.patch}, got {tuple(x.shape)}"
         if self.packed_version != self.arena.version:
-            self.pack_weights()
+            self.pack_weights(overlap=body)
         if body:
             if self.c1_path:
                 nat.call("lnn_cast_f32_to_h", x.contiguous(), self.image, x.numel())
@@ -553,6 +582,8 @@ class UNetEngine:
         u = 0
         fused_segs = set()
         for item in self.order:
+            if item is not self.order[0]:
+                self._await_pack()                 # (everything behind the first block reads panels the side stream may still be writing)
             if isinstance(item, ConvBlock):
                 if not body:
                     continue
@@ -666,6 +697,7 @@ class UNetEngine:
         """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.
         Accumulates parameter gradients into the flat arena ``self.grad`` (scaled like dlogits)."""
         N = self.N
+        self._await_pack()
         self.gpanels.zero_()
         self.unused_heads = [seg.w.name for seg, dl in zip(self.segs, dlogits) if dl is None]
         dls = [None if dl is None else dl.contiguous() for dl in dlogits]

@@ -223,3 +223,35 @@ def test_deferred_loss_fetch_keeps_the_grad_scaler_semantics(dry, monkeypatch):
             tr._finish_pending_step()
             scales[mode][-1] = tr.amp_grad_scaler.get_scale()
     assert scales["eager"] == scales["deferred"] == [65536.0, 65536.0, 65536.0, 32768.0, 32768.0, 32768.0]
+
+
+def test_training_forward_repacks_the_weights_next_to_the_first_block(dry, monkeypatch):
+    """After an optimiser step the fp16 panels are rebuilt by the next forward: the first block's on the forward's stream, all others
+    on a side stream, and the forward waits for that stream before the first launch of the SECOND block -- never later."""
+    net, eng = _engine()
+    monkeypatch.setattr(type(eng.theta), "is_cuda", property(lambda self: True), raising=False)
+    x = torch.zeros(2, 1, 16, 16, 16)
+    eng.forward(x)
+    packs = [(i, r) for i, r in enumerate(dry) if r[0] == "call" and r[1] == "lnn_pack_weights_batched"]
+    assert [r[2] for _, r in packs] == ["main", "side1"]
+    na, nb = packs[0][1][3][3], packs[1][1][3][3]
+    assert na == 1 and na + nb == eng._pack_desc.shape[0]
+    assert packs[0][1][3][4] + packs[1][1][3][4] == eng._pack_total
+    # rebased work offsets of the second table
+    assert int(eng._pack_desc_b[0, 8]) == 0 and int(eng._pack_desc_b[-1, 8]) == int(eng._pack_desc[-1, 8]) - int(eng._pack_desc[1, 8])
+    waits = [i for i, r in enumerate(dry) if r[0] == "wait_event" and r[1] == "main"]
+    assert len(waits) == 1
+    second = eng.order[1]
+    first_of_second = min(i for i, r in enumerate(dry) if r[0] == "call" and any(a is second.y for a in r[3]))
+    first_block_calls = [i for i, r in enumerate(dry) if r[0] == "call" and any(a is eng.order[0].y for a in r[3])]
+    assert max(first_block_calls) < waits[0] < first_of_second
+    # nothing to re-pack: no further pack launches, no waits
+    dry.clear()
+    eng.forward(x)
+    assert not [r for r in dry if r[0] == "wait_event" or (r[0] == "call" and r[1] == "lnn_pack_weights_batched")]
+    # an evaluation of stored activations (body=False) after a parameter change packs in line
+    net.mark_params_changed()
+    dry.clear()
+    eng.forward(x, seg_weights=[torch.zeros(3, sg.cin, 1, 1, 1) for sg in eng.segs], body=False)
+    packs = [r for r in dry if r[0] == "call" and r[1] == "lnn_pack_weights_batched"]
+    assert len(packs) == 1 and packs[0][2] == "main" and packs[0][3][3] == eng._pack_desc.shape[0]
