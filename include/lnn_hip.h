@@ -164,8 +164,8 @@ int lnn_instnorm_lrelu_fwd(lnn_stream_t s, const void* y_h, void* z_h, int ld_z,
                            float slope);
 /* lnn_instnorm_lrelu_fwd + lnn_seg1x1_fwd of the same activation in one pass (decoder blocks that feed a seg_outputs head,
  * generic_ViT_UNet.py:263-264): logits (N,K,V) fp32 = seg_w (K,C) . z, computed from the fp16-rounded z the kernel writes.
- * K <= 8, C/8 a power of two <= 64; other shapes: call the two functions.  z may be NULL: only the logits are written (the last
- * decoder block of a training step: its normalised tensor has no other reader, the head's backward rebuilds it from y). */
+ * K <= 8, C/8 a power of two <= 64; other shapes: call the two functions.  z may be NULL: only the logits are written (for a
+ * caller with no other reader of the normalised tensor; the head's backward, lnn_instnorm_lrelu_seg_bwd, rebuilds it from y). */
 int lnn_instnorm_lrelu_seg_fwd(lnn_stream_t s, const void* y, void* z, int ld_z, int N, long V, int C, const float* mean,
                                const float* rstd, const float* gamma, const float* beta, float slope, const float* seg_w,
                                float* logits, int K);

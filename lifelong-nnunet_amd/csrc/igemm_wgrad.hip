@@ -93,260 +93,17 @@ __global__ __launch_bounds__(256) void wg_reduce_parts_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// v2 for the stride-1 3x3x3 case (2/3 of all wgrad FLOPs sit in the two highest resolutions): same MFMA /
-// transpose-read mapping, but (a) unpadded, unswizzled 64-byte LDS rows (4 consecutive rows x 64 B = one
-// conflict-free 256-byte bank row per 32 lanes; every read address = per-lane register + immediate),
-// (b) register prefetch: the next tile's global loads are issued before the MFMAs of the current tile, parked
-// in registers and written to LDS between two barriers afterwards; 54 KB LDS / block -> two blocks per CU,
-// so one block's staging and barriers are covered by the other block's MFMAs.
-// ------------------------------------------------------------------------------------------------
-// SHARE (default): the wave's taps are grouped by (dz, dy) ROWS so that the three dx taps of a row share their operand.
-// After the transposing read a lane holds one channel's 8 consecutive x positions of a halo row (4 dwords); the operand
-// of tap dx+1 is the same row shifted by one position.  One extra 8-byte read (positions 8..11) + 4 v_alignbit give all
-// three operands: 3 reads per 3 MFMAs instead of 6 (wave w: rows 2w, 2w+1, and tap dx = w of row 8 for w < 3:
-// 5 KB of LDS reads per 16-voxel chunk instead of 8 KB -- the kernel is LDS-bandwidth bound, 1.14 KB per MFMA before).
-template <bool SHARE>
-__global__ __launch_bounds__(256, 2) void igemm_wgrad_s1_v2_kernel(const WgradParams p) {
-    constexpr int TZ = 4, TY = 8, TX = 8, TV = TZ * TY * TX, PZ = 6, PY = 10, PX = 10, P = PZ * PY * PX, TPW = 7;
-    constexpr int QB = P * 64;
-    constexpr int QN = (P * 4 + 255) / 256, PN = TV * 4 / 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ql = smem;        // [P][64 B]   linear rows: 4 consecutive rows = one 256-byte bank row, so the
-    char* const pl = smem + QB;   // [TV][64 B]  transpose reads (4 voxels x 32 B per 16-lane group) are conflict free
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const WgBlock blk = wg_block(p);
-    const int m0 = (blk.panel / (p.Cpad / 32)) * 32, c0 = (blk.panel % (p.Cpad / 32)) * 32;
-    // Q = channel concatenation of two tensors (lnn_conv3d_wgrad_cat): this block's 32-channel panel lives in one of them
-    const half_t* const qsrc = c0 >= p.csplit ? p.q2 : p.q;
-    const int cq = c0 >= p.csplit ? c0 - p.csplit : c0;
-    const int hk = lane >> 5, cb = 16 * ((lane >> 4) & 1), sj = (lane & 15) >> 2, sq = lane & 3;
-    const int chb = (cb + 4 * sq) * 2;                 // byte offset of this lane's 4 channels inside a row
-    const int p_addr = (8 * hk + sj) * 64 + chb;       // + ch*1024 (+256 for the second read)
-    const int q_lane = (hk * PX + sj) * 64 + chb;      // + chunk-row offset + tap offset (+256)
-
-    floatx16 acc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-    const int t_begin = blk.chunk * p.tiles_per_block;
-    const int t_end = min(t_begin + p.tiles_per_block, p.tiles_total);
-    if (t_begin >= t_end) return;
-
-    // per-thread staging constants (tile independent): 32-bit offsets relative to the tile origin
-    int qrel[QN], prel0;      // P-tile loads: thread i*256+tid -> plane z = i of the tile, so prel[i] = prel0 + i*plane
-#pragma unroll
-    for (int i = 0; i < QN; ++i) {
-        const int idx = min(i * 256 + tid, P * 4 - 1);
-        const int pos = idx >> 2, c8 = idx & 3;
-        const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-        qrel[i] = ((pz * p.Qh + py) * p.Qw + px) * p.ld_q + c8 * 8;
-    }
-    {
-        const int vox = tid >> 2, c8 = tid & 3;
-        prel0 = ((vox / TX) * p.Lw + vox % TX) * p.ld_p + c8 * 8;
-    }
-    const int pplane = p.Lh * p.Lw * p.ld_p;
-
-    // unconditional loads + validity masks (see igemm_conv_v2.hip: predicated loads get serialised by hipcc)
-    half8 qr[QN], pr[PN];
-    unsigned qok = 0, pok = 0;
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto load_tile = [&](int tile) {
-        // z runs fastest: a block walks a column of tiles, so 2 of the 6 halo planes of a tile were fetched by the SAME
-        // block one tile earlier and come from the XCD's L2 instead of HBM (the level-0 layers move 3 TB/s here)
-        int t = tile;
-        const int tz = t % p.tiles_z; t /= p.tiles_z;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int n = t;
-        const int lz0 = tz * TZ, ly0 = ty * TY, lx0 = tx * TX;
-        const long qbase = ((((long)n * p.Qd + (lz0 - 1)) * p.Qh + (ly0 - 1)) * p.Qw + (lx0 - 1)) * p.ld_q + cq;
-        const long pbase = ((((long)n * p.Ld + lz0) * p.Lh + ly0) * p.Lw + lx0) * p.ld_p + m0;
-        const bool interior = lz0 >= 1 && ly0 >= 1 && lx0 >= 1 && lz0 + TZ + 1 <= p.Qd && ly0 + TY + 1 <= p.Qh &&
-                              lx0 + TX + 1 <= p.Qw && c0 + 32 <= p.C && m0 + 32 <= p.M;
-        if (interior) {
-            const half_t* qp = qsrc + qbase;
-            const half_t* pp = p.p + pbase;
-#pragma unroll
-            for (int i = 0; i < QN; ++i) qr[i] = *reinterpret_cast<const half8*>(qp + qrel[i]);
-#pragma unroll
-            for (int i = 0; i < PN; ++i) pr[i] = *reinterpret_cast<const half8*>(pp + i * pplane + prel0);
-            qok = 0xFFFFu; pok = 0xFFFFu;
-        } else {
-            qok = 0; pok = 0;
-#pragma unroll
-            for (int i = 0; i < QN; ++i) {
-                const int idx = min(i * 256 + tid, P * 4 - 1);
-                const int pos = idx >> 2, c8 = idx & 3;
-                const int px = pos % PX, py = (pos / PX) % PY, pz = pos / (PX * PY);
-                const int iz = lz0 - 1 + pz, iy = ly0 - 1 + py, ix = lx0 - 1 + px;
-                const bool ok = (unsigned)iz < (unsigned)p.Qd && (unsigned)iy < (unsigned)p.Qh && (unsigned)ix < (unsigned)p.Qw &&
-                                c0 + c8 * 8 < p.C;
-                qr[i] = *reinterpret_cast<const half8*>(qsrc + (ok ? qbase + qrel[i] : 0));
-                qok |= (ok ? 1u : 0u) << i;
-            }
-#pragma unroll
-            for (int i = 0; i < PN; ++i) {
-                const int idx = i * 256 + tid;
-                const int vox = idx >> 2, c8 = idx & 3;
-                const int x = vox % TX, y = (vox / TX) % TY, z = vox / (TX * TY);
-                const bool ok = lz0 + z < p.Ld && ly0 + y < p.Lh && lx0 + x < p.Lw && m0 + c8 * 8 < p.M;
-                pr[i] = *reinterpret_cast<const half8*>(p.p + (ok ? pbase + i * pplane + prel0 : 0));
-                pok |= (ok ? 1u : 0u) << i;
-            }
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < QN; ++i) {
-            const int idx = i * 256 + tid;
-            if (idx < P * 4) *reinterpret_cast<half8*>(ql + idx * 16) = ((qok >> i) & 1u) ? qr[i] : zero8;
-        }
-#pragma unroll
-        for (int i = 0; i < PN; ++i) {
-            const int idx = i * 256 + tid;
-            *reinterpret_cast<half8*>(pl + idx * 16) = ((pok >> i) & 1u) ? pr[i] : zero8;
-        }
-    };
-
-    // accumulator ti -> tap: SHARE: rows 2w (ti 0..2), 2w+1 (ti 3..5), row 8 dx = w (ti 6, w < 3); else taps w + 4 ti
-    const int uw = __builtin_amdgcn_readfirstlane(wave);
-    auto tap_of = [&](int ti) { return SHARE ? (ti < 6 ? (2 * uw + ti / 3) * 3 + ti % 3 : (uw < 3 ? 24 + uw : 27)) : uw + 4 * ti; };
-    int tapaddr[TPW];   // per-lane halo-tile byte address of this wave's taps (no table gather in the loop)
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = min(tap_of(ti), 26);
-        tapaddr[ti] = q_lane + (((tap / 9) * PY + (tap / 3) % 3) * PX + tap % 3) * 64;
-    }
-    load_tile(t_begin);
-    store_tile();
-    __syncthreads();
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};
-    const bool timed = (p.debug & 4) && p.dbgbuf;
-#pragma unroll 1
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const bool more = tile + 1 < t_end;
-        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-        if (timed) t0 = __builtin_readcyclecounter();
-        if (more) load_tile(tile + 1);
-        if (timed) t1 = __builtin_readcyclecounter();
-        // Software-pipelined operand reads.  hipcc schedules `ds_read; s_waitcnt lgkmcnt(0); v_mfma` back to back (the
-        // LDS latency of ~100 cycles then paces every 32-cycle MFMA: PMC showed the matrix pipe 43 % busy with 4 % LDS
-        // stalls and no HBM limit), so the reads are issued two MFMA groups ahead into rotating registers and pinned with
-        // sched_barrier.  The 7th accumulator of the wave that has only 6 taps runs on a duplicate tap and is dropped in
-        // the epilogue: no wave-dependent branches in the loop.
-        constexpr int NCH = TV / 16;
-        auto qrow = [&](int ch) { return (((2 * ch) / TY) * PY + (2 * ch) % TY) * PX * 64; };
-        half4 al[2], ah[2];
-        auto rdA = [&](int ch) {
-            al[ch & 1] = lds_tr16(pl + ch * 1024 + p_addr);
-            ah[ch & 1] = lds_tr16(pl + ch * 1024 + 256 + p_addr);
-        };
-        if (SHARE) {
-            // groups per chunk: row 2w (3 reads, 3 MFMAs), row 2w+1 (3, 3), single tap (2, 1)
-            uint2v g0[3], g1[3], g2[3];
-            auto rdG = [&](int g) {
-                const int ch = g / 3, k = g % 3, sl = g % 3;
-                const char* qa = ql + qrow(ch) + tapaddr[3 * k];
-                g0[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa));
-                g1[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 256));
-                if (k < 2) g2[sl] = __builtin_bit_cast(uint2v, lds_tr16(qa + 512));
-            };
-            rdA(0);
-            rdG(0);
-            rdG(1);
-#pragma unroll
-            for (int g = 0; g < 3 * NCH; ++g) {
-                const int ch = g / 3, k = g % 3, sl = g % 3;
-                if (g + 2 < 3 * NCH) rdG(g + 2);
-                if (k == 1 && ch + 1 < NCH) rdA(ch + 1);
-                const half8 a = {al[ch & 1][0], al[ch & 1][1], al[ch & 1][2], al[ch & 1][3],
-                                 ah[ch & 1][0], ah[ch & 1][1], ah[ch & 1][2], ah[ch & 1][3]};
-                const uint2v d01 = g0[sl], d23 = g1[sl], d45 = g2[sl];
-                const uint4v w0 = {d01[0], d01[1], d23[0], d23[1]};
-                if (k < 2) {
-                    const uint4v w1 = {__builtin_amdgcn_alignbit(d01[1], d01[0], 16), __builtin_amdgcn_alignbit(d23[0], d01[1], 16),
-                                       __builtin_amdgcn_alignbit(d23[1], d23[0], 16), __builtin_amdgcn_alignbit(d45[0], d23[1], 16)};
-                    const uint4v w2 = {d01[1], d23[0], d23[1], d45[0]};
-                    acc[3 * k + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[3 * k + 0], 0, 0, 0);
-                    acc[3 * k + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w1), acc[3 * k + 1], 0, 0, 0);
-                    acc[3 * k + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w2), acc[3 * k + 2], 0, 0, 0);
-                } else {
-                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, w0), acc[6], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            half4 bl[3], bh[3];
-            auto rdB = [&](int j) {
-                const int ch = j / TPW, ti = j % TPW;
-                bl[j % 3] = lds_tr16(ql + qrow(ch) + tapaddr[ti]);
-                bh[j % 3] = lds_tr16(ql + qrow(ch) + 256 + tapaddr[ti]);
-            };
-            rdA(0);
-            rdB(0);
-            rdB(1);
-#pragma unroll
-            for (int j = 0; j < NCH * TPW; ++j) {
-                const int ch = j / TPW, ti = j % TPW;
-                if (j + 2 < NCH * TPW) rdB(j + 2);
-                if (ti == 3 && ch + 1 < NCH) rdA(ch + 1);
-                const half8 a = {al[ch & 1][0], al[ch & 1][1], al[ch & 1][2], al[ch & 1][3],
-                                 ah[ch & 1][0], ah[ch & 1][1], ah[ch & 1][2], ah[ch & 1][3]};
-                const half8 b = {bl[j % 3][0], bl[j % 3][1], bl[j % 3][2], bl[j % 3][3], bh[j % 3][0], bh[j % 3][1], bh[j % 3][2], bh[j % 3][3]};
-                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (timed) t2 = __builtin_readcyclecounter();
-        __syncthreads();                 // every wave is done reading this tile
-        if (timed) t3 = __builtin_readcyclecounter();
-        if (more) store_tile();
-        if (timed) t4 = __builtin_readcyclecounter();
-        __syncthreads();
-        if (timed) {
-            const unsigned long long t5 = __builtin_readcyclecounter();
-            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4;
-        }
-    }
-    if (timed && lane == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(p.dbgbuf + i, ph[i]);
-        atomicAdd(p.dbgbuf + 5, (unsigned long long)(t_end - t_begin));
-    }
-    const int c = c0 + (lane & 31);
-    if (p.debug & 1) {
-        if (acc[0][0] == 12345.678f) p.dwp[0] = acc[1][0] + acc[2][0] + acc[3][0] + acc[4][0] + acc[5][0] + acc[6][0];
-        return;
-    }
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int tap = tap_of(ti);
-        if (tap < 27) {
-            const long pbase_ = (long)tap * p.Mpad * p.Cpad;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 8 * (r >> 2) + 4 * hk + (r & 3);
-                wg_out(p, blk.chunk, 0, pbase_ + (long)m * p.Cpad + c, acc[ti][r]);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Stride-2 gathers (wgrad of the stride-2 3x3x3 conv, EXT = 3, pad 1; wgrad of the 2x2x2 stride-2 transposed conv,
 // EXT = 2, pad 0):  DWP[tap][m][c] += sum_l P[l, m] * Q[2l + d - pad, c].
 // The generic kernel staged a 5x9x17-position Q tile per 64 loop voxels and per 32 P channels and read it with a
 // 128-byte lane stride (2-way bank conflicts); these layers are bound by the Q read (4x the P operand), so:
 //   * the Q tile is stored in LDS as EIGHT PARITY SUB-TILES (z, y, x parity of the position): tap d reads sub-tile
 //     (d & 1 per dimension) at loop coordinate l + (d >> 1) with UNIT stride, i.e. exactly the conflict-free
-//     linear-64-byte-row pattern of the stride-1 kernel above;
+//     linear-64-byte-row pattern of the stride-1 kernels;
 //   * one block owns TWO 32-row P panels (64 P channels) x one 32-column Q panel: the Q tile is read from HBM once
 //     per 64 output rows;
 //   * 512 threads (8 waves, taps wave, wave+8, ...: <= 4 taps x 2 panels = 8 accumulators), one block per CU,
-//     register prefetch of the next tile as in the stride-1 kernel.
+//     register prefetch of the next tile (global loads issued before the MFMAs of the current tile, written to LDS between two barriers).
 // ------------------------------------------------------------------------------------------------
 template <int EXT>
 __global__ __launch_bounds__(512, 2) void igemm_wgrad_s2_v2_kernel(const WgradParams p) {
@@ -1202,42 +959,6 @@ int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
     return wg_reduce_parts(s, p, chunks, slot_elems, "lnn_conv3d_wgrad(s1,v5,reduce)");
 }
 
-int launch_wgrad_s1_v2(hipStream_t s, WgradParams& p) {
-    constexpr int TZ = 4, TY = 8, TX = 8;
-    p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
-    p.tiles_total = p.N * p.tiles_z * p.tiles_y * p.tiles_x;
-    const int panels = (p.Mpad / 32) * (p.Cpad / 32);
-    // two blocks per CU (54 KB LDS each): spread tiles x panels over ~512 blocks, >= 1 tile per block
-    int tpb = lnn_cdiv((long)p.tiles_total * panels, 512);
-    if (tpb < 1) tpb = 1;
-    if (tpb > p.tiles_total) tpb = p.tiles_total;
-    p.tiles_per_block = tpb;
-    const size_t lds = (size_t)(600 + 256) * 64;
-    static int share = -1;          // LNN_WGRAD_NOSHARE=1: the per-tap operand reads of round 1 (A/B measurements)
-    if (share < 0) {
-        const char* e = getenv("LNN_WGRAD_NOSHARE");
-        share = (e && e[0] == '1') ? 0 : 1;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("LNN_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; }
-    p.debug = dbg;
-    static unsigned long long* dbgbuf = nullptr;
-    if ((dbg & 4) && !dbgbuf) { const char* e = getenv("LNN_WGRAD_PHASEBUF"); if (e) dbgbuf = (unsigned long long*)strtoull(e, nullptr, 0); }
-    p.dbgbuf = dbgbuf;
-    if (dbg & 2) { tpb = lnn_cdiv((long)p.tiles_total * panels, 256); if (tpb > p.tiles_total) tpb = p.tiles_total; p.tiles_per_block = tpb; }
-    dim3 grid((unsigned)lnn_cdiv(p.tiles_total, tpb), (unsigned)panels);
-    // operand sharing pays where the launch is LDS-bound (deeper layers: +5..10 %); the two level-0 shapes with 1-2 panels are
-    // bound by the halo traffic (PMC: 2.5x algorithmic at 3.3 TB/s) and lose 4-8 % to the extra VALU work
-    const long slot_elems = 27L * p.Mpad * p.Cpad;
-    if (int e = wg_prepare_parts(p, grid.x, 1, slot_elems, "lnn_conv3d_wgrad(s1,v2)")) return e;
-    if (share && panels >= 4) hipLaunchKernelGGL((igemm_wgrad_s1_v2_kernel<true>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((igemm_wgrad_s1_v2_kernel<false>), grid, dim3(256), lds, s, p);
-    LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v2)");
-    return wg_reduce_parts(s, p, grid.x, slot_elems, "lnn_conv3d_wgrad(s1,v2,reduce)");
-}
-
 template <int EXT>
 int launch_wgrad_s2_v2(hipStream_t s, WgradParams& p, const char* name) {
     constexpr int TY = 8, TX = 8;
@@ -1391,12 +1112,12 @@ int conv3d_wgrad_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, i
             p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
             p.taps.slot[t] = (unsigned char)t;
         }
-        static int use_v2 = -1;          // LNN_WGRAD_V2=1: the register-prefetch kernel (kept: fallback for >2 GB plane sets, A/B measurements, tests)
-        if (use_v2 < 0) { const char* e = getenv("LNN_WGRAD_V2"); use_v2 = (e && e[0] == '1') ? 1 : 0; }
-        // the DMA descriptors address a tile with 32-bit offsets relative to its origin: 6 input planes must stay below 2 GB
-        const bool dma_ok = 6L * p.Qh * p.Qw * p.ld_q * 2 < 0x7fffffffL && 4L * p.Lh * p.Lw * p.ld_p * 2 < 0x7fffffffL;
-        if (!use_v2 && dma_ok) return launch_wgrad_s1_v5(s, p);
-        return launch_wgrad_s1_v2(s, p);
+        // the DMA descriptors address a tile with 32-bit offsets relative to its origin: 6 input planes must stay below 2 GB (a
+        // z-plane of 350 MB -- no 3-D patch comes near; the register-prefetch kernel that used to take such shapes, 24 spilled
+        // registers in its loop, was deleted in round 5)
+        LNN_REQUIRE(6L * p.Qh * p.Qw * p.ld_q * 2 < 0x7fffffffL && 4L * p.Lh * p.Lw * p.ld_p * 2 < 0x7fffffffL,
+                    "lnn_conv3d_wgrad: a z-plane of %ld bytes is beyond the 2 GB window of the tile descriptors", (long)p.Qh * p.Qw * p.ld_q * 2);
+        return launch_wgrad_s1_v5(s, p);
     }
     return launch_wgrad_s2<3>(s, p, "lnn_conv3d_wgrad(s2)");
 }

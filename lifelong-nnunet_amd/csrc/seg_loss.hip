@@ -718,7 +718,9 @@ extern "C" int lnn_seg1x1_fwd(lnn_stream_t s_, const void* z, int ld_z, const fl
     LNN_REQUIRE(z && lnn_aligned16(z) && w && logits, "lnn_seg1x1_fwd: null/misaligned pointer");
     LNN_REQUIRE(C % 8 == 0 && ld_z >= C && ld_z % 8 == 0, "lnn_seg1x1_fwd: bad channel count / ld");
     LNN_REQUIRE(K >= 1 && K <= KMAX, "lnn_seg1x1_fwd: K=%d unsupported (max %d)", K, KMAX);
-    if (C <= 512) {
+    // (128 channels and more: up to 4 voxels per wave and pass.  Below, a voxel's channels are 1-4 loads of the voxel-per-thread
+    // kernel, whose logits stores are fully coalesced; this one writes 64-byte pieces)
+    if (C >= 128 && C <= 512) {
         int G = 1;
         while (G < C / 8) G <<= 1;
         const long NV = (long)N * V, waves = (NV + 64 / G - 1) / (64 / G);

@@ -409,14 +409,6 @@ class UNetEngine:
         self._pack_desc = torch.tensor(pk, dtype=torch.int64, device=dev)
         self._unpack_desc = torch.tensor(up, dtype=torch.int64, device=dev)
         self._pack_total, self._unpack_total = pk_total, up_total
-        # the same table in two parts -- the first block's panels / everything else -- for the overlapped re-pack of forward()
-        k0 = 1 if order[0].cin_k == 1 else 2
-        first0 = pk[k0][8] if len(pk) > k0 else pk_total
-        self._pack_desc_a = torch.tensor(pk[:k0], dtype=torch.int64, device=dev)
-        self._pack_total_a = first0
-        self._pack_desc_b = torch.tensor([r[:8] + [r[8] - first0] for r in pk[k0:]], dtype=torch.int64, device=dev) if len(pk) > k0 else None
-        self._pack_total_b = pk_total - first0
-        self._pack_event = None
         cmax = max(2 * f for f in feats)
         ws_doubles = max(nat.query("lnn_instnorm_ws_doubles", N, cmax), (nat.query("lnn_seg1x1_bwd_ws_floats", N, cmax) + 1) // 2,
                          nat.query("lnn_instnorm_lrelu_seg_bwd_ws_doubles", N, max(seg.cin for seg in self.segs)), 64)
@@ -461,10 +453,6 @@ class UNetEngine:
         self._sides = {}
         # A/B switches of round 5 (measurements only; see backward / forward)
         self.c1_wgrad_stream = os.environ.get("LNN_NO_C1_WGRAD_STREAM", "0") != "1"
-        self.pack_overlap = os.environ.get("LNN_NO_PACK_OVERLAP", "0") != "1"
-        self.lazy_top_z = os.environ.get("LNN_NO_LAZY_TOP_Z", "0") != "1"
-        self._top_block = self.segs[-1].x_block
-        self._top_z_valid = False
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
@@ -522,31 +510,13 @@ class UNetEngine:
         return _Ptr(self.gpanels, off)
 
     # ------------------------------------------------------------------------------------------ pack
-    def pack_weights(self, overlap=False):
-        """fp32 parameter arena -> fp16 MFMA panels of every layer, one launch.  ``overlap`` (a training forward): the first block's
-        panels on the current stream, all others on a side stream next to the first block's HBM-bound kernels (image cast, C = 1
-        convolution, its normalisation pass); forward() waits for them in front of the second block."""
-        if overlap and self.pack_overlap and self._pack_desc_b is not None and self.theta.is_cuda:
-            nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc_a, self._pack_desc_a.shape[0],
-                     self._pack_total_a)
-            main, side = torch.cuda.current_stream(), self._side_stream(2)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc_b, self._pack_desc_b.shape[0],
-                         self._pack_total_b)
-                self._pack_event = torch.cuda.Event()
-                self._pack_event.record(side)
-        else:
-            nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc, self._pack_desc.shape[0],
-                     self._pack_total)
+    def pack_weights(self):
+        """fp32 parameter arena -> fp16 MFMA panels of every layer, one launch.  (Round 5 measured the re-pack of all panels but the
+        first block's on a side stream next to the first block's kernels: the 98-us pack and the C = 1 convolution are both
+        HBM-bound and slowed each other down -- 119 + 357 us side by side against 98 + 190 in sequence; not kept.)"""
+        nat.call("lnn_pack_weights_batched", self.theta, self.wpanels, self._pack_desc, self._pack_desc.shape[0],
+                 self._pack_total)
         self.packed_version = self.arena.version
-
-    def _await_pack(self):
-        if self._pack_event is not None:
-            torch.cuda.current_stream().wait_event(self._pack_event)
-            self._pack_event = None
 
     def unpack_wgrads(self):
         """fp32 wgrad panels of every layer += into the gradient arena (PyTorch layouts), one launch."""
@@ -570,7 +540,7 @@ class UNetEngine:
         assert tuple(x.shape) == (N, self.in_channels) + self.patch, \
             f"engine built for {(N, self.in_channels) + self.patch}, got {tuple(x.shape)}"
         if self.packed_version != self.arena.version:
-            self.pack_weights(overlap=body)
+            self.pack_weights()
         if body:
             if self.c1_path:
                 nat.call("lnn_cast_f32_to_h", x.contiguous(), self.image, x.numel())
@@ -582,8 +552,6 @@ class UNetEngine:
         u = 0
         fused_segs = set()
         for item in self.order:
-            if item is not self.order[0]:
-                self._await_pack()                 # (everything behind the first block reads panels the side stream may still be writing)
             if isinstance(item, ConvBlock):
                 if not body:
                     continue
@@ -616,24 +584,19 @@ class UNetEngine:
                     nat.call("lnn_instnorm_stats", item.y, N, V, C, IN_EPS, mean, rstd, ws)
                 seg = self._seg_after.get(id(item))
                 if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
-                    # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y.  The
-                    # LAST block's normalised tensor has no other reader in a training step (the head's backward rebuilds it from
-                    # y, lnn_instnorm_lrelu_seg_bwd): it is not written (0.63 GB at the top level of the 160x192x160 plan) and
-                    # produced on demand by materialise_top_z() for the callers that read it (multi-head evaluation, body=False)
-                    lazy = item is self._top_block and self.lazy_top_z
+                    # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y
+                    # (measured in round 5: NOT writing the last block's normalised tensor -- nobody reads it in a plain training
+                    # step -- changes nothing, 20.01 vs 20.02 / 19.94 ms: the pass is bound by its instruction stream, not by its
+                    # stores, and LwF's old heads do read it)
                     self._probed("in_fwd", item, lambda: nat.call(
-                        "lnn_instnorm_lrelu_seg_fwd", item.y, None if lazy else item.z, item.z.ld, N, V, C, mean, rstd,
+                        "lnn_instnorm_lrelu_seg_fwd", item.y, item.z, item.z.ld, N, V, C, mean, rstd,
                         self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, self.pview(seg.w),
                         logits[self.segs.index(seg)], self.K))
                     fused_segs.add(id(seg))
-                    if item is self._top_block:
-                        self._top_z_valid = not lazy
                 else:
                     self._probed("in_fwd", item, lambda: nat.call(
                         "lnn_instnorm_lrelu_fwd", item.y, item.z, item.z.ld, N, V, C, mean, rstd,
                         self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE))
-                    if item is self._top_block:
-                        self._top_z_valid = True
             elif isinstance(item, UpBlock):
                 if not body:
                     continue
@@ -648,21 +611,10 @@ class UNetEngine:
                         item.y.ld, N, D, H, W, item.cin, item.cout, *item.strides, splitk_ws, splitk_ws.numel()))
             else:
                 if id(item) not in fused_segs:
-                    if item.x_block is self._top_block:
-                        self.materialise_top_z()
                     w = self.pview(item.w) if sw is None else sw[u]
                     nat.call("lnn_seg1x1_fwd", item.x, item.x.ld, w, logits[u], N, item.x.V, item.cin, self.K)
                 u += 1
         return logits
-
-    def materialise_top_z(self):
-        """The normalised output of the last decoder block, if the forward skipped writing it (see forward)."""
-        if self._top_z_valid:
-            return
-        b = self._top_block
-        nat.call("lnn_instnorm_lrelu_fwd", b.y, b.z, b.z.ld, self.N, b.z.V, b.cout, b.mean, b.rstd,
-                 self.pview(b.gamma), self.pview(b.beta), LRELU_SLOPE)
-        self._top_z_valid = True
 
     def conv_outputs(self, logits):
         """name -> (N,C,D,H,W) strided VIEW of the output of every conv / transposed conv / seg head of the LAST forward,
@@ -697,7 +649,6 @@ class UNetEngine:
         """dlogits[u]: gradient wrt ``logits[u]`` (fp32, already carrying the loss scale) or None.
         Accumulates parameter gradients into the flat arena ``self.grad`` (scaled like dlogits)."""
         N = self.N
-        self._await_pack()
         self.gpanels.zero_()
         self.unused_heads = [seg.w.name for seg, dl in zip(self.segs, dlogits) if dl is None]
         dls = [None if dl is None else dl.contiguous() for dl in dlogits]
@@ -766,8 +717,6 @@ class UNetEngine:
                 if fuse_seg:
                     pending[id(item.x_block)] = (item, dl)
                     continue
-                if item.x_block is self._top_block:
-                    self.materialise_top_z()
                 gw = self.pview(item.w, self.grad).view(self.K, item.cin)
                 nat.call("lnn_seg1x1_bwd", item.x, item.x.ld, self.pview(item.w), dl, item.gx,
                          item.gx.ld, gw, N, item.x.V, item.cin, self.K, 1 if item.gx_has_prior else 0, 1.0, ws)
@@ -906,9 +855,18 @@ class UNetEngine:
             self.unpack_wgrads()
 
     def _side_stream(self, i=0):
-        st = self._sides.get(i)
+        """Side HIP stream ``i`` of this engine's device: 0 = weight gradients, 1 = the first layer's weight gradient.  PROCESS-WIDE, shared by every engine: the runtime multiplexes
+        streams onto a handful of hardware queues, and an engine whose side stream lands on the queue of its main stream loses
+        the overlap it exists for (measured in round 5: the trainers built later in one process -- each engine with three streams
+        of its own -- ran 1 ms per step slower)."""
+        idx = self.device.index
+        if idx is None:
+            idx = torch.cuda.current_device() if self.device.type == "cuda" else -1
+        key = (idx, i)
+        st = _SIDE_STREAMS.get(key)
         if st is None:
-            st = self._sides[i] = torch.cuda.Stream(device=self.device)
+            st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.device)
+        self._sides[i] = st
         return st
 
     # ------------------------------------------------------------------------------------------ stats
@@ -927,6 +885,9 @@ class UNetEngine:
             else:
                 mac += item.x.V * item.cin * self.K
         return 6 * mac - 2 * first, mac
+
+
+_SIDE_STREAMS = {}      # (device index, i) -> torch.cuda.Stream, see UNetEngine._side_stream
 
 
 class _Ptr:

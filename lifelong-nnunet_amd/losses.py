@@ -161,7 +161,9 @@ class _EWCPenaltyFunction(torch.autograd.Function):
     bucket it sends already holds the penalty's share -- replica-identical, so sum / world preserves it."""
 
     @staticmethod
-    def forward(ctx, base, arena, fishers, stars, ewc_lambda, net=None, touched=()):
+    def forward(ctx, base, anchor, arena, fishers, stars, ewc_lambda, net=None, touched=()):
+        # ``anchor``: one penalised parameter that requires grad -- it makes the result differentiable when ``base`` is not (a loss
+        # object called on logits that carry no graph); its gradient, like every parameter's, is written into the arena directly
         ctx.net, ctx.touched = net, touched
         ws = torch.empty(nat.query("lnn_flat_reduce_ws_doubles"), dtype=torch.float64, device=arena.theta.device)
         total = base.detach().reshape(()).to(arena.theta.device, torch.float32)
@@ -182,7 +184,7 @@ class _EWCPenaltyFunction(torch.autograd.Function):
             # the network's own backward never touches: clip_grad_norm_ counts it and SGD steps it (weight decay, momentum,
             # the pull towards theta*) -- optim._ranges must not skip it
             ctx.net.penalty_grad_names = set(getattr(ctx.net, "penalty_grad_names", ())) | set(ctx.touched)
-        return g, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None
 
 
 class MultipleOutputLossEWC(MultipleOutputLoss2):
@@ -230,7 +232,7 @@ class MultipleOutputLossEWC(MultipleOutputLoss2):
         """``base`` + sum over ``self.tasks`` of lam/2 * sum F_t (theta - theta*_t)^2 (``base`` itself when nothing applies)."""
         if len(self.tasks) == 0 or self.network_params is None:
             return base
-        fishers, stars, arena, net, touched = [], [], None, None, set()
+        fishers, stars, arena, net, touched, anchor = [], [], None, None, set(), None
         for task in self.tasks:
             # deep_supervision.py:65-66: the task loop is outermost and ``network_params`` is whatever the
             # trainer handed over -- a *generator* for the base EWC trainer (ewc/nnUNetTrainerEWC.py:140,247),
@@ -241,12 +243,13 @@ class MultipleOutputLossEWC(MultipleOutputLoss2):
             net = named[0][1]._lnn_net
             arena = net.arena
             touched |= {n for n, p in named if p.requires_grad and self._selected(n)}
+            anchor = next((p for _, p in named if p.requires_grad), named[0][1])
             F, S = self._flat_for(task, named, arena)
             fishers.append(F)
             stars.append(S)
         if not fishers:
             return base
-        return _EWCPenaltyFunction.apply(base, arena, fishers, stars, lam, net, frozenset(touched))
+        return _EWCPenaltyFunction.apply(base, anchor, arena, fishers, stars, lam, net, frozenset(touched))
 
     def forward(self, x, y, reg=True):
         loss = super().forward(x, y)

@@ -38,9 +38,15 @@ class GradAllReducer:
         self.buckets = make_buckets(grad.numel(), max(1, bucket_bytes // grad.element_size()))
         # host tensors (gloo, CPU tests): the same watermark-driven bucket order, each all-reduce simply runs in line
         self.overlap = overlap
-        self.stream = torch.cuda.Stream() if grad.is_cuda else None
+        self._stream = None     # created on first use: the buckets normally leave from the engine's weight-gradient stream
         self.next = 0
         self._used = set()
+
+    @property
+    def stream(self):
+        if self._stream is None and self.grad.is_cuda:
+            self._stream = torch.cuda.Stream()
+        return self._stream
 
     @property
     def averaging_factor(self) -> float:
@@ -81,7 +87,7 @@ class GradAllReducer:
             self._launch(*self.buckets[self.next])
             self.next += 1
         if self.active:
-            for st in (self._used | ({self.stream} if self.stream is not None else set())):
+            for st in self._used:
                 torch.cuda.current_stream().wait_stream(st)
 
 

@@ -98,11 +98,16 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
             target = [torch.as_tensor(t).to(self.device) for t in data_dict['target']]
             output = self.network(data)
             loss = self.loss(output, target)
-            if self.dp is not None:
+            # parity mode squares the ALL-REDUCED gradient (exchanged during this backward like a training iteration's);
+            # accumulate mode squares each rank's OWN gradient: no exchange
+            exchange = self.dp is not None and self.fisher_mode != "accumulate"
+            if exchange:
                 self.dp.begin()
+                self.network.on_grad_progress = self.dp.progress
             self.amp_grad_scaler.scale(loss).backward()
-            if self.dp is not None and self.fisher_mode != "accumulate":
-                self.dp.finish()                            # parity mode squares the ALL-REDUCED gradient
+            if exchange:
+                self.network.on_grad_progress = None
+                self.dp.finish()
             if self.fisher_mode == "accumulate":
                 nat.call("lnn_fisher_accumulate", arena.grad, facc, arena.size, unscale, 1.0 / n)
         if self.fisher_mode == "accumulate":

@@ -249,6 +249,7 @@ class nnUNetTrainerMultiHead:
             self.amp_grad_scaler.backward(l)           # = scale(l).backward(), the scale as the seed gradient
             world_avg = 1.0
             if self.dp is not None:
+                self.network.on_grad_progress = None   # (a backward outside run_iteration exchanges nothing unless it asks to)
                 self.dp.finish()
                 world_avg = self.dp.averaging_factor
             inv = world_avg / scale

@@ -59,6 +59,7 @@ def dry(monkeypatch):
     def fake_call(name, *args):
         _REC.append(("call", name, _CUR[-1].name, args))
 
+    monkeypatch.setattr(eng_mod, "_SIDE_STREAMS", {})
     monkeypatch.setattr(nat, "call", fake_call)
     monkeypatch.setattr(nat, "call_plain", lambda name, *a: _REC.append(("plain", name, a)))
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _CUR[-1])
@@ -78,38 +79,26 @@ def _calls(rec, prefix=None):
     return [r for r in rec if r[0] == "call" and (prefix is None or r[1].startswith(prefix))]
 
 
-def test_forward_writes_no_normalised_tensor_for_the_last_block_and_materialises_it_on_demand(dry):
+def test_forward_plan_of_a_training_step(dry):
+    """One fused normalise + head pass per decoder level whose channel count allows it (every level here), each writing its block's
+    normalised tensor (the next level's transposed convolution / LwF's old heads read it); explicit head weights take the unfused
+    pair; body=False re-evaluates heads on the stored activations without touching the body."""
     net, eng = _engine()
     x = torch.zeros(2, 1, 16, 16, 16)
     logits = eng.forward(x)
     assert len(logits) == 3
     segf = _calls(dry, "lnn_instnorm_lrelu_seg_fwd")
-    assert len(segf) == 3                                   # one fused normalise + head pass per decoder level
-    top = eng.segs[-1].x_block
-    zs = [c[3][1] for c in segf]                            # the z argument
-    assert zs[-1] is None and all(z is not None for z in zs[:-1]) and not eng._top_z_valid
-    # the plain normalisation pass never targets the top block in a training forward
-    assert all(c[3][0] is not top.y for c in _calls(dry, "lnn_instnorm_lrelu_fwd"))
-    # a second head evaluated on the stored body activations (LwF / multi-head validation) reads z: produced first, once
+    assert len(segf) == 3 and all(c[3][1] is not None for c in segf)
+    nconv = sum(isinstance(i, ConvBlock) for i in eng.order)
+    assert len(_calls(dry, "lnn_instnorm_lrelu_fwd")) == nconv - 3 and not _calls(dry, "lnn_seg1x1_fwd")
     dry.clear()
     w = [torch.zeros(3, s.cin, 1, 1, 1) for s in eng.segs]
     eng.forward(x, seg_weights=w, body=False)
-    names = [c[1] for c in _calls(dry)]
-    assert names.count("lnn_instnorm_lrelu_fwd") == 1 and names.count("lnn_seg1x1_fwd") == 3
-    assert names.index("lnn_instnorm_lrelu_fwd") < len(names) - 1 - names[::-1].index("lnn_seg1x1_fwd")
-    mat = _calls(dry, "lnn_instnorm_lrelu_fwd")[0]
-    assert mat[3][0] is top.y and mat[3][1] is top.z and eng._top_z_valid
-    dry.clear()
-    eng.forward(x, seg_weights=w, body=False)
-    assert not _calls(dry, "lnn_instnorm_lrelu_fwd")
-    # a forward with explicit head weights takes the unfused path and writes z itself
+    assert [c[1] for c in _calls(dry)] == ["lnn_seg1x1_fwd"] * 3
     dry.clear()
     eng.forward(x, seg_weights=w, body=True)
-    assert eng._top_z_valid and not _calls(dry, "lnn_instnorm_lrelu_seg_fwd")
-    eng.lazy_top_z = False
-    dry.clear()
-    eng.forward(x)
-    assert _calls(dry, "lnn_instnorm_lrelu_seg_fwd")[-1][3][1] is top.z and eng._top_z_valid
+    assert not _calls(dry, "lnn_instnorm_lrelu_seg_fwd") and len(_calls(dry, "lnn_seg1x1_fwd")) == 3
+    assert len(_calls(dry, "lnn_instnorm_lrelu_fwd")) == nconv
 
 
 def _wgrads(rec):
@@ -223,35 +212,3 @@ def test_deferred_loss_fetch_keeps_the_grad_scaler_semantics(dry, monkeypatch):
             tr._finish_pending_step()
             scales[mode][-1] = tr.amp_grad_scaler.get_scale()
     assert scales["eager"] == scales["deferred"] == [65536.0, 65536.0, 65536.0, 32768.0, 32768.0, 32768.0]
-
-
-def test_training_forward_repacks_the_weights_next_to_the_first_block(dry, monkeypatch):
-    """After an optimiser step the fp16 panels are rebuilt by the next forward: the first block's on the forward's stream, all others
-    on a side stream, and the forward waits for that stream before the first launch of the SECOND block -- never later."""
-    net, eng = _engine()
-    monkeypatch.setattr(type(eng.theta), "is_cuda", property(lambda self: True), raising=False)
-    x = torch.zeros(2, 1, 16, 16, 16)
-    eng.forward(x)
-    packs = [(i, r) for i, r in enumerate(dry) if r[0] == "call" and r[1] == "lnn_pack_weights_batched"]
-    assert [r[2] for _, r in packs] == ["main", "side1"]
-    na, nb = packs[0][1][3][3], packs[1][1][3][3]
-    assert na == 1 and na + nb == eng._pack_desc.shape[0]
-    assert packs[0][1][3][4] + packs[1][1][3][4] == eng._pack_total
-    # rebased work offsets of the second table
-    assert int(eng._pack_desc_b[0, 8]) == 0 and int(eng._pack_desc_b[-1, 8]) == int(eng._pack_desc[-1, 8]) - int(eng._pack_desc[1, 8])
-    waits = [i for i, r in enumerate(dry) if r[0] == "wait_event" and r[1] == "main"]
-    assert len(waits) == 1
-    second = eng.order[1]
-    first_of_second = min(i for i, r in enumerate(dry) if r[0] == "call" and any(a is second.y for a in r[3]))
-    first_block_calls = [i for i, r in enumerate(dry) if r[0] == "call" and any(a is eng.order[0].y for a in r[3])]
-    assert max(first_block_calls) < waits[0] < first_of_second
-    # nothing to re-pack: no further pack launches, no waits
-    dry.clear()
-    eng.forward(x)
-    assert not [r for r in dry if r[0] == "wait_event" or (r[0] == "call" and r[1] == "lnn_pack_weights_batched")]
-    # an evaluation of stored activations (body=False) after a parameter change packs in line
-    net.mark_params_changed()
-    dry.clear()
-    eng.forward(x, seg_weights=[torch.zeros(3, sg.cin, 1, 1, 1) for sg in eng.segs], body=False)
-    packs = [r for r in dry if r[0] == "call" and r[1] == "lnn_pack_weights_batched"]
-    assert len(packs) == 1 and packs[0][2] == "main" and packs[0][3][3] == eng._pack_desc.shape[0]
