@@ -697,6 +697,7 @@ class UNetEngine:
                 nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), nt, C, K, K * nt, nt, 1, 1.0, 1)
 
         fuse_seg = self.fuse_seg_bwd and not skip_body and not self.numeric_conv_bias_grad and self.K <= 4
+        exp_lazy, lazy_events = os.environ.get("LNN_EXP_LAZY_IN", "0") == "1", {}
         seg_u = len(self.segs)
         pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
         presummed = set()     # id(block): pass 1 of its normalisation backward was taken by the data gradient that produced its dL/dz
@@ -724,6 +725,8 @@ class UNetEngine:
                 continue
             elif isinstance(item, ConvBlock):
                 V, K, C = item.z.V, item.cout, item.cin_k
+                if id(item) in lazy_events:
+                    main.wait_event(lazy_events.pop(id(item)))
                 if id(item) in pending:
                     seg, dl = pending.pop(id(item))
                     self._probed("in_bwd", item, lambda: nat.call(
@@ -767,6 +770,17 @@ class UNetEngine:
                 ldx = 1 if item.x is None else item.x.ld
 
                 def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
+                    xb = item.x_block
+                    if exp_lazy and xb is not None and xb.cout == 32 and item.stride == 1 and item.iso and side is not None:
+                        # EXPERIMENT (LNN_EXP_LAZY_IN=1, measurement only): what a normalise-on-load forward would add to the
+                        # backward -- the predecessor's normalised tensor produced here, on the side stream, in front of the weight
+                        # gradient that reads it (the pass is a duplicate today: z is recomputed from the still intact y, results
+                        # unchanged); the main stream waits for it before it overwrites y with dL/dy
+                        nat.call("lnn_instnorm_lrelu_fwd", xb.y, xb.z, xb.z.ld, N, xb.z.V, xb.cout, xb.mean, xb.rstd,
+                                 self.pview(xb.gamma), self.pview(xb.beta), LRELU_SLOPE)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        lazy_events[id(xb)] = ev
                     self._probed("wgrad", item, lambda: conv_wgrad_call(item, xin, ldx, K, C, D, H, W))
                     if per_layer_unpack:
                         unpack(item)
