@@ -737,6 +737,8 @@ def main():
                 dt_h, _ = timed(args.steps)
                 tr.tr_gen = keep
                 nbytes = sum(t.numel() * t.element_size() for t in [items[0]["data"]] + list(items[0]["target"]))
+                # top-level twins of value / ms_per_step with the host-to-device copy of every batch inside the iteration
+                out["value_h2d_inclusive"], out["ms_per_step_h2d_inclusive"] = B * args.steps / dt_h, dt_h / args.steps * 1e3
                 out["config"]["h2d_inclusive"] = {"ms_per_step": dt_h / args.steps * 1e3, "value": B * args.steps / dt_h,
                                                   "host_bytes_per_step": nbytes,
                                                   "how": "pinned host buffers, copy of batch i+1 on a side stream during step i"}

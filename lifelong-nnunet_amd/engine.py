@@ -451,8 +451,6 @@ class UNetEngine:
         self.packed_version = -1
         self.unused_heads: List[str] = []
         self._sides = {}
-        # A/B switches of round 5 (measurements only; see backward / forward)
-        self.c1_wgrad_stream = os.environ.get("LNN_NO_C1_WGRAD_STREAM", "0") != "1"
         self.overlap_wgrad = os.environ.get("LNN_NO_WGRAD_OVERLAP", "0") != "1"
         # the conv-bias gradient in front of an InstanceNorm is sum_v dy = 0 analytically; True sums the fp16 rounding noise of dy
         # the way autograd does (one more block reduction + launch per layer).  Either way the optimiser steps the bias
@@ -660,23 +658,17 @@ class UNetEngine:
         # gradient arena there too, and the all-reduce of every bucket that became final is launched FROM the side stream
         # (parallel.GradAllReducer.progress): two streams share the chip, as in the single-GPU plan
         side = self._side_stream() if self.overlap_wgrad else None
-        # The first layer's weight gradient (HBM-bound: it streams dL/dz and y of the full-resolution block) gets a stream of its own:
-        # it is the last launch of backward and would otherwise queue BEHIND the MFMA-bound weight gradient of the second block
-        # while the main stream has nothing left to run (profiles/r05_step_timeline_before.txt: 0.83 ms of the step with one
-        # stream busy); side by side the two share a CU's registers and LDS (156 + 2 x 175 VGPRs per SIMD, 21 + 116 KB).  Single-GPU
-        # plan only: with the data-parallel exchange or the ordered (deterministic) reduction all weight gradients keep one stream.
-        side_c1 = self._side_stream(1) if (side is not None and self.c1_wgrad_stream and progress is None
-                                           and not self.deterministic_wgrad) else side
-
-        def on_side(fn, st=None):
-            st = side if st is None else st
-            if st is None:
+        def on_side(fn):
+            # (round 5 also measured the first layer's HBM-bound weight gradient on a stream of its own, next to the second block's
+            # MFMA-bound one instead of behind it: the trace's tail shrank by 0.17 ms, the step by 0.00-0.04 ms -- the two kernels
+            # slow each other down; not kept, profiles/r05_switches_ab.txt)
+            if side is None:
                 fn()
                 return
             ev = torch.cuda.Event()
             ev.record(main)
-            st.wait_event(ev)
-            with torch.cuda.stream(st):
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
                 fn()
 
         # the DP all-reduce overlaps with backward and needs every layer's gradient final as soon as its wgrad is:
@@ -697,7 +689,6 @@ class UNetEngine:
                 nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), nt, C, K, K * nt, nt, 1, 1.0, 1)
 
         fuse_seg = self.fuse_seg_bwd and not skip_body and not self.numeric_conv_bias_grad and self.K <= 4
-        exp_lazy, lazy_events = os.environ.get("LNN_EXP_LAZY_IN", "0") == "1", {}
         seg_u = len(self.segs)
         pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
         presummed = set()     # id(block): pass 1 of its normalisation backward was taken by the data gradient that produced its dL/dz
@@ -725,8 +716,6 @@ class UNetEngine:
                 continue
             elif isinstance(item, ConvBlock):
                 V, K, C = item.z.V, item.cout, item.cin_k
-                if id(item) in lazy_events:
-                    main.wait_event(lazy_events.pop(id(item)))
                 if id(item) in pending:
                     seg, dl = pending.pop(id(item))
                     self._probed("in_bwd", item, lambda: nat.call(
@@ -753,7 +742,7 @@ class UNetEngine:
                                  0 if det is None else det.numel())
                         if per_layer_unpack:
                             unpack(item)
-                    on_side(lambda: self._probed("wgrad", item, first_wgrad), side_c1)
+                    on_side(lambda: self._probed("wgrad", item, first_wgrad))
                     continue
                 elif id(item) in presummed:
                     self._probed("in_bwd", item, lambda: nat.call(
@@ -770,17 +759,6 @@ class UNetEngine:
                 ldx = 1 if item.x is None else item.x.ld
 
                 def conv_wgrad(item=item, xin=xin, ldx=ldx, K=K, C=C, D=D, H=H, W=W):
-                    xb = item.x_block
-                    if exp_lazy and xb is not None and xb.cout == 32 and item.stride == 1 and item.iso and side is not None:
-                        # EXPERIMENT (LNN_EXP_LAZY_IN=1, measurement only): what a normalise-on-load forward would add to the
-                        # backward -- the predecessor's normalised tensor produced here, on the side stream, in front of the weight
-                        # gradient that reads it (the pass is a duplicate today: z is recomputed from the still intact y, results
-                        # unchanged); the main stream waits for it before it overwrites y with dL/dy
-                        nat.call("lnn_instnorm_lrelu_fwd", xb.y, xb.z, xb.z.ld, N, xb.z.V, xb.cout, xb.mean, xb.rstd,
-                                 self.pview(xb.gamma), self.pview(xb.beta), LRELU_SLOPE)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                        lazy_events[id(xb)] = ev
                     self._probed("wgrad", item, lambda: conv_wgrad_call(item, xin, ldx, K, C, D, H, W))
                     if per_layer_unpack:
                         unpack(item)
@@ -863,13 +841,11 @@ class UNetEngine:
             progress(0, side)           # the first layer's gradients are enqueued: the last bucket leaves from here too
         if side is not None:
             main.wait_stream(side)      # every weight gradient is final before anything downstream (norm, step)
-        if side_c1 is not side:
-            main.wait_stream(side_c1)
         if not per_layer_unpack and not skip_body:
             self.unpack_wgrads()
 
     def _side_stream(self, i=0):
-        """Side HIP stream ``i`` of this engine's device: 0 = weight gradients, 1 = the first layer's weight gradient.  PROCESS-WIDE, shared by every engine: the runtime multiplexes
+        """Side HIP stream ``i`` of this engine's device (0 = weight gradients).  PROCESS-WIDE, shared by every engine: the runtime multiplexes
         streams onto a handful of hardware queues, and an engine whose side stream lands on the queue of its main stream loses
         the overlap it exists for (measured in round 5: the trainers built later in one process -- each engine with three streams
         of its own -- ran 1 ms per step slower)."""

@@ -105,10 +105,8 @@ def _wgrads(rec):
     return [c for c in _calls(rec) if "wgrad" in c[1] and "unpack" not in c[1]]
 
 
-@pytest.mark.parametrize("own_stream", [True, False])
-def test_backward_launches_every_weight_gradient_once(dry, own_stream):
+def test_backward_launches_every_weight_gradient_once(dry):
     net, eng = _engine()
-    eng.c1_wgrad_stream = own_stream
     x = torch.zeros(2, 1, 16, 16, 16)
     logits = eng.forward(x)
     dry.clear()
@@ -129,10 +127,9 @@ def test_backward_launches_every_weight_gradient_once(dry, own_stream):
     last_join = max(i for i, r in enumerate(dry) if r[0] == "wait_stream")
     unpack = [i for i, r in enumerate(dry) if r[0] == "call" and r[1] == "lnn_unpack_wgrad_batched"]
     assert len(unpack) == 1 and unpack[0] > last_join
-    # the first layer's (HBM-bound) weight gradient has a stream of its own, next to the second block's MFMA-bound one
+    # ONE side stream; the first layer's weight gradient (dy rebuilt from y and dL/dz inside it) is the last launch of backward
     first = [c for c in wg if c[1] == "lnn_conv3d_wgrad_c1_in_bwd"]
-    assert len(first) == 1 and wg[-1] is first[0]
-    assert first[0][2] == ("side2" if own_stream else "side1") and {c[2] for c in wg[:-1]} == {"side1"}
+    assert len(first) == 1 and wg[-1] is first[0] and {c[2] for c in wg} == {"side1"}
     # every side launch waits for an event recorded on main when its dL/dy (and, for the first layer, the sums in ws) were enqueued
     waits = [r for r in dry if r[0] == "wait_event"]
     assert len(waits) == len(wg) and all(r[2] == "main" for r in waits)
