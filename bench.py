@@ -568,6 +568,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the warm-up and the timed steps (no synchronising-fetch / H2D-inclusive repeats): counter passes")
     ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
                     help="CPU baseline / parity patch: one full-size patch (~15 s of CPU work) or a 128^3 sub-patch")
     ap.add_argument("--other-workloads", default=None,
@@ -711,7 +713,7 @@ def main():
     }
     out["config"].update(extra_cfg)
     out["config"]["loss_fetch"] = "asynchronous: consumed by the next iteration's loss-scale decision (the trainer's epoch loop)"
-    if world == 1:
+    if world == 1 and not args.no_extras:
         tr.defer_loss_fetch = False
         timed(2)
         dt_e, _ = timed(args.steps)
@@ -726,7 +728,7 @@ def main():
         out["config"]["same_batch_predictions_patches_per_s"] = B * args.steps / dt_sb
         out["config"]["note"] = ("value = reference semantics (T+2 batches per iteration, one extra eval forward per head); "
                                  "conv_stack_* count the training pass only")
-    if world == 1 and ext != "lwf":
+    if world == 1 and ext != "lwf" and not args.no_extras:
         # H2D-inclusive variant of the same loop (MH.py:606-617 includes to_cuda in the iteration)
         try:
             items = tr.tr_gen.items if isinstance(tr.tr_gen, ResidentBatches) else None

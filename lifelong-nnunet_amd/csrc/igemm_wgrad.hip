@@ -471,10 +471,10 @@ __device__ __forceinline__ uint4v wg_rsrc_n(const void* base, unsigned num_recor
     return r;
 }
 
-// RUN (round 5): the input planes of the next tile are fetched through RUNNING scalars -- plane pointer, ring offset, plane index --
-// set once per tile, instead of rebuilding each descriptor from (tile origin, plane number, ring base): ~15 instead of ~30 scalar
-// instructions at each of the six issue points between the MFMA groups (profiles/r05_wgrad_v5_scalar_work.txt).
-template <bool RUN>
+// Round 5 measured the six plane fetches of the next tile through RUNNING scalars (plane pointer, ring offset, plane index set once per
+// tile: 161 instead of 226 scalar instructions in the MFMA blocks of a tile): 1-2 % SLOWER on every layer (dec4.0 1.235 / 1.253 vs
+// 1.220 / 1.226 ms, enc0.1 0.578 / 0.573 vs 0.562 / 0.562 ms, alternating runs on one box, profiles/r05_wgrad_v5_scalar_work.txt) --
+// the descriptor arithmetic below is independent work the scalar unit does beside the MFMAs, the running form a serial chain.
 __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradParams p) {
     constexpr int TZ = 4, TY = 8, TX = 8, PY = 10, PX = 10, PP = PY * PX, TPW = 7, NT = 512;
     constexpr int SLOTB = 7 * 1024, NSLOT = 12, QB = NSLOT * SLOTB, PB = 2 * NT * 16;
@@ -588,18 +588,6 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
         wg_dma16(wg_rsrc_n(t.porg, 0x7fffffffu), lds0 + QB + img * PB + j * (NT * 16) + wave * 1024, t.pv[j]);
     };
     auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
-    // RUN: state of the plane fetches of the tile being prefetched (set before its first issue point)
-    const half_t* rq_ptr = nullptr;
-    int rq_so = 0, rq_iz = 0, rq_qv = OOB;
-    const unsigned ldsw = lds0 + wave * 1024;
-    auto dma_q_run = [&]() {
-        const uint4v rs = wg_rsrc_n(rq_ptr, (unsigned)rq_iz < (unsigned)p.Qd ? 0x7fffffffu : 0u);
-        if (wave < 7) wg_dma16(rs, ldsw + rq_so, rq_qv);
-        rq_ptr += qplane;
-        ++rq_iz;
-        rq_so = rq_so + SLOTB == NSLOT * SLOTB ? 0 : rq_so + SLOTB;
-    };
-
     Tile cur = prep(t_begin);
     int base = 0, img = 0;
 #pragma unroll
@@ -635,12 +623,6 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
         const int nin = more ? (same_col ? 4 : 6) : 0, rel0 = same_col ? 2 : 0;
         const int nbase = wrap(base + (same_col ? 4 : 6));
         int qaddr_n[3][2], pa_n;
-        if constexpr (RUN) {
-            rq_ptr = nxt.qorg + rel0 * qplane;
-            rq_iz = nxt.lz0 - 1 + rel0;
-            rq_so = wrap(wrap(base + 6)) * SLOTB;
-            rq_qv = nxt.qv;
-        }
 
         if (timed) t1 = __builtin_readcyclecounter();
         constexpr int NCH = 8;
@@ -669,10 +651,7 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_s1_v5_kernel(const WgradPa
             if (g % 2 == 1 && g / 2 < 8) {                  // 8 DMA issue points, every second group (every group: +-0, round 2)
                 const int i = g / 2;
                 if (i < 6) {
-                    if (i < nin) {
-                        if constexpr (RUN) dma_q_run();
-                        else dma_q(nxt, rel0 + i, wrap(wrap(base + 6 + i)));
-                    }
+                    if (i < nin) dma_q(nxt, rel0 + i, wrap(wrap(base + 6 + i)));
                 } else if (more) {
                     dma_p(nxt, i - 6, img ^ 1);
                 }
@@ -971,11 +950,8 @@ int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
         int dev = 0;
         hipDeviceProp_t prop;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_wgrad_s1_v5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    static int run = -1;             // LNN_WGRAD_RUN=0: per-descriptor arithmetic of rounds 2-4 (A/B measurement)
-    if (run < 0) { const char* e = getenv("LNN_WGRAD_RUN"); run = (e && e[0] == '0') ? 0 : 1; }
     static int dbg4 = -1;
     static unsigned long long* dbgbuf4 = nullptr;
     if (dbg4 < 0) {
@@ -992,8 +968,7 @@ int launch_wgrad_s1_v5(hipStream_t s, WgradParams& p) {
     const dim3 grid = wg_grid(p, chunks, (unsigned)panels);
     const long slot_elems = 27L * p.Mpad * p.Cpad;
     if (int e = wg_prepare_parts(p, chunks, 2, slot_elems, "lnn_conv3d_wgrad(s1)")) return e;       // writers: the two tile halves
-    if (run) hipLaunchKernelGGL(igemm_wgrad_s1_v5_kernel<true>, grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
-    else hipLaunchKernelGGL(igemm_wgrad_s1_v5_kernel<false>, grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
+    hipLaunchKernelGGL(igemm_wgrad_s1_v5_kernel, grid, dim3(512), (size_t)(12 * 7 * 1024 + 2 * 2 * 512 * 16), s, p);
     LNN_CHECK_LAUNCH("lnn_conv3d_wgrad(s1,v5)");
     return wg_reduce_parts(s, p, chunks, slot_elems, "lnn_conv3d_wgrad(s1,v5,reduce)");
 }

@@ -57,11 +57,13 @@ def main(src, dst):
     f = parse(src + "/pmc_fetch.txt", "FETCH_SIZE")
     w = parse(src + "/pmc_write.txt", "WRITE_SIZE")
     rows = []
+    # steps in the profiled run = launches of the image cast kernel (one per forward)
+    nsteps = float(sum(a["dispatches"] for key, a in f.items() if key[0].startswith("cast_kernel")) or 3)
     for key, a in f.items():
         if key not in w or "FETCH_SIZE" not in a or "WRITE_SIZE" not in w[key] or a["mean_us"] < 40:
             continue
         byts = a["FETCH_SIZE"] * 1024 * 2 + w[key]["WRITE_SIZE"] * 1024
-        rows.append({"kernel": short(key[0]), "grid_x": key[1], "size_rank": key[2], "launches_per_step": a["dispatches"] / 7.0,
+        rows.append({"kernel": short(key[0]), "grid_x": key[1], "size_rank": key[2], "launches_per_step": a["dispatches"] / nsteps,
                      "mean_us": a["mean_us"], "fetch_size_kb": a["FETCH_SIZE"], "write_size_kb": w[key]["WRITE_SIZE"],
                      "hbm_bytes_per_launch_corrected": byts, "hbm_tb_per_s": round(byts / a["mean_us"] / 1e6, 2)})
     rows.sort(key=lambda r: -r["mean_us"] * r["launches_per_step"])
@@ -72,7 +74,7 @@ def main(src, dst):
         alg = vox * (64 + 32) * 2
         return dict(r, algorithmic_bytes=alg, ratio_to_algorithmic=round(r["hbm_bytes_per_launch_corrected"] / alg, 3))
     out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py itself "
-                   "(tools/gpu_r4_pmc.sh, C2 step, weight gradients on the main stream, mean over 7 steps); FETCH_SIZE x2 per "
+                   "(tools/gpu_r5_final.sh, C2 step, weight gradients on the main stream, mean over the %d steps of the run)" % nsteps + "; FETCH_SIZE x2 per "
                    "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported; per launch",
            "layer": "conv_blocks_localization.4.0 64->32 @160x192x160 N=2 (algorithmic bytes 1.887 GB for each of the three)",
            "kernels": {"fwd": pick("conv_s1_v9<4,1,2,epi=1>", 131072), "dgrad": pick("conv_s1_v9<2,2,2,epi=0>", 131072),
