@@ -767,7 +767,7 @@ def main():
         dom_key = min(fams, key=lambda k: fams[k]["achieved_in_step"] or fams[k]["achieved_isolated"])
         dom = fams[dom_key]
         # HBM bytes per launch / shader clock / matrix-pipe busy cycles come from committed PMC passes over this same command
-        # (separate rocprofv3 runs, tools/gpu_r4_pmc.sh).  They describe ONE binary: each file carries the sha256 of the
+        # (separate rocprofv3 runs, tools/gpu_r5_final.sh).  They describe ONE binary: each file carries the sha256 of the
         # liblnn_hip.so it was collected with and is quoted only when that is the library loaded now.
         traffic, traffic_note, clock = None, None, None
         so_sha = so_sha256()

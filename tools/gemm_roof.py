@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Calibration of the practical fp16 MFMA roof of THIS box: a plain library GEMM (torch.matmul -> hipBLASLt / rocBLAS) at sizes
 that fit the MALL-less regime, timed with HIP events.  Not part of the product; it gives the roofline discussion in DESIGN.md a
-measured reference next to the 2.5 PFLOP/s datasheet figure (run it under tools/gpu_r4_pmc.sh, which also collects
+measured reference next to the 2.5 PFLOP/s datasheet figure (run it under tools/gpu_r5_final.sh, which also collects
 GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES for its kernels)."""
 import sys
 

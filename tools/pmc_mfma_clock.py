@@ -1,5 +1,5 @@
 """profiles/r04_pmc_mfma_clock.json from a `rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
-SQ_BUSY_CYCLES` pass over bench.py (tools/gpu_r4_pmc.sh): for every MFMA kernel group of the step
+SQ_BUSY_CYCLES` pass over bench.py (tools/gpu_r5_final.sh): for every MFMA kernel group of the step
 
   clock_ghz      = GRBM_GUI_ACTIVE per dispatch / 8 XCDs (the counter is summed over the XCDs) / launch duration
   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8): share of the matrix pipes' CYCLES

@@ -1,10 +1,10 @@
-"""Turn the per-kernel PMC listings of tools/gpu_r4_pmc.sh (tools/rocpd_pmc.py --by-grid over separate FETCH_SIZE / WRITE_SIZE
-rocprofv3 passes of bench.py) into profiles/r04_pmc_traffic.json: HBM bytes per launch for every kernel group of the step.
+"""Turn the per-kernel PMC listings of tools/gpu_r5_final.sh (tools/rocpd_pmc.py --by-grid over separate FETCH_SIZE / WRITE_SIZE
+rocprofv3 passes of bench.py) into profiles/rNN_pmc_traffic.json: HBM bytes per launch for every kernel group of the step.
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE is reported in KB and on gfx950 tallies the
 128-byte requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE is taken as reported (it equals the output size of
 the conv kernels exactly).
-usage: python tools/pmc_traffic.py gpurun_out/r4pmc profiles/r04_pmc_traffic.json
+usage: python tools/pmc_traffic.py gpurun_out/r4pmc profiles/rNN_pmc_traffic.json
 """
 import json
 import re
