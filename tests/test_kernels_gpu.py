@@ -759,6 +759,45 @@ def test_dgrad_with_fused_norm_backward_reduce(N, C, D, H, W, zseg):
     assert rel_err(from_cl_h(ub, C), u.grad) < 3e-3             # dy in place over u
 
 
+def test_fused_norm_backward_reduce_with_a_large_channel_offset():
+    """The fused reduce sums g u of the UN-normalised convolution output in fp32 and forms sum g xhat = rstd (sum g u - mean sum g) in
+    fp64 afterwards: with |mean| = 30 std per channel the cancellation must stay far below the fp16 rounding of the operands
+    (profiles/r05_fused_reduce_conditioning.txt: 3e-6 of the largest sum here, 7e-6 at 100 std)."""
+    N, C, D, H, W = 2, 32, 24, 16, 24
+    K, V = C, 24 * 16 * 24
+    g = torch.Generator().manual_seed(11)
+    u = q16(torch.randn((N, C, D, H, W), generator=g) + 30.0)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV), (0.2 * torch.randn(C, generator=g)).to(DEV)
+    w = torch.randn((K, C, 3, 3, 3), generator=g) * 0.1
+    dy = torch.randn((N, K, D, H, W), generator=g)
+    ub, _ = to_cl_h(u)
+    dyb, _ = to_cl_h(dy)
+    wp = pack_conv_dgrad(w.to(DEV))
+    mean = torch.empty(N * C, device=DEV); rstd = torch.empty(N * C, device=DEV)
+    nws = nat.query("lnn_instnorm_ws_doubles", N, C)
+    nat.call("lnn_instnorm_stats", ub, N, V, C, 1e-5, mean, rstd, torch.zeros(nws, dtype=torch.float64, device=DEV))
+    sums = []
+    try:
+        assert nat.lib().lnn_debug_force_conv_kernel(9) == 0
+        for fused in (False, True):
+            dx = torch.zeros((N, D, H, W, C), dtype=torch.float16, device=DEV)
+            ws = torch.zeros(nws, dtype=torch.float64, device=DEV)
+            dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
+            if fused:
+                nat.call("lnn_conv3d_dgrad_in_bwd_sums", dyb, K, wp, dx, C, N, D, H, W, C, K, ub, mean, rstd, gamma, beta, 0.01, dg, db, 1.0,
+                         ws, None, 0)
+                assert nat.lib().lnn_debug_last_dgrad_reduce_fused() == 1
+            else:
+                nat.call("lnn_conv3d_dgrad_ws", dyb, K, wp, dx, C, N, D, H, W, C, K, 1, 0, None, 0)
+                nat.call("lnn_instnorm_lrelu_bwd_sums", ub, dx, C, N, V, C, mean, rstd, gamma, beta, 0.01, dg, db, 1.0, ws)
+            sums.append(ws[:N * C * 3].view(N * C, 3)[:, :2].cpu().clone())
+    finally:
+        nat.lib().lnn_debug_force_conv_kernel(-1)
+    s0, s1 = sums
+    for j in range(2):
+        assert float((s1[:, j] - s0[:, j]).abs().max()) <= 2e-5 * float(s0[:, j].abs().max())
+
+
 @pytest.mark.parametrize("C", [32, 128])
 @pytest.mark.parametrize("zseg", [2, 3, 5])
 def test_v9_z_segments(zseg, C):
