@@ -38,10 +38,11 @@ __device__ __forceinline__ void lane_voxel(int v, int& r, int& x) {
 }
 
 struct Step {   // (work unit, 16-channel chunk)
-    int n, lz0, ly0, lx0, m0, c0, ch, part;
+    int n, lz0, ly0, lx0, m0, c0, ch, part, zlim;
     bool valid, first_chunk, last_chunk, interior;
 };
 
+template <bool ZSKIP>
 __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParams p, int units_total, int tiles_total,
                                                                  int units_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
         const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int tz = t % p.tiles_z; t /= p.tiles_z;
         r.n = t; r.lz0 = tz * TZ; r.ly0 = ty * TY; r.lx0 = tx * TX;
+        r.zlim = p.Ld - r.lz0;                    // planes of this tile inside the volume (>= TZ: all)
         // whole halo inside the volume and a full 16-channel chunk -> no per-element checks needed
         r.interior = r.lz0 >= 1 && r.ly0 >= 1 && r.lx0 >= 1 && r.lz0 + TZ + 1 <= p.Di && r.ly0 + TY + 1 <= p.Hi &&
                      r.lx0 + TX + 1 <= p.Wi && r.c0 + CK <= p.C;
@@ -192,6 +194,11 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
         }
+        // A wave owns one z plane of the 8x8x8 tile.  Where the volume ends inside the tile (20 planes = 8 + 8 + 4 at the fourth
+        // level of the 160x192x160 plan, 5 planes at the sixth) the waves of the padding planes skip the 54 MFMAs and their 81
+        // fragment reads of the step -- they only take part in the staging and its barriers -- and leave the matrix pipe and the
+        // LDS port to the second block resident on the CU (round 5; LNN_V7_NO_ZSKIP=1: A/B).
+        const bool zlive = !ZSKIP || wave < cur.zlim;
         half8 fa[3], fb[3][VT];
         auto frag = [&](int tl, half8& a, half8 (&b)[VT]) {     // tl compile-time after unrolling
             const int dz = tl / 9, dy = (tl / 3) % 3, dx = tl % 3;
@@ -201,16 +208,18 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
             for (int vt = 0; vt < VT; ++vt)
                 b[vt] = *reinterpret_cast<const half8*>(xl + ximm + lterm[vt][dy & 1]);
         };
-        frag(0, fa[0], fb[0]);
-        frag(1, fa[1], fb[1]);
+        if (zlive) {
+            frag(0, fa[0], fb[0]);
+            frag(1, fa[1], fb[1]);
 #pragma unroll
-        for (int g = 0; g < 27; ++g) {
-            if (g + 2 < 27) frag(g + 2, fa[(g + 2) % 3], fb[(g + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < 27; ++g) {
+                if (g + 2 < 27) frag(g + 2, fa[(g + 2) % 3], fb[(g + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int vt = 0; vt < VT; ++vt)
-                acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g % 3], fb[g % 3][vt], acc[vt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int vt = 0; vt < VT; ++vt)
+                    acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g % 3], fb[g % 3][vt], acc[vt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (cur.last_chunk) {
             // ---- epilogue: lane holds voxel (vr, vx) x channels {8*q + 4*hk + 0..3} per accumulator quad ----
@@ -308,10 +317,14 @@ int lnn_launch_conv_s1_v7(hipStream_t s, ConvParams& p, const char* name) {
     const size_t lds = XBYTES + WBYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v7_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v7_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(igemm_conv_s1_v7_kernel, dim3(grid), dim3(NT), lds, s, p, (int)units, tiles, upb);
+    static int no_zskip = -1;
+    if (no_zskip < 0) { const char* e = getenv("LNN_V7_NO_ZSKIP"); no_zskip = (e && e[0] == '1') ? 1 : 0; }
+    if (no_zskip) hipLaunchKernelGGL(igemm_conv_s1_v7_kernel<false>, dim3(grid), dim3(NT), lds, s, p, (int)units, tiles, upb);
+    else hipLaunchKernelGGL(igemm_conv_s1_v7_kernel<true>, dim3(grid), dim3(NT), lds, s, p, (int)units, tiles, upb);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }
