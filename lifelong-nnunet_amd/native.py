@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblnn_hip.so")
+# LNN_LIB_PATH: another build of the same library (A/B measurements of two kernel versions on one box); never a fallback
+LIB_PATH = os.environ.get("LNN_LIB_PATH") or os.path.join(_HERE, "csrc", "liblnn_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int

@@ -592,7 +592,10 @@ def test_every_stride1_conv_kernel_variant(which):
                                                     (1, 32, 64, 7, 9, 18, 1), (1, 64, 64, 6, 10, 9, 1), (2, 64, 128, 5, 12, 9, 1),
                                                     (1, 32, 32, 37, 5, 21, 1),
                                                     # 128 input channels: v9 with all eight waves as channel chunks (round 3)
-                                                    (1, 128, 128, 7, 9, 18, 1), (1, 128, 96, 5, 6, 10, 1), (1, 128, 256, 4, 5, 9, 1)]
+                                                    (1, 128, 128, 7, 9, 18, 1), (1, 128, 96, 5, 6, 10, 1), (1, 128, 256, 4, 5, 9, 1),
+                                                    # last z tile with 4 / 3 / 4 live planes (the tile kernel's half steps: two waves
+                                                    # per live plane, round 5) behind one or two full tiles, and 20 = 8 + 8 + 4
+                                                    (1, 48, 40, 20, 11, 9, 1), (1, 32, 32, 11, 8, 16, 1), (2, 16, 32, 12, 8, 8, 1)]
     assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
     try:
         for (N, C, K, D, H, W, s) in cases:
