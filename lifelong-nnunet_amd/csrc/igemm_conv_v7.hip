@@ -169,9 +169,6 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
             lterm[vt][par] = ((wave * PY + y) * PX + vx) * ROWB + ((hk ^ ((y + par) & 1)) << 4);
     }
     const int a_lane = v * ROWB + ((hk ^ ((v >> 3) & 1)) << 4);
-    // half steps (see the step loop): this wave's plane, row block and the LDS offset of (plane, row block) relative to lterm[0]
-    const int hplane = wave & 3, hrow = 4 * (wave >> 2);
-    const int hoff = ((hplane - wave) * PY + hrow) * PX * ROWB;
 
     floatx16 acc[VT];
 
@@ -196,32 +193,34 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
         }
-        // A wave owns one z plane of the 8x8x8 tile (two 32-voxel MFMA tiles: rows 0-3 and 4-7).  Where the volume ends inside the
-        // tile (20 planes = 8 + 8 + 4 at the fourth level of the 160x192x160 plan) the padding planes are not computed (round 5):
-        //   * more than 4 live planes: the waves of the padding planes skip the step's 54 MFMAs and 81 fragment reads (they only take
-        //     part in the staging and its barriers);
-        //   * at most 4 live planes ("half" steps): the two MFMA tiles of a live plane go to TWO waves -- wave w takes plane w & 3,
-        //     rows 4 (w >> 2) .. + 3 -- so every wave of the block runs 27 MFMAs instead of four waves running 54.
-        const bool half_step = cur.zlim <= 4;
-        const bool two = !half_step;                                     // both MFMA tiles of the wave's plane
-        const int boff = half_step ? hoff : 0;
+        // A wave owns one z plane of the 8x8x8 tile.  Where the volume ends inside the tile (20 planes = 8 + 8 + 4 at the fourth
+        // level of the 160x192x160 plan, 5 planes at the sixth) the waves of the padding planes skip the 54 MFMAs and their 81
+        // fragment reads of the step -- they only take part in the staging and its barriers -- and leave the matrix pipe and the
+        // LDS port to the second block resident on the CU (round 5: 19.99 / 20.00 vs 20.05 / 20.04 ms per C2 step, alternating runs;
+        // enc3.1 dgrad 0.120-0.125 vs 0.122-0.136 ms).  Also measured: "half steps" -- for tiles with <= 4 live planes the two MFMA
+        // tiles of a plane on two waves, 27 MFMAs per wave -- with the second tile's read + MFMA behind a uniform branch in this one
+        // loop: 13 % SLOWER (enc3.1 fwd 0.120-0.124 vs 0.105-0.107 ms, step 19.98 vs 19.86 ms; 51 branches in the MFMA loop); as two
+        // loops: 44 spilled registers at the 128 this kernel may use.  Not kept.
+        const bool zlive = wave < cur.zlim;
         half8 fa[3], fb[3][VT];
-        if ((half_step ? hplane : wave) < cur.zlim) {
-            auto frag = [&](int tl, half8& a, half8 (&b)[VT]) {     // tl compile-time after unrolling
-                const int dz = tl / 9, dy = (tl / 3) % 3, dx = tl % 3;
-                const int ximm = ((dz * PY + dy) * PX + dx) * ROWB;
-                a = *reinterpret_cast<const half8*>(wl + tl * MB * ROWB + a_lane);
-                b[0] = *reinterpret_cast<const half8*>(xl + ximm + lterm[0][dy & 1] + boff);
-                if (two) b[1] = *reinterpret_cast<const half8*>(xl + ximm + lterm[1][dy & 1]);
-            };
+        auto frag = [&](int tl, half8& a, half8 (&b)[VT]) {     // tl compile-time after unrolling
+            const int dz = tl / 9, dy = (tl / 3) % 3, dx = tl % 3;
+            const int ximm = ((dz * PY + dy) * PX + dx) * ROWB;
+            a = *reinterpret_cast<const half8*>(wl + tl * MB * ROWB + a_lane);
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+                b[vt] = *reinterpret_cast<const half8*>(xl + ximm + lterm[vt][dy & 1]);
+        };
+        if (zlive) {
             frag(0, fa[0], fb[0]);
             frag(1, fa[1], fb[1]);
 #pragma unroll
             for (int g = 0; g < 27; ++g) {
                 if (g + 2 < 27) frag(g + 2, fa[(g + 2) % 3], fb[(g + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g % 3], fb[g % 3][0], acc[0], 0, 0, 0);
-                if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g % 3], fb[g % 3][1], acc[1], 0, 0, 0);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt)
+                    acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g % 3], fb[g % 3][vt], acc[vt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -229,8 +228,7 @@ __global__ __launch_bounds__(NT, 4) void igemm_conv_s1_v7_kernel(const ConvParam
             // ---- epilogue: lane holds voxel (vr, vx) x channels {8*q + 4*hk + 0..3} per accumulator quad ----
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) {
-                if (half_step && vt > 0) continue;           // half steps: one accumulator, plane w & 3, rows 4 (w >> 2) .. + 3
-                const int lz = cur.lz0 + (half_step ? hplane : wave), ly = cur.ly0 + (half_step ? hrow : vt * 4) + vr, lx = cur.lx0 + vx;
+                const int lz = cur.lz0 + wave, ly = cur.ly0 + vt * 4 + vr, lx = cur.lx0 + vx;
                 if (lz >= p.Ld || ly >= p.Lh || lx >= p.Lw) continue;
                 const long vox = (((long)cur.n * p.Do + lz) * p.Ho + ly) * p.Wo + lx;
                 if (ks > 1) {
