@@ -617,3 +617,29 @@ def test_backward_plan_invariants_of_the_fused_normalisation_reduce(pools, kerne
     assert partners == len(eng.blocks) // 2
     firsts = [b for b in eng.blocks if b.x_block is None]
     assert all(not any(o.x_block is b for o in firsts) for b in firsts)
+
+
+def test_bench_workload_plans_build_their_networks():
+    """Every workload bench.py can be asked for names a plan the engine accepts (built on the CPU at a reduced in-plane size with the
+    same poolings / kernels / channels): the anisotropic Prostate-shaped plan runs its [1,3,3] / [1,2,2] stages on the generic
+    kernels and its lower stages on the isotropic ones, and its FLOP count scales to the 3.39 TFLOP per patch the bench reports."""
+    import bench
+    from lifelong_nnunet_amd.engine import ConvBlock
+    assert set(bench.WORKLOADS) == {"c1", "c2", "c3", "c4", "c5", "prostate"}
+    for name, (plans, ext, desc) in bench.WORKLOADS.items():
+        q = 2 ** plans["num_pool"]
+        pools = plans.get("pool_op_kernel_sizes")
+        small = tuple(q for _ in range(3)) if pools is None else tuple(
+            int(np.prod([p[a] for p in pools])) * (4 if a == 0 and name == "prostate" else 1) for a in range(3))
+        net = Generic_UNet(plans["num_input_channels"], plans["base_num_features"], plans["num_classes"], plans["num_pool"],
+                           patch_size=small, batch_size=1, device="cpu", pool_op_kernel_sizes=pools,
+                           conv_kernel_sizes=plans.get("conv_kernel_sizes"))
+        eng = net.engine_for(torch.zeros((1, plans["num_input_channels"]) + small))
+        assert len(eng.segs) == plans["num_pool"] and ext in ("sequential", "ewc", "lwf", "rehearsal_ewc")
+        if name == "prostate":
+            blocks = [b for b in eng.order if isinstance(b, ConvBlock)]
+            assert not blocks[0].iso and blocks[0].kernel == (1, 3, 3) and any(b.iso for b in blocks)
+            assert eng.feats == [32, 64, 128, 256, 320, 320, 320]
+            fl, _ = eng.flops_per_patch()
+            full = fl * (20 * 320 * 256) / (small[0] * small[1] * small[2])
+            assert abs(full / 1e9 - 3385.56) < 1.0
