@@ -9,7 +9,7 @@ per-task copies; the head of the active task is refreshed from the running model
 iteration.  What is dropped is the cost: the reference re-splits the module tree and ``deepcopy``s the
 head every iteration (MHM.py:153-157,324) and deep-copies + ``load_state_dict``s on every
 ``assemble_model`` (MHM.py:343-359); here both are a handful of device-to-device copies of the head
-tensors (2 400 floats for the 5-level U-Net).
+tensors (2 400 floats for the 5-level U-Net).  NESTED splits follow the reference after construction too (``_reference_resplit``).
 """
 from __future__ import annotations
 
@@ -32,6 +32,10 @@ def _set_nested(root: nn.Module, dotted: str, param: nn.Parameter):
 
 
 class MultiHead_Module(nn.Module):
+    # What a NESTED split ('tu.1', ...) does after construction: True = the reference's behaviour (see _reference_resplit), False = the
+    # construction-time partition is kept.  Top-level splits ('seg_outputs', 'tu', ...) are not affected.
+    reference_nested_resplit = True
+
     def __init__(self, class_object: Type[nn.Module], split_at, task, prev_trainer=None, *args, **kwargs):
         super().__init__()
         self.class_object = class_object
@@ -70,6 +74,7 @@ class MultiHead_Module(nn.Module):
         # copies that ``assemble_model`` writes back).  Top-level splits ('seg_outputs', 'tu') have no such overlap.
         top = self.split[0] + '.'
         self._body_names = [n for i, n in enumerate(names) if i < first or (len(self.split) > 1 and n.startswith(top))]
+        self._resplit = False
         self._share_body()
         init_module = self._head_from_model()
         self.state_init = OrderedDict((k, v.clone()) for k, v in init_module.state_dict().items())
@@ -114,8 +119,31 @@ class MultiHead_Module(nn.Module):
             _set_nested(self.body, n, params[n])
         self._body_detached = False
 
-    def _head_from_model(self):
-        params = dict(self.model.named_parameters())
+    def _reference_resplit(self):
+        """NESTED splits only -- the partition the reference is in from its FIRST re-split on (``update_after_iteration``,
+        MHM.py:139-157), reproduced tensor by tensor (tests/golden/multihead_nested_flow_reference.json, produced by executing the
+        reference class).  Its recursive split keeps its working objects in mutable default arguments (MHM.py:159-160): the second
+        and every later call starts with the path list the constructor's call left behind, never descends into the split
+        container, and returns
+          * a body that holds EVERY top-level module: all tensors are body from here on (shared with the running model, ``body.*``
+            state-dict keys, frozen by ``freeze_body``), the segmentation layers included;
+          * a copy of the default-argument head, which holds the members of the INNERMOST split container from the split index on
+            (``tu.1`` -> ``tu.1..``; ``conv_blocks_context.1.blocks.1`` -> ``conv_blocks_context.1.blocks.1..``) as the module
+            objects the constructor took out of the model -- they left the running model at the first ``assemble_model`` and keep
+            their CONSTRUCTION-TIME values (``state_init``'s) whatever the training does.
+        So the active task's head is replaced by those few tensors at their initial values on every update, ``assemble_model`` writes
+        them back over the trained ones, and ``add_new_task(use_init=True)`` raises (``state_init`` has the construction-time keys).
+        ``MultiHead_Module.reference_nested_resplit = False`` keeps the construction-time partition instead (every tensor from the
+        split on is per-task and is refreshed from the running model -- what the reference's documentation describes)."""
+        parent = '.'.join(self.split[:-1]) + '.'
+        self._head_names = [n for n in self._head_names if n.startswith(parent)]
+        self._body_names = [n for n, _ in self.model.named_parameters()]
+        if not self._body_detached:
+            self._share_body()
+        self._resplit = True
+
+    def _head_from_model(self, model=None):
+        params = dict((self.model if model is None else model).named_parameters())
         head = nn.Module()
         for n in self._head_names:
             _set_nested(head, n, nn.Parameter(params[n].detach().clone(), requires_grad=params[n].requires_grad))
@@ -128,11 +156,25 @@ class MultiHead_Module(nn.Module):
     def update_after_iteration(self, model=None, update_body=True):
         """Refresh the active task's head from the running model (body tensors are shared already)."""
         model = self.model if model is None else model
+        if len(self.split) > 1 and not self._resplit and self.reference_nested_resplit:
+            self._reference_resplit()
         if update_body and self._body_detached:
             self._share_body()          # MHM.py:152-153: the body is re-split from the running model, a body given to set_body is dropped
+        head = self.heads[str(self.active_task)]
+        if self._resplit:               # see _reference_resplit: the head the reference's re-split returns holds construction-time values
+            if [n for n, _ in head.named_parameters()] != self._head_names:
+                head = nn.Module()
+                for n in self._head_names:
+                    _set_nested(head, n, nn.Parameter(self.state_init[n].clone()))
+                self.heads[str(self.active_task)] = head
+            else:
+                with torch.no_grad():
+                    for n, p in head.named_parameters():
+                        p.copy_(self.state_init[n])
+            return
         src = dict(model.named_parameters())
         with torch.no_grad():
-            for n, p in self.heads[str(self.active_task)].named_parameters():
+            for n, p in head.named_parameters():
                 p.copy_(src[n])
 
     def assemble_model(self, task, freeze_body=False):
@@ -173,9 +215,9 @@ class MultiHead_Module(nn.Module):
             new = nn.Module()
             for n, p in last.named_parameters():
                 _set_nested(new, n, nn.Parameter(p.detach().clone()))
-            if use_init:
-                new.load_state_dict(self.state_init)
             self.heads[str(task)] = new
+            if use_init:        # MHM.py:448-452: registered first, so a refused state_init (nested split after a re-split) leaves it behind
+                new.load_state_dict(self.state_init)
         else:
             new = nn.Module()
             for n, p in model.named_parameters():

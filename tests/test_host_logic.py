@@ -196,6 +196,65 @@ def test_multihead_flow_matches_the_reference(golden_dir):
         assert seen == list(steps) and len(seen) == 12
 
 
+def test_multihead_nested_flow_matches_the_reference(golden_dir):
+    """tests/golden/multihead_nested_flow_reference.json: NESTED splits after construction.  Two scripts (the 12 steps of the top-level
+    fixture; 9 steps with a task added before the first re-split, a head-only first update, ``add_new_task(use_init=True)`` after a
+    re-split -- the reference raises --, head transfer, frozen body, ``set_body``) EXECUTED on the reference's ``MultiHead_Module``
+    (oracle/make_goldens_mh_nested.py) for seven nested splits of depth 2-6 and one top-level split.  The product must leave the same
+    tensors in the running model, the body and every head, the same frozen set, flags and ``state_dict()`` keys after every step: from
+    the first ``update_after_iteration`` on every tensor is body and the active head is the innermost split container's tail at its
+    construction-time values (multihead.py:_reference_resplit)."""
+    import hashlib
+    from oracle.make_goldens_mh_flow import script as script_toplevel
+    from oracle.make_goldens_mh_nested import script_nested, set_construction_values
+    g = json.load(open(f"{golden_dir}/multihead_nested_flow_reference.json"))
+    names = g["names"]
+    close = lambda a, b: abs(a - b) <= 1e-6 * max(1.0, abs(b))
+    nsteps = 0
+    for sp, flows in g["flows"].items():
+        for key, scr in (("toplevel_script", script_toplevel), ("nested_script", script_nested)):
+            net = Generic_UNet(*g["ctor"], device="cpu")
+            assert [n for n, _ in net.named_parameters()] == names
+            set_construction_values(net)
+            mh = MultiHead_Module(Generic_UNet, sp, "A", net)
+            seen = []
+            for name, _ in scr(mh):
+                ref, where = flows[key][name], (sp, key, name)
+                seen.append(name)
+                if "raises" in ref:
+                    assert ref["raises"] == "RuntimeError" and "C" not in mh.heads, where      # the script removed the refused head
+                    continue
+                model = dict(mh.model.named_parameters())
+                val = lambda p: float(p.detach().double().sum())
+                assert list(model) == names and all(close(val(model[n]), r) for n, r in zip(names, ref["model"])), where
+                body = dict(mh.body.named_parameters())
+                assert list(body) == [names[i] for i in ref["body_idx"]], where
+                assert all(close(val(p), r) for p, r in zip(body.values(), ref["body"])), where
+                assert list(mh.heads.keys()) == list(ref["heads"]), where
+                for t, h in ref["heads"].items():
+                    mine = dict(mh.heads[t].named_parameters())
+                    assert list(mine) == list(h) and all(close(val(mine[n]), h[n]) for n in h), where + (t,)
+                assert [i for i, n in enumerate(names) if not model[n].requires_grad] == ref["frozen_idx"], where
+                assert str(mh.active_task) == ref["active_task"] and bool(mh.body_freezed) == ref["body_freezed"], where
+                keys = list(mh.state_dict().keys())
+                assert len(keys) == ref["state_dict_len"] and hashlib.sha256("\n".join(keys).encode()).hexdigest() == ref["state_dict_sha256"], where
+                nsteps += 1
+            assert seen == list(flows[key])
+    assert nsteps >= 8 * 20
+    # the switch: with reference_nested_resplit off the construction-time partition survives the updates
+    try:
+        MultiHead_Module.reference_nested_resplit = False
+        mh = MultiHead_Module(Generic_UNet, "tu.1", "A", None, *g["ctor"], device="cpu")
+        h0 = [n for n, _ in mh.heads["A"].named_parameters()]
+        with torch.no_grad():
+            dict(mh.model.named_parameters())["tu.1.weight"].add_(1.0)
+        mh.update_after_iteration()
+        assert [n for n, _ in mh.heads["A"].named_parameters()] == h0 == ["tu.1.weight", "seg_outputs.0.weight", "seg_outputs.1.weight"]
+        assert torch.equal(dict(mh.heads["A"].named_parameters())["tu.1.weight"], dict(mh.model.named_parameters())["tu.1.weight"])
+    finally:
+        MultiHead_Module.reference_nested_resplit = True
+
+
 def test_network_configuration_matches_the_reference(golden_dir):
     """tests/golden/network_config_reference.json: the constructor arguments the reference's ``initialize_network``
     (nnViTUNetTrainer.py:97-122) EXECUTED with a recording network class produces.  The oracle network and the product's constants must

@@ -209,3 +209,31 @@ def test_deferred_loss_fetch_keeps_the_grad_scaler_semantics(dry, monkeypatch):
             tr._finish_pending_step()
             scales[mode][-1] = tr.amp_grad_scaler.get_scale()
     assert scales["eager"] == scales["deferred"] == [65536.0, 65536.0, 65536.0, 32768.0, 32768.0, 32768.0]
+
+
+def test_trainer_iterations_with_a_nested_split(dry):
+    """``--split_at tu.1`` through the trainer: the iteration's ``update_after_iteration`` puts the module into the partition the
+    reference arrives at (every tensor body, the head = ``tu.1`` at its construction-time value; multihead.py:_reference_resplit),
+    the next task takes over the last head, and the step itself keeps launching the same kernels."""
+    from lifelong_nnunet_amd import get_trainer_class
+    plans = {"patch_size": (16, 16, 16), "batch_size": 2, "num_pool": 2, "base_num_features": 8, "num_classes": 3, "num_input_channels": 1}
+    tr = get_trainer_class("sequential")("tu.1", "A", plans=dict(plans), device="cpu")
+    tr.initialize(True, num_epochs=1)
+    mh = tr.mh_network
+    names = [n for n, _ in mh.model.named_parameters()]
+    assert [n for n, _ in mh.heads["A"].named_parameters()] == ["tu.1.weight", "seg_outputs.0.weight", "seg_outputs.1.weight"]
+    init = mh.state_init["tu.1.weight"].clone()
+    calls = []
+    for i in range(2):
+        dry.clear()
+        tr.run_iteration(tr.tr_gen, True)
+        calls.append([c[1] for c in _calls(dry)])
+        assert [n for n, _ in mh.body.named_parameters()] == names
+        assert [n for n, _ in mh.heads["A"].named_parameters()] == ["tu.1.weight"]
+        assert torch.equal(dict(mh.heads["A"].named_parameters())["tu.1.weight"], init)
+    assert calls[0] == calls[1] and "lnn_sgd_nesterov_step_clipped" in calls[0]
+    mh.add_new_task("B", use_init=False)
+    mh.assemble_model("B")
+    assert torch.equal(dict(mh.model.named_parameters())["tu.1.weight"], init)
+    with pytest.raises(RuntimeError):
+        mh.add_new_task("C", use_init=True)
