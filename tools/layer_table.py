@@ -48,18 +48,20 @@ def main():
         it = items[prefix]
         ms = sum(v) / len(v)
         if isinstance(it, ConvBlock):
-            fl = 2.0 * N * it.z.V * it.cin * it.cout * 27
-            shape = f"{it.cin}->{it.cout} s{it.stride} @{'x'.join(map(str, it.z.dims))}"
+            fl = 2.0 * N * it.z.V * it.cin * it.cout * it.ntaps
+            geo = f"s{it.stride}" if it.iso else "k" + "".join(map(str, it.kernel)) + "/s" + "".join(map(str, it.strides))
+            shape = f"{it.cin}->{it.cout} {geo} @{'x'.join(map(str, it.z.dims))}"
             level = eng.dims.index(tuple(it.z.dims))
         else:
-            fl = 2.0 * N * it.x.V * it.cin * it.cout * 8
-            shape = f"{it.cin}->{it.cout} convT @{'x'.join(map(str, it.x.dims))}"
+            kt = tuple(it.strides)          # kernel == stride
+            fl = 2.0 * N * it.x.V * it.cin * it.cout * it.ntaps
+            shape = f"{it.cin}->{it.cout} convT{''.join(map(str, kt))} @{'x'.join(map(str, it.x.dims))}"
             level = eng.dims.index(tuple(it.x.dims)) - 1
         if kind.startswith("in_"):
             fl = 0.0
         rows.append((prefix, kind, shape, level, ms, fl))
-        key = ("norm" if kind.startswith("in_") else ("s2/convT" if (isinstance(it, UpBlock) or it.stride != 1) else
-                                                     ("first" if it.cin == 1 else "s1"))) + f" L{level}"
+        key = ("norm" if kind.startswith("in_") else ("s2/convT" if (isinstance(it, UpBlock) or it.stride == 2) else
+                                                     ("first" if it.first else ("s1" if it.iso else "aniso")))) + f" L{level}"
         fam[key] += ms
     tot = sum(r[4] for r in rows)
     print(f"# {desc}; step {step_ms:.2f} ms with probes (weight gradients on the main stream); probed calls {tot:.2f} ms")
