@@ -30,7 +30,7 @@ from __future__ import annotations
 import os
 import pickle
 from collections import OrderedDict
-from typing import Dict, Sequence
+from typing import Dict
 
 import numpy as np
 

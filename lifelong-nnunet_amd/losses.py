@@ -9,8 +9,7 @@ autograd; mutators ``update_ewc_params``, ``update_network_params``, ``update_lo
 """
 from __future__ import annotations
 
-import types
-from typing import Dict, List
+from typing import Dict
 
 import numpy as np
 import torch

@@ -13,7 +13,6 @@ backward accumulates into that arena (``optimizer.zero_grad()`` = one memset).
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, Tuple
 
 import torch

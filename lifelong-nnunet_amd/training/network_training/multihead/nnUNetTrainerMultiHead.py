@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import warnings
 from collections import OrderedDict
-from typing import Callable, Dict, Optional
+from typing import Callable, Optional
 
 import numpy as np
 import torch

@@ -25,7 +25,6 @@ own code produced):
     fix behind a flag;
   * thresholds / max_entropy are reset after every ``run_training`` (:205-206).
 """
-import math
 
 import torch
 

@@ -6,7 +6,6 @@ forced-DP code paths.  The 2-rank arithmetic of GradAllReducer itself runs on CP
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist

@@ -6,7 +6,7 @@ Columns: ms per call (mean over the steps), algorithmic GFLOP of the call, TFLOP
 import argparse
 import os
 import sys
-from collections import OrderedDict, defaultdict
+from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
