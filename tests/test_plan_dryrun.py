@@ -46,8 +46,9 @@ _CUR = [_FakeStream("main")]
 _NSTREAMS = [0]
 
 
-@pytest.fixture
-def dry(monkeypatch):
+def install_dry_run(setattr_fn):
+    """Replace the launch layer by recorders through ``setattr_fn(obj, name, value)`` (monkeypatch.setattr in the fixture below, plain
+    setattr in the spawned workers of tests/test_dp_trainers_gloo.py)."""
     _REC.clear()
     del _CUR[1:]
     _NSTREAMS[0] = 0
@@ -59,14 +60,19 @@ def dry(monkeypatch):
     def fake_call(name, *args):
         _REC.append(("call", name, _CUR[-1].name, args))
 
-    monkeypatch.setattr(eng_mod, "_SIDE_STREAMS", {})
-    monkeypatch.setattr(nat, "call", fake_call)
-    monkeypatch.setattr(nat, "call_plain", lambda name, *a: _REC.append(("plain", name, a)))
-    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _CUR[-1])
-    monkeypatch.setattr(torch.cuda, "Stream", new_stream)
-    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
-    monkeypatch.setattr(torch.cuda, "stream", lambda s: _StreamCtx(s))
+    setattr_fn(eng_mod, "_SIDE_STREAMS", {})
+    setattr_fn(nat, "call", fake_call)
+    setattr_fn(nat, "call_plain", lambda name, *a: _REC.append(("plain", name, a)))
+    setattr_fn(torch.cuda, "current_stream", lambda *a, **k: _CUR[-1])
+    setattr_fn(torch.cuda, "Stream", new_stream)
+    setattr_fn(torch.cuda, "Event", _FakeEvent)
+    setattr_fn(torch.cuda, "stream", lambda s: _StreamCtx(s))
     return _REC
+
+
+@pytest.fixture
+def dry(monkeypatch):
+    return install_dry_run(monkeypatch.setattr)
 
 
 def _engine(num_pool=3, patch=(16, 16, 16)):
