@@ -702,3 +702,20 @@ def test_bench_workload_plans_build_their_networks():
             fl, _ = eng.flops_per_patch()
             full = fl * (20 * 320 * 256) / (small[0] * small[1] * small[2])
             assert abs(full / 1e9 - 3385.56) < 1.0
+
+
+def test_committed_counter_passes_belong_to_the_library_the_tree_builds():
+    """bench.py quotes HBM bytes per launch / shader clock / matrix-pipe occupancy from committed rocprofv3 counter passes and only for
+    the binary they were collected with (``so_sha256``).  The build is reproducible, so the library built from this tree is normally that
+    binary: the counter files that match its sha256 hold every key the bench line reads (all three families)."""
+    import bench
+    sha = bench.so_sha256()
+    tj = bench.committed_pmc("pmc_traffic.json", sha)
+    cj = bench.committed_pmc("pmc_mfma_clock.json", sha)
+    if tj is None or cj is None:        # a library built by another toolchain: the bench line then carries traffic: null and says why
+        pytest.skip(f"no profiles/rNN_pmc_*.json for liblnn_hip.so {sha[:16]} (counters are re-collected by tools/gpu_r5_final.sh)")
+    for fam in ("fwd", "dgrad", "wgrad"):
+        b = tj[1]["kernels"][fam]["hbm_bytes_per_launch_corrected"]
+        assert 1e9 < b < 5e9, (fam, b)                         # dec4.0 launches: 1.9 GB algorithmic
+    fams = {k: v for k, v in cj[1]["families"].items() if v}
+    assert fams and all(1.0 < v["clock_ghz"] < 2.5 and 0.0 < v["mfma_busy_frac_in_cycles"] < 1.0 for v in fams.values())
