@@ -110,6 +110,11 @@ int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy_h, int ld_dy, const void
                          int ld_dx, int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate);
 int lnn_conv3d_wgrad_cat(lnn_stream_t s, const void* x_a_h, const void* x_b_h, int ld_x, int c_a, const void* dy_h, int ld_dy,
                          float* dwp, int N, int Di, int Hi, int Wi, int C, int K);
+/* lnn_conv3d_dgrad_cat with the optional split-K workspace of lnn_conv3d_dgrad_ws (the lowest-resolution decoder convolution's data
+ * gradient, 320 -> 640 channels @ 10x12x10 at the 160x192x160 plan: 100 (band x channel-block) items for 256 CUs without it). */
+int lnn_conv3d_dgrad_cat_ws(lnn_stream_t s, const void* dy_h, int ld_dy, const void* wp_dgrad_h, void* dx_a_h, void* dx_b_h,
+                            int ld_dx, int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate, float* splitk_ws,
+                            long splitk_elems);
 
 /* ------------------------------------------------------------------------------------------------
  * nn.ConvTranspose3d kernel 2, stride 2, no bias (`tu`, convolutional_upsampling=True

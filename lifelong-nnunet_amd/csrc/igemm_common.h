@@ -65,6 +65,11 @@ int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, in
 int lnn_launch_in_bwd_sums_raw(hipStream_t s, const float* pws, int nslots, int N, int C, const float* mean, const float* rstd,
                                double* ws, float* dgamma, float* dbeta, float unscale);
 int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name);
+// macro-tile kernel with in-block split-K over the taps (igemm_conv_mt.hip): the deep levels (>= 128 channels, short volumes)
+bool lnn_conv_s1_mt_supported(const ConvParams& p);
+double lnn_conv_s1_mt_efficiency(const ConvParams& p);
+int lnn_conv_s1_mt_ksplit(const ConvParams& p, const float* ws, long ws_elems);
+int lnn_launch_conv_s1_mt(hipStream_t s, ConvParams& p, float* ws, long ws_elems, const char* name);
 // single-launch resolution-doubling kernels (igemm_up2.hip): stride-2 conv dgrad / transposed conv k2s2 forward,
 // all eight output parity classes per block
 int lnn_launch_up2_dgrad(hipStream_t s, ConvParams& p, const char* name);

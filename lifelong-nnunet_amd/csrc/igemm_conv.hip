@@ -166,7 +166,7 @@ static unsigned long long* g_dbg = nullptr;
 extern "C" int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64) { g_dbg = (unsigned long long*)dev_ptr_6x_u64; return LNN_OK; }
 
 // runtime override for the parity tests (lnn_debug_force_conv_kernel): -1 = automatic selection,
-// 5 / 7 / 8 / 9 = that stride-1 kernel for every layer it supports
+// 5 / 7 / 8 / 9 / 10 = that stride-1 kernel (10 = the macro-tile kernel) for every layer it supports
 int g_force_conv = -1;
 
 // v9 (z-streaming, register-resident weights): the kernel for the 32- / 64-input-channel layers of the two highest
@@ -228,6 +228,23 @@ bool use_v8(const ConvParams& p) {
     if (v == 1) return true;
     const long units = (long)p.N * lnn_cdiv(p.Ld, 8) * lnn_cdiv(p.Lh, 8) * lnn_cdiv(p.Lw, 8) * lnn_cdiv(p.M, 64);
     return units >= 512;
+}
+
+// Macro-tile kernel with in-block split-K (igemm_conv_mt.hip, round 6): the deep levels -- >= 128 input channels on volumes too short
+// for the z-streaming kernel -- wherever its band geometry fills >= 70 % of its MFMA columns (levels 3 and 4 of the 160x192x160 plan:
+// 1.0 / 0.94; level 5's 5x6x5 volume fills 0.2 and stays on the split-K tile kernel).  LNN_CONV_MT=1 / 0 forces / forbids it (A/B
+// measurements); lnn_debug_force_conv_kernel(10) forces it wherever supported.
+bool use_mt(const ConvParams& p) {
+    if (!lnn_conv_s1_mt_supported(p)) return false;
+    if (g_force_conv >= 0) return g_force_conv == 10;
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("LNN_CONV_MT");
+        v = e ? (e[0] == '1' ? 1 : 0) : -1;
+    }
+    if (v == 0) return false;
+    if (v == 1) return true;
+    return p.C >= 128 && p.Ld < 32 && lnn_conv_s1_mt_efficiency(p) >= 0.7;
 }
 
 // Split-K for the small deep layers (v7 path): the 8x8x8-tile x 32-channel units do not fill the chip (level 5 of C2: 20 units
@@ -301,7 +318,7 @@ extern "C" int lnn_debug_force_down2_kernel(int which) {
 }
 
 extern "C" int lnn_debug_force_conv_kernel(int which) {
-    LNN_REQUIRE(which == -1 || which == 5 || (which >= 7 && which <= 9), "lnn_debug_force_conv_kernel: %d is not one of -1, 5, 7, 8, 9", which);
+    LNN_REQUIRE(which == -1 || which == 5 || (which >= 7 && which <= 10), "lnn_debug_force_conv_kernel: %d is not one of -1, 5, 7, 8, 9, 10", which);
     g_force_conv = which;
     return LNN_OK;
 }
@@ -345,10 +362,6 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
         return LNN_OK;
     }
     if (int e = check_act(x, ld_x, x2 ? c_a : C, "lnn_conv3d_fwd(x)")) return e;
-    if (!x2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * p.Do * p.Ho * p.Wo)) {
-        const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
-        return lnn_gen_conv3d_fwd(s, x, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, k3, st3, splitk_ws, splitk_elems);
-    }
     p.KCpad = lnn_round_up(C, 16);
     p.taps.ntaps = 27;
     if (stride == 1) {
@@ -357,6 +370,13 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
             p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
             p.taps.slot[t] = (unsigned char)t;
         }
+        if (use_mt(p)) return lnn_launch_conv_s1_mt(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,mt)");
+    }
+    if (!x2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * p.Do * p.Ho * p.Wo)) {
+        const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
+        return lnn_gen_conv3d_fwd(s, x, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, k3, st3, splitk_ws, splitk_elems);
+    }
+    if (stride == 1) {
         p.dbg = g_dbg;
         // fused InstanceNorm statistics (dense output tensor only; the partials must fit the 1024 slots of lnn_instnorm_ws_doubles:
         // true up to 256 CUs -- a larger part falls back to the separate statistics pass)
@@ -430,10 +450,6 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
     if (int e = check_act(dy, ld_dy, K, "lnn_conv3d_dgrad(dy)")) return e;
     if (int e = check_act(dx, ld_dx, dx2 ? c_a : C, "lnn_conv3d_dgrad(dx)")) return e;
     const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-    if (!dx2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * Di * Hi * Wi)) {
-        const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
-        return lnn_gen_conv3d_dgrad(s, dy, ld_dy, wp, dx, ld_dx, N, Di, Hi, Wi, C, K, k3, st3, accumulate, splitk_ws, splitk_elems);
-    }
     ConvParams p{};
     if (dx2) { p.y2 = (half_t*)dx2; p.msplit = c_a; }
     // roles: gathered input = dy (K channels), output = dx (C channels); panel wp[slot][C][K]
@@ -451,6 +467,13 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
             p.taps.pos_off[t] = (unsigned short)((dz * PY + dyy) * PX + dxx);
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
+        if (use_mt(p)) return lnn_launch_conv_s1_mt(s, p, splitk_ws, splitk_elems, "lnn_conv3d_dgrad(s1,mt)");
+    }
+    if (!dx2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * Di * Hi * Wi)) {
+        const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
+        return lnn_gen_conv3d_dgrad(s, dy, ld_dy, wp, dx, ld_dx, N, Di, Hi, Wi, C, K, k3, st3, accumulate, splitk_ws, splitk_elems);
+    }
+    if (stride == 1) {
         p.dbg = g_dbg;
         if (use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad(s1,v9)");
         if (use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_dgrad(s1,v8)");
@@ -527,6 +550,14 @@ extern "C" int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy, int ld_dy, c
     if (int e = check_cat(dx_b, c_a, C, 1, "lnn_conv3d_dgrad_cat")) return e;
     LNN_REQUIRE(ld_dx >= c_a && ld_dx >= C - c_a, "lnn_conv3d_dgrad_cat: ld_dx %d smaller than a part (%d / %d)", ld_dx, c_a, C - c_a);
     return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx_a, dx_b, c_a, ld_dx, N, Di, Hi, Wi, C, K, 1, accumulate);
+}
+
+extern "C" int lnn_conv3d_dgrad_cat_ws(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx_a, void* dx_b, int ld_dx,
+                                       int c_a, int N, int Di, int Hi, int Wi, int C, int K, int accumulate, float* splitk_ws,
+                                       long splitk_elems) {
+    if (int e = check_cat(dx_b, c_a, C, 1, "lnn_conv3d_dgrad_cat_ws")) return e;
+    LNN_REQUIRE(ld_dx >= c_a && ld_dx >= C - c_a, "lnn_conv3d_dgrad_cat_ws: ld_dx %d smaller than a part (%d / %d)", ld_dx, c_a, C - c_a);
+    return conv3d_dgrad_impl(s, dy, ld_dy, wp, dx_a, dx_b, c_a, ld_dx, N, Di, Hi, Wi, C, K, 1, accumulate, splitk_ws, splitk_elems);
 }
 
 namespace {

@@ -1,0 +1,390 @@
+// Stride-1 3x3x3 implicit-GEMM convolution, macro-tile kernel with in-block split-K ("mt", round 6).
+//
+// Replaces nn.Conv3d forward / data gradient (test/network_architecture/test_MultiHead_Module.py:346-415; forward order
+// generic_ViT_UNet.py:261-286) for the DEEP levels of the U: >= 128 channels on volumes of 10..24 planes (levels 3 / 4 of the
+// 160x192x160 plan: 256 -> 256 and 512 -> 256 @ 20x24x20, 320 -> 320 and 640 -> 320 @ 10x12x10).  There the GEMM is
+// M = 256..640 output channels x 2 400..19 200 voxels x 27 C contraction: only ~19 (level 3) or ~3 (level 4) 32x32 accumulator
+// tiles of OUTPUT per CU.  The tile kernels (igemm_conv_v7 / v8: 8x8x8 voxels x 32 / 64 channels per unit, one or two
+// accumulators per wave, 1.0 - 1.5 KB of LDS reads per MFMA, the halo re-staged for every 32 output channels) ran them at
+// 500 - 670 TFLOP/s, the flattened-voxel kernel (igemm_gen) level 4 at ~200.  What this kernel does instead:
+//   * a block owns 64 output channels x one BAND of voxels: 2 planes x TY rows x all W columns; a plane of the band is one
+//     SUB-TILE of WN x 32 voxels (flattened (y, x): 8 rows x 20 = 160 = 5 MFMA column tiles at level 3, 12 x 10 = 120 -> 4 at
+//     level 4, no padding planes);
+//   * its 8 waves are 2 sub-tiles x 4 TAP QUARTERS (taps 7 kq .. 7 kq + 6 of the 27): every wave holds the FULL 64 x (32 WN)
+//     sub-tile as 2 x WN accumulators (160 registers at WN = 5) and walks only its share of the contraction -- the in-block
+//     split-K that gives a wave 10 MFMAs per 7 fragment reads (0.7 KB of LDS reads per MFMA) although the CU owns only 20
+//     accumulator tiles of output.  The four partial sums of a sub-tile meet once, after the last chunk, through LDS (each
+//     wave finalises one accumulator quad = 8 channels of every tile; MFMA rows are rotated by 8 kq so that this is always
+//     quad 0 -- no runtime register indexing);
+//   * the band's halo of ONE 16-channel chunk (4 planes x (TY + 2) x (W + 2) positions x 32 B <= 32 KB) is brought into a
+//     double-buffered LDS image by direct-to-LDS buffer loads (out-of-volume positions: zero-filled by the descriptor's range
+//     check = the convolution's padding), one barrier per chunk (7 x 10 MFMAs per wave between barriers);
+//   * weight fragments (32 rows x 16 channels of one tap = 1 KB, contiguous in the blocked panel) are private to a wave (its
+//     taps, its chunk): each wave streams them through its OWN 4-slot LDS ring by direct-to-LDS loads, 3 iterations ahead,
+//     ordered by counted s_waitcnt vmcnt only -- no barrier, no staging registers, and every memory operation of the kernel is
+//     a DMA, so the counts are exact (cdna_hip_programming.md section 5: mixing load kinds de-pipelines);
+//   * levels with fewer band x channel-block items than CUs split the chunk range over `ksplit` blocks that write fp32 partial
+//     tiles to the caller's workspace ([part][voxel][Mpad], as the v7 split-K), lnn_launch_splitk_finalize adds the slices.
+// LDS image of the halo: [position][32 B], 16-byte half index XOR ((position >> 3) & 1): the 16-lane groups of a
+// ds_read_b128 touch 16 consecutive positions up to row wraps -> conflict free for every tap shift (two lanes collide only if
+// their positions are congruent mod 16).  The key is applied to the SOURCE half each DMA lane fetches (linear LDS writes).
+#include "igemm_common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N>
+__device__ __forceinline__ void mt_wait_vm() {     // literal counts only (see igemm_conv_v9.hip)
+    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 10, "extend the table");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+__device__ __forceinline__ void mt_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
+constexpr int MT_NW = 8;                    // waves per block
+constexpr int MT_NH = 4;                    // halo DMA instructions per wave and chunk: 8 x 4 x 32 = 1024 positions
+constexpr int MT_HALO = MT_NW * MT_NH * 1024;
+constexpr int MT_AR = 4;                    // weight-fragment ring slots per wave (one slot = the two 1 KB fragments of an iteration)
+constexpr int MT_ABYTES = MT_NW * MT_AR * 2048;
+constexpr int MT_LDS = 2 * MT_HALO + MT_ABYTES;         // 128 KB
+constexpr int MT_NIT = 7;                   // tap iterations per wave and chunk (4 x 7 = 28 >= 27: the last quarter's 7th is a zero tap)
+
+struct MTLaunch {
+    int mblk;          // 64-channel output blocks
+    int zb, yb;        // bands per sample along z / y
+    int TY, PY, PX, P; // band rows, halo rows / columns / positions
+    int cpp;           // 16-channel chunks per K part
+    int nbands;        // N * zb * yb
+};
+
+// PIPE: the fragments of iteration it + 1 are read WHILE the MFMAs of iteration it issue (each column tile's B fragment is re-read
+// for the next tap as soon as its two MFMAs are out; the next weight pair goes to a second register pair) -- the wave no longer
+// depends on its SIMD partner to cover the LDS latency.  PIPE = false keeps the plain read-then-multiply order (A/B: LNN_MT_PIPE=0).
+template <int WN, bool PIPE>
+__global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams p, const MTLaunch q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const aring = smem + 2 * MT_HALO;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wave >> 2, kq = wave & 3;
+    const int hk = lane >> 5, v = lane & 31;
+
+    // ---- block -> (channel block, band, K part) -------------------------------------------------------------------
+    int b = blockIdx.x;
+    const int mb = b % q.mblk; b /= q.mblk;
+    const int band = b % q.nbands;
+    const int part = b / q.nbands;
+    const int ybi = band % q.yb, zbi = (band / q.yb) % q.zb, n = band / (q.yb * q.zb);
+    const int z0 = zbi * 2, y0 = ybi * q.TY;
+    const int m0 = mb * 64;
+    const int PX = q.PX, PYX = q.PY * q.PX;
+    const bool flip = p.taps.slot[0] != 0;               // data gradient: tap offset d' uses weight slot 26 - d'
+
+    // ---- halo DMA lane constants -------------------------------------------------------------------------------------
+    int hvoff[MT_NH];
+#pragma unroll
+    for (int k = 0; k < MT_NH; ++k) {
+        const int pos = (wave * MT_NH + k) * 32 + (lane >> 1);
+        const int pz = pos / PYX, rem = pos - pz * PYX, py = rem / PX, px = rem - py * PX;
+        const int iz = z0 - 1 + pz, iy = y0 - 1 + py, ix = px - 1;
+        const bool ok = pos < q.P && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const int half = (lane & 1) ^ ((pos >> 3) & 1);
+        hvoff[k] = ok ? (((iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + half * 8) * 2 : (int)0x80000000;
+    }
+    const long sample_elems = (long)p.Di * p.Hi * p.Wi * p.ld_x;
+    int hbuf = 0;                                        // byte offset of the halo buffer the NEXT halo DMA fills
+    auto dma_halo = [&](int chunk, bool live) {          // chunk = absolute 16-channel chunk index
+        const int c0 = chunk * 16;
+        const bool part2 = c0 >= p.csplit;
+        const half_t* base = (part2 ? p.x2 : p.x) + (long)n * sample_elems + (part2 ? c0 - p.csplit : c0);
+        const int nrec = live ? (int)((sample_elems - (part2 ? c0 - p.csplit : c0)) * 2) : 0;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < MT_NH; ++k) mt_dma16(rs, smem + hbuf + (wave * MT_NH + k) * 1024, hvoff[k]);
+        hbuf ^= MT_HALO;
+    };
+
+    // ---- weight-fragment DMA: per iteration the two row blocks of (tap, chunk) -> ring slot -------------------------
+    // lane i fetches row ((i & 31) + 8 kq) & 31, half hk of the fragment: the LDS image is then lane-linear (ds_read_b128 at
+    // lane * 16, conflict free) and MFMA row rho holds output channel 32 rb + ((rho + 8 kq) & 31): the channels a wave
+    // finalises (quad kq) are always its accumulator quad 0
+    const int avoff = ((((lane & 31) + 8 * kq) & 31) * 32 + hk * 16);
+    const int kc16 = p.KCpad >> 4;
+    const long rb_stride = (long)kc16 * 27 * 512;        // halves between the two row blocks of a (chunk, tap)
+    const bool rb1_live = m0 + 32 < p.Mpad;
+    int tapslot[MT_NIT];                                 // weight slot of this wave's taps (-1: none)
+    int toffb[MT_NIT];                                   // halo byte offset of the tap relative to the centre position
+#pragma unroll
+    for (int it = 0; it < MT_NIT; ++it) {
+        const int tap = kq * MT_NIT + it;
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        tapslot[it] = tap < 27 ? (flip ? 26 - tap : tap) : -1;
+        toffb[it] = tap < 27 ? (((dz - 1) * q.PY + (dy - 1)) * PX + (dx - 1)) * 32 : 0;
+    }
+    const half_t* const wblk = p.wp + (long)(m0 >> 5) * rb_stride;
+    int aslot = 0;                                       // ring slot (bytes) the NEXT weight DMA fills
+    auto dma_a = [&](int it, int chunk, bool live) {     // it compile-time after unrolling
+        const bool ok = live && tapslot[it] >= 0;
+        const half_t* f0 = wblk + ((long)chunk * 27 + (ok ? tapslot[it] : 0)) * 512;
+        __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)f0, 0, ok ? 1024 : 0, 0x00020000);
+        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + rb_stride), 0, (ok && rb1_live) ? 1024 : 0, 0x00020000);
+        char* dst = aring + wave * (MT_AR * 2048) + aslot;
+        mt_dma16(r0, dst, avoff);
+        mt_dma16(r1, dst + 1024, avoff);
+        aslot = (aslot + 2048) & (MT_AR * 2048 - 1);
+    };
+
+    // ---- B-fragment lane addresses: centre position of the lane's voxel in every column tile ------------------------
+    const int nv = q.TY * p.Lw;                          // voxels of a sub-tile
+    int lb[WN], ooff[WN];
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int vv = ct * 32 + v;
+        const int vc = vv < nv ? vv : nv - 1;
+        const int yy = vc / p.Lw, xx = vc - yy * p.Lw;
+        lb[ct] = (((sub + 1) * q.PY + (yy + 1)) * PX + (xx + 1)) * 32 + hk * 16;
+        const int oz = z0 + sub, oy = y0 + yy;
+        ooff[ct] = (vv < nv && oz < p.Ld && oy < p.Lh) ? ((oz * p.Ho + oy) * p.Wo + xx) : -1;
+    }
+
+    floatx16 acc[2][WN];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][ct][i] = 0.f;
+
+    const int c_begin = part * q.cpp, nc = q.cpp;
+    half8 fa[PIPE ? 2 : 1][2], fb[WN];
+    int rslot = 0;                                       // ring slot (bytes) of the iteration whose fragments are read next
+    int rbuf = 0;                                        // halo buffer the current chunk reads
+    auto load_a = [&](int set) {                         // set compile-time
+        const char* ab = aring + wave * (MT_AR * 2048) + rslot + lane * 16;
+        fa[set][0] = *reinterpret_cast<const half8*>(ab);
+        fa[set][1] = *reinterpret_cast<const half8*>(ab + 1024);
+        rslot = (rslot + 2048) & (MT_AR * 2048 - 1);
+    };
+    auto load_b = [&](int it, int ct) {                  // it, ct compile-time
+        const int bb = lb[ct] + rbuf + toffb[it];
+        fb[ct] = *reinterpret_cast<const half8*>(smem + (bb ^ ((bb >> 4) & 16)));
+    };
+
+    // ---- prologue: halo of the first chunk, the first MT_AR weight iterations -----------------------------------------
+    // (weight iterations are numbered i = c * 7 + it over the part's chunks; the first MT_AR = 4 are (chunk 0, it 0..3))
+    dma_halo(c_begin, true);
+    dma_a(0, c_begin, true);
+    dma_a(1, c_begin, true);
+    dma_a(2, c_begin, true);
+    dma_a(3, c_begin, true);
+    mt_wait_vm<2 * (MT_AR - 1)>();                       // halo(0) and A(0) landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    dma_halo(c_begin + 1, nc > 1);
+
+#pragma unroll 1
+    for (int c = 0; c < nc; ++c) {
+        const int chunk = c_begin + c;
+        // here: A(c*7) landed; halo(c) landed for every wave (barrier); in flight, oldest first: A(+1), A(+2), A(+3), halo(c+1)
+        load_a(0);
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) load_b(0, ct);
+#pragma unroll
+        for (int it = 0; it < MT_NIT; ++it) {
+            const int cur = PIPE ? (it & 1) : 0, nxt = PIPE ? ((it + 1) & 1) : 0;
+            if (PIPE && it + 1 < MT_NIT) {
+                // weights of iteration it + 1 (issued MT_AR - 1 refills ago): younger than them are the two later iterations (4) and,
+                // for it + 1 <= 3 -- issued in the previous chunk -- the next chunk's halo (4)
+                if (it + 1 <= MT_AR - 1) mt_wait_vm<2 * (MT_AR - 2) + MT_NH>();
+                else mt_wait_vm<2 * (MT_AR - 2)>();
+                load_a(nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][rb], fb[ct], acc[rb][ct], 0, 0, 0);
+                if (PIPE) {
+                    if (it + 1 < MT_NIT) load_b(it + 1, ct);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slot just consumed with iteration i + MT_AR (= it + 4 of this chunk, or it - 3 of the next one)
+            if (it + MT_AR < MT_NIT) dma_a(it + MT_AR, chunk, true);
+            else dma_a(it + MT_AR - MT_NIT, chunk + 1, c + 1 < nc);
+            if (!PIPE && it + 1 < MT_NIT) {
+                // fragments of iteration it + 1: allowed in flight = the two later weight iterations + this one's refill (6), + the
+                // next chunk's halo while it is younger than A(it + 1)
+                if (it + 1 <= MT_AR - 1) mt_wait_vm<2 * (MT_AR - 1) + MT_NH>();
+                else mt_wait_vm<2 * (MT_AR - 1)>();
+                load_a(0);
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct) load_b(it + 1, ct);
+            }
+        }
+        if (c + 1 < nc) {
+            // next chunk: A((c+1)*7) (issued at it = 3) landed, and with it the older halo(c + 1); every wave is done reading
+            // halo(c) once it arrives at the barrier (its fragment reads were consumed by MFMAs it has issued)
+            mt_wait_vm<2 * (MT_AR - 1)>();
+            __builtin_amdgcn_s_barrier();
+            rbuf ^= MT_HALO;
+            dma_halo(chunk + 2, c + 2 < nc);
+        }
+    }
+    mt_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                        // LDS is free: exchange of the four tap quarters' partial sums
+
+    // ---- reduction over the tap quarters + store ---------------------------------------------------------------------
+    // accumulator quad a of wave kq holds channel quad Q = (a + kq) & 3 (rows rotated): quad 0 is its own, quad a > 0 goes to wave
+    // Q's region, source slot 3 - a.  Region of (sub, Q): [3 slots][WN tiles][64 lanes x 16 B].
+    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+    const long vbase = (long)n * p.Do * p.Ho * p.Wo;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        if (rb) __builtin_amdgcn_s_barrier();            // round 0's readers are done
+#pragma unroll
+        for (int a = 1; a < 4; ++a) {
+            const int Q = (a + kq) & 3;
+            char* dst = smem + (((sub * 4 + Q) * 3 + (3 - a)) * WN) * 1024 + lane * 16;
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) {
+                const floatx4 w = {acc[rb][ct][4 * a], acc[rb][ct][4 * a + 1], acc[rb][ct][4 * a + 2], acc[rb][ct][4 * a + 3]};
+                *reinterpret_cast<floatx4*>(dst + ct * 1024) = w;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* src = smem + (((sub * 4 + kq) * 3) * WN) * 1024 + lane * 16;
+        const int m = m0 + rb * 32 + 8 * kq + 4 * hk;
+        const bool m_ok = m < p.M;
+        floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.ksplit == 1 && m_ok) bv = *reinterpret_cast<const floatx4*>(p.bias + m);
+        const bool part2 = m0 + rb * 32 >= p.msplit;
+        half_t* const yt = part2 ? p.y2 - p.msplit : p.y;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            floatx4 r = {acc[rb][ct][0], acc[rb][ct][1], acc[rb][ct][2], acc[rb][ct][3]};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) r += *reinterpret_cast<const floatx4*>(src + (s * WN + ct) * 1024);
+            if (ooff[ct] < 0 || !m_ok) continue;
+            const long vox = vbase + ooff[ct];
+            if (p.ksplit > 1) {
+                *reinterpret_cast<floatx4*>(p.scratch + ((long)part * nvox + vox) * p.Mpad + m) = r;
+                continue;
+            }
+            r += bv;
+            half4* dst = reinterpret_cast<half4*>(yt + vox * p.ld_y + m);
+            if (p.accumulate) {
+                const half4 old = *dst;
+                r[0] += (float)old[0]; r[1] += (float)old[1]; r[2] += (float)old[2]; r[3] += (float)old[3];
+            }
+            const half4 o = {(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
+            *dst = o;
+        }
+    }
+}
+
+int mt_num_cu() {
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return lnn_cu_budget(num_cu);
+}
+
+// band geometry for a (H, W) plane: the (WN, TY) with the fewest MFMA columns per plane whose halo fits the LDS image
+bool mt_geometry(const ConvParams& p, int& WN, int& TY, double& eff) {
+    WN = 0; TY = 0; eff = 0.0;
+    for (int wn = 4; wn <= 5; ++wn) {
+        int ty = (32 * wn) / p.Lw;
+        if (ty > p.Lh) ty = p.Lh;
+        while (ty >= 1 && 4L * (ty + 2) * (p.Lw + 2) > MT_NW * MT_NH * 32) --ty;
+        if (ty < 1) continue;
+        const double e = (double)p.Lh * p.Lw / ((double)lnn_cdiv(p.Lh, ty) * 32 * wn);
+        if (e > eff + 1e-9) { eff = e; WN = wn; TY = ty; }
+    }
+    return WN != 0;
+}
+
+template <int WN, bool PIPE>
+int launch_mt(hipStream_t s, ConvParams& p, const MTLaunch& q, int grid, const char* name) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_mt_kernel<WN, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, MT_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((igemm_conv_mt_kernel<WN, PIPE>), dim3(grid), dim3(512), MT_LDS, s, p, q);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
+
+}  // namespace
+
+bool lnn_conv_s1_mt_supported(const ConvParams& p) {
+    if (p.os != 1 || p.pad_lo != 1 || p.taps.ntaps != 27 || p.wtaps != 27) return false;
+    if (p.C % 16 != 0 || p.Mpad % 32 != 0 || p.M % 8 != 0) return false;
+    if (p.ld_x % 8 != 0 || p.ld_y % 8 != 0) return false;
+    if (p.csplit != 0x7fffffff && p.csplit % 16 != 0) return false;
+    if (p.msplit != 0x7fffffff && p.msplit % 32 != 0) return false;
+    if (p.Di != p.Do || p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    if ((double)p.Di * p.Hi * p.Wi * p.ld_x * 2.0 >= 2147483648.0) return false;
+    int wn, ty; double eff;
+    return mt_geometry(p, wn, ty, eff);
+}
+
+// fraction of the MFMA columns that carry real voxels (band geometry x plane-pair padding): the automatic selection asks for >= 0.7
+double lnn_conv_s1_mt_efficiency(const ConvParams& p) {
+    int wn, ty; double eff;
+    if (!lnn_conv_s1_mt_supported(p) || !mt_geometry(p, wn, ty, eff)) return 0.0;
+    return eff * p.Ld / (2.0 * lnn_cdiv(p.Ld, 2));
+}
+
+// K parts this launch would use with a workspace of ws_elems floats (1 = no split)
+int lnn_conv_s1_mt_ksplit(const ConvParams& p, const float* ws, long ws_elems) {
+    int wn, ty; double eff;
+    if (!mt_geometry(p, wn, ty, eff)) return 1;
+    const long items = (long)lnn_cdiv(p.Mpad, 64) * p.N * lnn_cdiv(p.Ld, 2) * lnn_cdiv(p.Lh, ty);
+    const int nchunks = p.C / 16;
+    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+    const int cus = mt_num_cu();
+    int best = 1;
+    if (!ws) return 1;
+    for (int k = 2; k <= 16; ++k)
+        if (nchunks % k == 0 && nchunks / k >= 2 && items * k <= cus + cus / 16 && ws_elems >= (long)k * nvox * p.Mpad) best = k;
+    return items * 2 <= cus ? best : 1;
+}
+
+int lnn_launch_conv_s1_mt(hipStream_t s, ConvParams& p, float* ws, long ws_elems, const char* name) {
+    LNN_REQUIRE(lnn_conv_s1_mt_supported(p), "%s: shape not supported by the macro-tile kernel", name);
+    int WN, TY; double eff;
+    mt_geometry(p, WN, TY, eff);
+    MTLaunch q;
+    q.mblk = lnn_cdiv(p.Mpad, 64);
+    q.zb = lnn_cdiv(p.Ld, 2); q.yb = lnn_cdiv(p.Lh, TY);
+    q.TY = TY; q.PY = TY + 2; q.PX = p.Lw + 2; q.P = 4 * q.PY * q.PX;
+    q.nbands = p.N * q.zb * q.yb;
+    const int ks = lnn_conv_s1_mt_ksplit(p, ws, ws_elems);
+    p.ksplit = ks;
+    p.scratch = ks > 1 ? ws : nullptr;
+    q.cpp = (p.C / 16) / ks;
+    const int grid = q.mblk * q.nbands * ks;
+    static int pipe = -1;
+    if (pipe < 0) { const char* e = getenv("LNN_MT_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; }
+    const int rc = pipe ? (WN == 5 ? launch_mt<5, true>(s, p, q, grid, name) : launch_mt<4, true>(s, p, q, grid, name))
+                        : (WN == 5 ? launch_mt<5, false>(s, p, q, grid, name) : launch_mt<4, false>(s, p, q, grid, name));
+    if (rc != LNN_OK || ks == 1) return rc;
+    return lnn_launch_splitk_finalize(s, p, name);
+}

@@ -801,8 +801,9 @@ class UNetEngine:
                     presummed.add(id(xb))
                 elif item.gx2 is not None:
                     self._probed("dgrad", item, lambda: nat.call(
-                        "lnn_conv3d_dgrad_cat", item.y, K, self._wp(item.wp_dgrad), item.gx,
-                        item.gx2, item.gx.ld, item.gx.C, N, D, H, W, C, K, 1 if item.gx_accumulate else 0))
+                        "lnn_conv3d_dgrad_cat_ws", item.y, K, self._wp(item.wp_dgrad), item.gx,
+                        item.gx2, item.gx.ld, item.gx.C, N, D, H, W, C, K, 1 if item.gx_accumulate else 0,
+                        splitk_ws, splitk_ws.numel()))
                 else:
                     self._probed("dgrad", item, lambda: nat.call(
                         "lnn_conv3d_dgrad_ws", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld,

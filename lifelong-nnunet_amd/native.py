@@ -34,6 +34,7 @@ SIGNATURES = {
     "lnn_conv3d_fwd_in_stats": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _l]),
     "lnn_conv3d_dgrad_ws": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l]),
     "lnn_conv3d_dgrad_cat": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "lnn_conv3d_dgrad_cat_ws": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l]),
     "lnn_conv3d_wgrad_cat": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
     "lnn_convT3d_k2s2_fwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "lnn_convT3d_k2s2_dgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),

@@ -582,7 +582,7 @@ def test_batch_dice_data_parallel_exchange_equals_full_batch():
     assert float((got - dfull).abs().max()) <= 1e-6 * float(dfull.abs().max())
 
 
-@pytest.mark.parametrize("which", [5, 7, 8, 9])
+@pytest.mark.parametrize("which", [5, 7, 8, 9, 10])
 def test_every_stride1_conv_kernel_variant(which):
     """The automatic selection picks v5 / v7 / v8 / v9 by layer shape, so the small parity shapes above only exercise v5:
     pin each shipped stride-1 kernel in turn and run forward + dgrad (with and without accumulation) on all
@@ -843,7 +843,7 @@ def test_conv3d_cat_ops_match_concatenated_tensor(N, Ca, Cb, K, D, H, W):
     xc = torch.zeros((N, D, H, W, ld), dtype=torch.float16, device=DEV); xc[..., :Cb] = xb[..., Ca:]
     dyb, _ = to_cl_h(dy)
     wf, wd = pack_conv_fwd(w), pack_conv_dgrad(w)
-    for which in (-1, 5, 7, 8, 9):
+    for which in (-1, 5, 7, 8, 9, 10):
         assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
         try:
             y1 = torch.empty((N, D, H, W, K), dtype=torch.float16, device=DEV); y2 = torch.empty_like(y1)
@@ -950,3 +950,99 @@ def test_wgrad_deterministic_variants(case):
             nat.call("lnn_conv3d_wgrad_cat_det", xa, xb, 32, 32, dy, K, p1, N, D, H, W, C, K, scratch, 1024)
         else:
             nat.call("lnn_conv3d_wgrad_det", x, ld, dy, K, p1, N, D, H, W, C, K, stride, scratch, 1024)
+
+
+# The deep stride-1 layers of BASELINE configs[1] at exactly the bench shapes (N = 2; 160x192x160 plan, levels 3-5):
+# name, Ca (+ Cb for a concatenated input), K, D, H, W
+DEEP_LAYERS = [("enc3.1 256->256", 256, 0, 256, 20, 24, 20), ("dec1.0 512->256 cat", 256, 256, 256, 20, 24, 20),
+               ("enc4.1 320->320", 320, 0, 320, 10, 12, 10), ("dec0.0 640->320 cat", 320, 320, 320, 10, 12, 10),
+               ("enc5.1 320->320", 320, 0, 320, 5, 6, 5)]
+
+
+@pytest.mark.parametrize("name,Ca,Cb,K,D,H,W", DEEP_LAYERS, ids=[c[0].split()[0] for c in DEEP_LAYERS])
+@pytest.mark.parametrize("which", [-1, 10])
+def test_deep_layers_at_bench_shapes(name, Ca, Cb, K, D, H, W, which):
+    """Forward (+ bias, split-K workspace as the engine passes it) and data gradient of the level 3-5 stride-1 convolutions at the
+    BASELINE shapes against F.conv3d on the CPU in fp32 (2e-3 / 3e-3: fp16 storage, fp32 accumulation in a different order),
+    with the automatic kernel selection and with the macro-tile kernel (igemm_conv_mt.hip) pinned.  Concatenated inputs go through
+    the *_cat entries (two tensors, never materialised), their data gradient through lnn_conv3d_dgrad_cat_ws.
+    Layers: test/network_architecture/test_MultiHead_Module.py:346-415; forward order generic_ViT_UNet.py:261-286."""
+    N, C = 2, Ca + Cb
+    g = torch.Generator().manual_seed(C + K + D)
+    x = torch.randn((N, C, D, H, W), generator=g) * 0.5
+    w = torch.randn((K, C, 3, 3, 3), generator=g) * (2.0 / (27 * C)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    dy = torch.randn((N, K, D, H, W), generator=g) * 0.5
+    xq, wq, dyq = x.half().float(), w.half().float(), dy.half().float()
+    ref = F.conv3d(xq, wq, b, padding=1)
+    ref_dx = F.conv_transpose3d(dyq, wq, None, padding=1)
+    xb, _ = to_cl_h(x)
+    dyb, _ = to_cl_h(dy)
+    wf, wd = pack_conv_fwd(w.to(DEV)), pack_conv_dgrad(w.to(DEV))
+    sk = torch.full((8 * N * D * H * W * ((max(C, K) + 31) // 32) * 32,), float("nan"), device=DEV)      # contents must not matter
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    mean, rstd = torch.zeros(N * K, device=DEV), torch.zeros(N * K, device=DEV)
+    y = torch.full((N, D, H, W, K), 7.0, dtype=torch.float16, device=DEV)
+    assert nat.lib().lnn_debug_force_conv_kernel(which) == 0
+    try:
+        if Cb:
+            xa, xc = xb[..., :Ca].contiguous(), xb[..., Ca:].contiguous()
+            nat.call("lnn_conv3d_fwd_in_stats", xa, xc, max(Ca, Cb), Ca, wf, b.to(DEV), y, N, D, H, W, C, K, 1, 1e-5, mean, rstd, ws, sk, sk.numel())
+            da = torch.full((N, D, H, W, Ca), 7.0, dtype=torch.float16, device=DEV); dc = torch.full((N, D, H, W, Cb), 7.0, dtype=torch.float16, device=DEV)
+            nat.call("lnn_conv3d_dgrad_cat_ws", dyb, K, wd, da, dc, max(Ca, Cb), Ca, N, D, H, W, C, K, 0, sk, sk.numel())
+            dx = torch.cat([da, dc], dim=-1)
+        else:
+            nat.call("lnn_conv3d_fwd_in_stats", xb, None, C, 0, wf, b.to(DEV), y, N, D, H, W, C, K, 1, 1e-5, mean, rstd, ws, sk, sk.numel())
+            dx = torch.full((N, D, H, W, C), 7.0, dtype=torch.float16, device=DEV)
+            nat.call("lnn_conv3d_dgrad_ws", dyb, K, wd, dx, C, N, D, H, W, C, K, 1, 0, sk, sk.numel())
+        torch.cuda.synchronize()
+    finally:
+        nat.lib().lnn_debug_force_conv_kernel(-1)
+    assert rel_err(from_cl_h(y, K), ref) < 2e-3
+    assert rel_err(from_cl_h(dx, C), ref_dx) < 3e-3
+    # the statistics the call returns are those of the stored tensor
+    yf = y.float().reshape(N, D * H * W, K)
+    assert float((mean - yf.mean(1).reshape(-1)).abs().max()) <= 1e-4 * float(yf.abs().max())
+
+
+@pytest.mark.parametrize("C,K,D,H,W,acc", [(32, 96, 3, 9, 10, 0), (64, 64, 5, 12, 10, 1), (16, 40, 3, 24, 20, 1), (48, 32, 7, 6, 5, 0),
+                                            (32, 64, 4, 8, 40, 0)])
+def test_macro_tile_kernel_split_k_and_ragged_bands(C, K, D, H, W, acc):
+    """igemm_conv_mt.hip pinned on small volumes: odd plane counts (the last band has one live plane), a last row band shorter than
+    TY, output channels that are not a multiple of 64 (the second row block of a channel block is dead), 40-wide rows (the widest
+    band the 32 KB halo image holds), the K split over chunks with a NaN-filled workspace (fixed-order finalize: bit-reproducible),
+    accumulate into an existing gradient."""
+    N = 2
+    g = torch.Generator().manual_seed(C * K + W)
+    x = torch.randn((N, C, D, H, W), generator=g) * 0.5
+    w = torch.randn((K, C, 3, 3, 3), generator=g) * 0.1
+    b = torch.randn(K, generator=g)
+    dy = torch.randn((N, K, D, H, W), generator=g) * 0.5
+    base = torch.randn((N, C, D, H, W), generator=g)
+    ref = F.conv3d(x.half().float(), w.half().float(), b, padding=1)
+    ref_dx = F.conv_transpose3d(dy.half().float(), w.half().float(), None, padding=1) + (base.half().float() if acc else 0)
+    xb, _ = to_cl_h(x)
+    dyb, _ = to_cl_h(dy)
+    wf, wd = pack_conv_fwd(w.to(DEV)), pack_conv_dgrad(w.to(DEV))
+    sk = torch.full((16 * N * D * H * W * ((max(C, K) + 31) // 32) * 32,), float("nan"), device=DEV)
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=DEV)
+    mean, rstd = torch.zeros(N * K, device=DEV), torch.zeros(N * K, device=DEV)
+    ys, dxs = [], []
+    assert nat.lib().lnn_debug_force_conv_kernel(10) == 0
+    try:
+        for wsbuf in (None, sk, sk):
+            y = torch.full((N, D, H, W, K), 7.0, dtype=torch.float16, device=DEV)
+            nat.call("lnn_conv3d_fwd_in_stats", xb, None, C, 0, wf, b.to(DEV), y, N, D, H, W, C, K, 1, 1e-5, mean, rstd, ws,
+                     wsbuf, 0 if wsbuf is None else wsbuf.numel())
+            dx, _ = to_cl_h(base, ld=C + 8)
+            nat.call("lnn_conv3d_dgrad_ws", dyb, K, wd, dx, C + 8, N, D, H, W, C, K, 1, acc, wsbuf, 0 if wsbuf is None else wsbuf.numel())
+            ys.append(y); dxs.append(dx)
+        torch.cuda.synchronize()
+    finally:
+        nat.lib().lnn_debug_force_conv_kernel(-1)
+    for y, dx in zip(ys, dxs):
+        assert rel_err(from_cl_h(y, K), ref) < 2e-3
+        assert rel_err(from_cl_h(dx, C), ref_dx) < 3e-3
+    assert torch.equal(ys[1], ys[2]) and torch.equal(dxs[1], dxs[2])        # split-K: slices added in a fixed order
+    if not acc:
+        assert torch.all(dxs[0][..., C:] == 0)                                   # channel padding of the buffer untouched

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--down2", type=int, default=-1, help="lnn_debug_force_down2_kernel: 0 tile kernel, 1 z-streaming kernel")
     ap.add_argument("--gen", type=int, default=-1, help="lnn_debug_set_gen_mode: 0 never the generic flattened-voxel kernels, 1 always, -1 automatic")
+    ap.add_argument("--force", type=int, default=-1, help="lnn_debug_force_conv_kernel for the timed stride-1 calls (5, 7, 8, 9, 10 = macro-tile)")
     ap.add_argument("--phases", action="store_true", help="print the v3 conv kernel's per-phase cycle split")
     ap.add_argument("--check", default="", help="comma list of forced kernels (e.g. 5,9): run fwd/dgrad with each and compare outputs")
     ap.add_argument("--wgrad-phases", action="store_true", help="print the stride-1 wgrad kernel's per-phase cycle split (LNN_WGRAD_DEBUG=4)")
@@ -41,6 +42,7 @@ def main():
     dev = "cuda:0"
     nat.lib().lnn_debug_force_down2_kernel(a.down2)
     nat.lib().lnn_debug_set_gen_mode(a.gen)
+    nat.lib().lnn_debug_force_conv_kernel(a.force)
     ws = torch.zeros(1 << 24, device=dev)          # split-K scratch the engine hands to the small layers
     wdbg = None
     if a.wgrad_phases:
@@ -102,12 +104,21 @@ def main():
         nat.call("lnn_pack_weights", w, wd, 27, C, K, 27, C * 27, 1)
         panel = torch.zeros(nat.query("lnn_wgrad_panel_elems", 27, K, C), device=dev)
         flops = 2.0 * N * Do * Ho * Wo * C * K * 27
+        xa = xb = dxa = dxb = None
         if cat:
             xa = x[..., :C // 2].contiguous(); xb = x[..., C // 2:].contiguous()
+            dxa = torch.empty_like(xa); dxb = torch.empty_like(xb)
+        st_mean, st_rstd = torch.zeros(N * K, device=dev), torch.zeros(N * K, device=dev)
+        st_ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, K), dtype=torch.float64, device=dev)
         fns = {"fwd": (lambda: nat.call("lnn_conv3d_fwd_cat", xa, xb, C // 2, C // 2, wf, b, y, K, N, D, H, W, C, K)) if cat else
                       (lambda: nat.call("lnn_conv3d_fwd_g", x, C, wf, b, y, K, N, D, H, W, C, K, 3, 3, 3, s, s, s, ws, ws.numel())) if a.gen == 1 else
                       (lambda: nat.call("lnn_conv3d_fwd", x, C, wf, b, y, K, N, D, H, W, C, K, s)),
-               "dgrad": lambda: nat.call("lnn_conv3d_dgrad_ws", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0, ws, ws.numel()),
+               "dgrad": (lambda: nat.call("lnn_conv3d_dgrad_cat_ws", dy, K, wd, dxa, dxb, C // 2, C // 2, N, D, H, W, C, K, 0, ws, ws.numel())) if cat else
+                        (lambda: nat.call("lnn_conv3d_dgrad_ws", dy, K, wd, dx, C, N, D, H, W, C, K, s, 0, ws, ws.numel())),
+               # conv + InstanceNorm statistics as the engine calls it (split-K workspace passed; includes the statistics pass where
+               # the kernel has no fused epilogue)
+               "fwd_st": lambda: nat.call("lnn_conv3d_fwd_in_stats", xa if cat else x, xb if cat else None, C // 2 if cat else C, C // 2 if cat else 0,
+                                          wf, b, y, N, D, H, W, C, K, s, 1e-5, st_mean, st_rstd, st_ws, ws, ws.numel()),
                "wgrad": lambda: nat.call("lnn_conv3d_wgrad", x, C, dy, K, panel, N, D, H, W, C, K, s)}
         if s == 1 and C == K:
             # the stage's second block: its data gradient with / without pass 1 of the first block's normalisation backward in the epilogue
