@@ -35,7 +35,7 @@ struct ConvParams {
     int red_ld = 0;
     const float *red_mean = nullptr, *red_rstd = nullptr, *red_gamma = nullptr, *red_beta = nullptr;
     float red_slope = 0.f;
-    int ksplit = 1;               // v7 only: the 16-channel chunk loop of a unit is split over ksplit blocks which write fp32 partial
+    int ksplit = 1;               // macro-tile kernel: the 16-channel chunk range is split over ksplit blocks which write fp32 partial
     float* scratch = nullptr;     //   sums to scratch[part][voxel][Mpad]; lnn_launch_splitk_finalize adds the slices and converts
     unsigned long long* dbg;   // optional phase-cycle accumulators (LNN_DEBUG_PHASES), null in production
     TapTable taps;
@@ -49,16 +49,13 @@ __host__ __device__ __forceinline__ long lnn_panel_off(int slot, int m, int kc, 
     return ((((long)(m >> 5) * (KCpad >> 4) + (kc >> 4)) * wtaps + slot) * 32 + (m & 31)) * 16 + (kc & 15);
 }
 
-// v2 stride-1 3x3x3 kernel (igemm_conv_v2.hip): persistent blocks, software-pipelined staging.
-int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name);
-// v7 (igemm_conv_v7.hip): single-buffered, two 8-wave blocks per CU (hardware interleaves staging and MFMA phases)
-int lnn_launch_conv_s1_v7(hipStream_t s, ConvParams& p, const char* name);
-// v8 (igemm_conv_v8.hip): v5 structure with a 64-output-channel register tile (M >= 64)
-int lnn_launch_conv_s1_v8(hipStream_t s, ConvParams& p, const char* name);
+// tile kernel ("v5", igemm_conv_tile.hip): 8x8x8-voxel x 32-channel units, persistent blocks, software-pipelined staging
+int lnn_launch_conv_s1_tile(hipStream_t s, ConvParams& p, const char* name);
 // v9 (igemm_conv_v9.hip): z-streaming, register-resident weights, direct-to-LDS input ring (C = 32 / 64, M % 32 == 0)
 bool lnn_conv_s1_v9_supported(const ConvParams& p);
 int lnn_conv_s1_v9_stats_slots(const ConvParams& p);
 bool lnn_conv_s1_v9_red_supported(const ConvParams& p);      // a fused-reduce instance (EPI = 2) exists for this shape
+// igemm_conv_mt.hip: scratch slices -> fp16 output (+ bias, + old value when accumulating)
 // norm_act.hip: mean / rstd from per-slot partial sums pws[a][slot][n*C + c] (the finalize half of lnn_instnorm_stats)
 int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name);
 int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd);

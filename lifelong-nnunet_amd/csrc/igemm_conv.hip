@@ -2,8 +2,11 @@
 // the C-ABI entry points, the kernel selection, and the first-layer (C == 1) kernel.
 //
 // Production kernels (one file each, selected in the wrappers at the bottom of this file):
-//   stride-1 conv fwd / dgrad   igemm_conv_v2.hip (v5), igemm_conv_v7.hip (>= 128 input channels, small volumes),
-//                               igemm_conv_v8.hip (>= 64 output channels)
+//   stride-1 conv fwd / dgrad   igemm_conv_v9.hip (z-streaming: 32 / 64 / 128 input channels, >= 32 planes), igemm_conv_mt.hip (macro
+//                               tile + in-block split-K: every other layer with >= 128 input channels), igemm_conv_tile.hip (the "v5" tile
+//                               kernel: everything else -- narrow layers on short volumes, odd channel counts).  The tile kernels v7 / v8 of
+//                               rounds 1-5 were retired in round 6: the macro-tile kernel is faster on every shape they served
+//                               (profiles/r06_kbench_mt_first.txt)
 //   stride-2 conv fwd, convT dgrad      igemm_down2.hip          stride-2 dgrad, convT fwd      igemm_up2.hip
 // (The generic first-version kernel -- one non-pipelined kernel for every op, stride-2 dgrad as 8 launches -- was the A/B
 // baseline of rounds 1-2 and was removed in round 3; profiles/r01_* hold its numbers.)
@@ -166,7 +169,7 @@ static unsigned long long* g_dbg = nullptr;
 extern "C" int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64) { g_dbg = (unsigned long long*)dev_ptr_6x_u64; return LNN_OK; }
 
 // runtime override for the parity tests (lnn_debug_force_conv_kernel): -1 = automatic selection,
-// 5 / 7 / 8 / 9 / 10 = that stride-1 kernel (10 = the macro-tile kernel) for every layer it supports
+// 5 / 9 / 10 = that stride-1 kernel (5 = tile kernel, 9 = z-streaming, 10 = macro tile) for every layer it supports
 int g_force_conv = -1;
 
 // v9 (z-streaming, register-resident weights): the kernel for the 32- / 64-input-channel layers of the two highest
@@ -201,39 +204,11 @@ bool use_down2s(const ConvParams& p) {
     return p.Ld >= 16;
 }
 
-// v7 (two single-buffered 8-wave blocks per CU) vs v5 (one double-buffered block with resident weights): measured
-// +4..18 % for layers with >= 128 input channels (weights streamed anyway, many short steps), -3..15 % below.
-// LNN_CONV_V7=1 / 0 forces / forbids v7 (A/B measurements).
-bool use_v7(int C) {
-    if (g_force_conv >= 0) return g_force_conv == 7;
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("LNN_CONV_V7");
-        v = e ? (e[0] == '1' ? 1 : 0) : -1;
-    }
-    return v < 0 ? C >= 128 : v == 1;
-}
-
-// v8 (64-output-channel register tile): measured +4..16 % over v5 / v7 for layers with >= 64 output channels as long as
-// the (8x8x8 tile x 64 channel) units fill the chip at least twice; below that the 32-channel units of v7 / v5 spread
-// better.  LNN_CONV_V8=1 / 0 forces / forbids it (A/B measurements).
-bool use_v8(const ConvParams& p) {
-    if (g_force_conv >= 0) return g_force_conv == 8 && p.M >= 64;
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("LNN_CONV_V8");
-        v = e ? (e[0] == '1' ? 1 : 0) : -1;
-    }
-    if (p.M < 64 || v == 0) return false;
-    if (v == 1) return true;
-    const long units = (long)p.N * lnn_cdiv(p.Ld, 8) * lnn_cdiv(p.Lh, 8) * lnn_cdiv(p.Lw, 8) * lnn_cdiv(p.M, 64);
-    return units >= 512;
-}
-
 // Macro-tile kernel with in-block split-K (igemm_conv_mt.hip, round 6): the deep levels -- >= 128 input channels on volumes too short
 // for the z-streaming kernel -- wherever its band geometry fills >= 70 % of its MFMA columns (levels 3 and 4 of the 160x192x160 plan:
-// 1.0 / 0.94; level 5's 5x6x5 volume fills 0.2 and stays on the split-K tile kernel).  LNN_CONV_MT=1 / 0 forces / forbids it (A/B
-// measurements); lnn_debug_force_conv_kernel(10) forces it wherever supported.
+// 1.0 / 0.94; level 5's 5x6x5 volume fills 0.2 of them and is still 5-8 % faster than the retired split-K tile kernel was), and the
+// >= 128-channel layers the z-streaming kernel has no instance for (256 -> 128 @ 40x48x40: 0.296 vs 0.309 ms on the retired v8).
+// LNN_CONV_MT=1 / 0 forces / forbids it (A/B measurements); lnn_debug_force_conv_kernel(10) forces it wherever supported.
 bool use_mt(const ConvParams& p) {
     if (!lnn_conv_s1_mt_supported(p)) return false;
     if (g_force_conv >= 0) return g_force_conv == 10;
@@ -244,31 +219,7 @@ bool use_mt(const ConvParams& p) {
     }
     if (v == 0) return false;
     if (v == 1) return true;
-    return p.C >= 128 && p.Ld < 32 && lnn_conv_s1_mt_efficiency(p) >= 0.7;
-}
-
-// Split-K for the small deep layers (v7 path): the 8x8x8-tile x 32-channel units do not fill the chip (level 5 of C2: 20 units
-// for 512 resident blocks) and each walks C/16 = 20..40 chunk steps serially -- 60..240 us of latency per launch, 14 launches
-// per step.  With a caller-provided fp32 workspace the chunk loop is split over up to 8 blocks per unit.
-int pick_ksplit(const ConvParams& p, const float* ws, long ws_elems) {
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("LNN_NO_SPLITK"); off = (e && e[0] == '1') ? 1 : 0; }
-    if (off || !ws) return 1;
-    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
-    const long units = (long)p.N * lnn_cdiv(p.Ld, 8) * lnn_cdiv(p.Lh, 8) * lnn_cdiv(p.Lw, 8) * lnn_cdiv(p.M, 32);
-    const int nchunks = (p.C + 15) / 16;
-    int best = 1;
-    for (int ks = 2; ks <= 8; ks *= 2)
-        if (nchunks % ks == 0 && nchunks / ks >= 2 && units * ks <= 1024 && ws_elems >= (long)ks * nvox * p.Mpad) best = ks;
-    return units < 512 ? best : 1;
-}
-int launch_v7_maybe_splitk(hipStream_t s, ConvParams& p, float* ws, long ws_elems, const char* name) {
-    const int ks = pick_ksplit(p, ws, ws_elems);
-    if (ks == 1) return lnn_launch_conv_s1_v7(s, p, name);
-    p.ksplit = ks;
-    p.scratch = ws;
-    if (int e = lnn_launch_conv_s1_v7(s, p, name)) return e;
-    return lnn_launch_splitk_finalize(s, p, name);
+    return p.C >= 128;
 }
 
 }  // namespace
@@ -318,7 +269,7 @@ extern "C" int lnn_debug_force_down2_kernel(int which) {
 }
 
 extern "C" int lnn_debug_force_conv_kernel(int which) {
-    LNN_REQUIRE(which == -1 || which == 5 || (which >= 7 && which <= 10), "lnn_debug_force_conv_kernel: %d is not one of -1, 5, 7, 8, 9, 10", which);
+    LNN_REQUIRE(which == -1 || which == 5 || which == 9 || which == 10, "lnn_debug_force_conv_kernel: %d is not one of -1, 5, 9, 10", which);
     g_force_conv = which;
     return LNN_OK;
 }
@@ -370,7 +321,7 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
             p.taps.pos_off[t] = (unsigned short)(((t / 9) * PY + (t / 3) % 3) * PX + t % 3);
             p.taps.slot[t] = (unsigned char)t;
         }
-        if (use_mt(p)) return lnn_launch_conv_s1_mt(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,mt)");
+        if (!use_v9(p) && use_mt(p)) return lnn_launch_conv_s1_mt(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,mt)");
     }
     if (!x2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * p.Do * p.Ho * p.Wo)) {
         const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
@@ -387,9 +338,7 @@ int conv3d_fwd_impl(lnn_stream_t s_, const void* x, const void* x2, int c_a, int
             return rc;
         }
         if (use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_fwd(s1,v9)");
-        if (use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_fwd(s1,v8)");
-        if (use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_fwd(s1,v7)");
-        return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_fwd(s1,v5)");
+        return lnn_launch_conv_s1_tile(s, p, "lnn_conv3d_fwd(s1,v5)");
     }
     if (use_down2s(p)) {
         if (stats_pws && ld_y == K && lnn_down2s_stats_slots(p) <= 1024) {      // fused InstanceNorm statistics (dense output tensor only)
@@ -467,7 +416,7 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
             p.taps.pos_off[t] = (unsigned short)((dz * PY + dyy) * PX + dxx);
             p.taps.slot[t] = (unsigned char)((2 - dz) * 9 + (2 - dyy) * 3 + (2 - dxx));
         }
-        if (use_mt(p)) return lnn_launch_conv_s1_mt(s, p, splitk_ws, splitk_elems, "lnn_conv3d_dgrad(s1,mt)");
+        if (!use_v9(p) && use_mt(p)) return lnn_launch_conv_s1_mt(s, p, splitk_ws, splitk_elems, "lnn_conv3d_dgrad(s1,mt)");
     }
     if (!dx2 && lnn_gen_prefers(stride == 1 ? LNN_GEN_OP_CONV_S1 : LNN_GEN_OP_CONV_S2, (long)N * Di * Hi * Wi)) {
         const int k3[3] = {3, 3, 3}, st3[3] = {stride, stride, stride};
@@ -476,9 +425,7 @@ int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp
     if (stride == 1) {
         p.dbg = g_dbg;
         if (use_v9(p)) return lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad(s1,v9)");
-        if (use_v8(p)) return lnn_launch_conv_s1_v8(s, p, "lnn_conv3d_dgrad(s1,v8)");
-        if (use_v7(p.C)) return launch_v7_maybe_splitk(s, p, splitk_ws, splitk_elems, "lnn_conv3d_dgrad(s1,v7)");
-        return lnn_launch_conv_s1_v2(s, p, "lnn_conv3d_dgrad(s1,v5)");
+        return lnn_launch_conv_s1_tile(s, p, "lnn_conv3d_dgrad(s1,v5)");
     }
     // stride 2: dx[2l+par] = sum over taps d with (par - d + 1) even: dy[l + (par - d + 1)/2]
     //   par = 0 -> d = 1 (offset 0);  par = 1 -> d = 0 (offset +1), d = 2 (offset 0)

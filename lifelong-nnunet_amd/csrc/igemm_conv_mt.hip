@@ -24,7 +24,7 @@
 //     ordered by counted s_waitcnt vmcnt only -- no barrier, no staging registers, and every memory operation of the kernel is
 //     a DMA, so the counts are exact (cdna_hip_programming.md section 5: mixing load kinds de-pipelines);
 //   * levels with fewer band x channel-block items than CUs split the chunk range over `ksplit` blocks that write fp32 partial
-//     tiles to the caller's workspace ([part][voxel][Mpad], as the v7 split-K), lnn_launch_splitk_finalize adds the slices.
+//     tiles to the caller's workspace ([part][voxel][Mpad], fixed slice order: deterministic), lnn_launch_splitk_finalize adds the slices.
 // LDS image of the halo: [position][32 B], 16-byte half index XOR ((position >> 3) & 1): the 16-lane groups of a
 // ds_read_b128 touch 16 consecutive positions up to row wraps -> conflict free for every tap shift (two lanes collide only if
 // their positions are congruent mod 16).  The key is applied to the SOURCE half each DMA lane fetches (linear LDS writes).
@@ -295,6 +295,31 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
     }
 }
 
+// scratch (fp32, [ksplit][voxel][Mpad]) -> y (fp16, slices added in order, + bias, + old value when accumulating)
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvParams p, long nvox) {
+    const int q4 = p.Mpad >> 2;
+    const long total = nvox * q4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long vox = i / q4;
+        const int m = (int)(i % q4) * 4;
+        if (m >= p.M) continue;
+        floatx4 r = *reinterpret_cast<const floatx4*>(p.scratch + vox * p.Mpad + m);
+        for (int k = 1; k < p.ksplit; ++k) r += *reinterpret_cast<const floatx4*>(p.scratch + ((long)k * nvox + vox) * p.Mpad + m);
+        if (p.bias) {
+            const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + m);
+            r += bv;
+        }
+        half_t* yrow = (m < p.msplit ? p.y : p.y2 - p.msplit) + vox * p.ld_y;
+        half4* dst = reinterpret_cast<half4*>(yrow + m);
+        if (p.accumulate) {
+            const half4 old = *dst;
+            r[0] += (float)old[0]; r[1] += (float)old[1]; r[2] += (float)old[2]; r[3] += (float)old[3];
+        }
+        const half4 o = {(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
+        *dst = o;
+    }
+}
+
 int mt_num_cu() {
     static int num_cu = 0;
     if (!num_cu) {
@@ -332,6 +357,15 @@ int launch_mt(hipStream_t s, ConvParams& p, const MTLaunch& q, int grid, const c
 }
 
 }  // namespace
+
+int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name) {
+    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+    const long total = nvox * (p.Mpad >> 2);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, s, p, nvox);
+    LNN_CHECK_LAUNCH(name);
+    return LNN_OK;
+}
 
 bool lnn_conv_s1_mt_supported(const ConvParams& p) {
     if (p.os != 1 || p.pad_lo != 1 || p.taps.ntaps != 27 || p.wtaps != 27) return false;

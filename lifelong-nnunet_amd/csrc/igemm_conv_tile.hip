@@ -1,7 +1,9 @@
-// Stride-1 3x3x3 implicit-GEMM convolution: persistent blocks, double-buffered LDS, resident weights (v5).
+// Stride-1 3x3x3 implicit-GEMM convolution, TILE kernel ("v5"): persistent blocks, double-buffered LDS, resident weights.
 //
-// This is the kernel behind ~90 % of the forward + dgrad FLOPs of the U-Net (every stride-1 conv and its
-// data gradient).  Same GEMM mapping as igemm_conv.hip (MFMA rows = output channels, columns = 32 voxels,
+// Since round 2 the big layers run on the z-streaming kernel (igemm_conv_v9.hip) and since round 6 the deep ones on the macro-tile
+// kernel (igemm_conv_mt.hip); this one serves what is left: narrow layers (< 128 input channels) on short volumes -- the levels of
+// Hippocampus-sized plans, the toy shapes of the parity tests -- and odd channel counts.  It was the kernel behind ~90 % of the
+// forward + dgrad FLOPs in round 1.  Same GEMM mapping as igemm_conv.hip (MFMA rows = output channels, columns = 32 voxels,
 // v_mfma_f32_32x32x16_f16); everything around the MFMAs was shaped by measurements of the previous versions:
 //   v2: PMC showed 12.6 VALU per MFMA and 51 % of LDS cycles lost to bank conflicts;
 //   v3: s_memtime phase split: re-fetching the 9-tap weight panels every 36 MFMAs kept the waves in load issue;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_conv_s1_v5_kernel(const ConvParam
 
 }  // namespace
 
-int lnn_launch_conv_s1_v2(hipStream_t s, ConvParams& p, const char* name) {
+int lnn_launch_conv_s1_tile(hipStream_t s, ConvParams& p, const char* name) {
     p.tiles_z = lnn_cdiv(p.Ld, TZ); p.tiles_y = lnn_cdiv(p.Lh, TY); p.tiles_x = lnn_cdiv(p.Lw, TX);
     const int mblocks = lnn_cdiv(p.M, MB);
     const int tiles = p.N * p.tiles_z * p.tiles_y * p.tiles_x;

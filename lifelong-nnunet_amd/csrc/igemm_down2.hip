@@ -34,7 +34,7 @@ struct DnCfg {
     static constexpr int WN = (WCHUNKS + NT - 1) / NT;
 };
 
-__device__ __forceinline__ void dn_lane_voxel(int v, int& r, int& x) {   // see igemm_conv_v2.hip
+__device__ __forceinline__ void dn_lane_voxel(int v, int& r, int& x) {   // see igemm_conv_tile.hip
     if (v < 4) { r = 0; x = v; }
     else if (v < 12) { r = 2; x = v - 4; }
     else if (v < 16) { r = 0; x = v - 8; }

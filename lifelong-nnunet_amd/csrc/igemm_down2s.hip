@@ -58,7 +58,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-__device__ __forceinline__ void lane_voxel_d(int v, int& r, int& x) {   // see igemm_conv_v2.hip
+__device__ __forceinline__ void lane_voxel_d(int v, int& r, int& x) {   // see igemm_conv_tile.hip
     if (v < 4) { r = 0; x = v; }
     else if (v < 12) { r = 2; x = v - 4; }
     else if (v < 16) { r = 0; x = v - 8; }

@@ -16,7 +16,7 @@
 //   * double-buffered LDS: halo tile 3x9x9 positions x 32 B (7.6 KB), weights NTAP x 32 rows x 32 B (27 / 8 KB);
 //     next chunk's global loads are issued before the MFMAs and written to the other buffers after them: one
 //     barrier per chunk;
-//   * same conflict-free LDS layout as the stride-1 kernel (igemm_conv_v2.hip): 32-byte rows, 16-byte half XOR-keyed
+//   * same conflict-free LDS layout as the stride-1 kernel (igemm_conv_tile.hip): 32-byte rows, 16-byte half XOR-keyed
 //     with the halo row parity (B) / bit 3 of the output channel (A).
 #include "igemm_common.h"
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_up2_kernel(const ConvParams p, in
     const int nck16 = p.KCpad >> 4;
     const half_t* const wbase = p.wp + (long)(m0 >> 5) * nck16 * Cfg::NTAP * 512;
 
-    // unconditional loads + masks (a predicated load serialises the prefetch, see igemm_conv_v2.hip)
+    // unconditional loads + masks (a predicated load serialises the prefetch, see igemm_conv_tile.hip)
     auto load_x = [&](int c0) {
         if (interior) {
             const half_t* bp = p.x + xbase + c0;

@@ -15,9 +15,10 @@ int lnn_debug_tr16_probe(lnn_stream_t s, float* out256);
 /* debug: when set to a zeroed device buffer of 6 uint64, the stride-1 conv kernel accumulates shader-clock cycles
  * per phase {issue loads, MFMA, barrier, LDS stores, barrier} and the step count; pass NULL to disable. */
 int lnn_debug_set_phase_buffer(void* dev_ptr_6x_u64);
-/* Parity tests only: pin the stride-1 conv forward / dgrad kernel (-1 automatic, 5 = v5, 7 = v7, 8 = v8 where
- * the layer has >= 64 output channels, 9 = v9 where the layer has 32 / 64 / 128 input channels and no accumulation,
- * v5 otherwise; any other value is an error -- the generic first-version kernel was deleted in round 3).  Process-wide, not thread-safe: a debug hook, not part of the production surface. */
+/* Parity tests only: pin the stride-1 conv forward / dgrad kernel (-1 automatic, 5 = the tile kernel "v5", 9 = the z-streaming kernel
+ * where the layer has 32 / 64 / 128 input channels and no accumulation, 10 = the macro-tile kernel where the contraction is a multiple
+ * of 16 channels and the band's halo fits its LDS image, the tile kernel otherwise; any other value is an error -- v7 / v8 were retired in
+ * round 6).  Process-wide, not thread-safe: a debug hook, not part of the production surface. */
 int lnn_debug_force_conv_kernel(int which);
 /* Parity tests only: pin the stride-2 conv forward kernel (-1 automatic, 0 the tile kernel, 1 the z-streaming kernel wherever
  * it supports the layer: 32 / 64 input channels, output channels a multiple of 64, even extents).  Process-wide. */

@@ -29,7 +29,7 @@ def parse(path, counter):
 SHORT = [("igemm_conv_s1_v9_kernelILi(\\d)ELi(\\d)ELi(\\d)ELi(\\d)", "conv_s1_v9<{0},{1},{2},epi={3}>"),
          ("igemm_down2s_kernelILi(\\d)ELi(\\d)ELi(\\d)ELi(\\d)ELb(\\d)", "down2s<{0},{1},{2},ext={3},stats={4}>"),
          ("igemm_wgrad_s1_v5_kernel", "wgrad_s1_v5"), ("igemm_wgrad_s2_v2_kernelILi(\\d)", "wgrad_s2<ext={0}>"),
-         ("igemm_conv_s1_v7_kernel", "conv_s1_v7"), ("igemm_conv_s1_v8_kernelILb(\\d)", "conv_s1_v8<{0}>"),
+         ("igemm_conv_mt_kernelILi(\\d)ELb(\\d)", "conv_s1_mt<wn={0},pipe={1}>"), ("igemm_conv_s1_v5_kernel", "conv_s1_tile"),
          ("igemm_up2_kernelILi(\\d)", "up2<{0}>"), ("igemm_down2_kernelILi(\\d)", "down2_tile<ext={0}>"),
          ("in_lrelu_seg_bwd_(\\w+?)_kernelILi(\\d)ELb(\\d)", "in_lrelu_seg_bwd_{0}<K={1},prior={2}>"),
          ("wgrad_c1_kernelILi4ELi8ELb(\\d)", "wgrad_c1<fused={0}>"), ("conv_c1_fwd_kernelILb(\\d)", "conv_c1_fwd<stats={0}>"),
