@@ -2,7 +2,10 @@
 
 Mirror of nnunet_ext/training/network_training/ewc/nnUNetTrainerEWC.py: ``initialize`` :98-140 (EWC loss with
 the network's ``named_parameters()`` GENERATOR), ``reinitialize`` :142-177, ``run_training`` :179-230,
-``run_iteration`` :232-250 (fresh generator after every iteration), ``after_train`` :252-310.
+``run_iteration`` :232-250 (fresh generator after every iteration), ``after_train`` :252-310; the side data of a finished task
+(``ewc_data/fisher_values.pkl`` / ``param_values.pkl``, ``fisher_at`` / ``params_at`` in ``already_trained_on``) is written at
+the end of ``run_training`` :205-228 and read back by the constructor :66-78 and by ``initialize(prev_trainer_path=...)``
+:104-115, so that a trainer restored from a checkpoint keeps regularising.
 
 Reference behaviours reproduced in parity mode:
   * the penalty covers only the FIRST previous task (generator exhausted by the outer task loop);
@@ -17,6 +20,7 @@ fp16 path squares ``param.grad`` right after ``amp_grad_scaler.scale(loss).backw
 ``fisher_mode='accumulate'`` is the optional true empirical Fisher (mean of g^2 over the batches, all-reduced
 across ranks once per task).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -37,12 +41,31 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
         self.ewc_lambda = ewc_lambda
         self.fisher_mode = fisher_mode
         self.fisher_keeps_loss_scale = fisher_keeps_loss_scale
+        # EWC.py:40-58: the method's entries of the fold's ``already_trained_on`` record
+        fold = self.already_trained_on.setdefault(str(self.fold), {})
+        fold.setdefault('used_ewc_lambda', self.ewc_lambda)
+        fold.setdefault('fisher_at', None)
+        fold.setdefault('params_at', None)
+        # EWC.py:66-78: empty dictionaries, or what an earlier run of this trainer left on disk
         self.fisher = OrderedDict()
         self.params = OrderedDict()
+        self._load_fisher_and_params()
+        # EWC.py:96
+        self.ewc_data_path = None if self.trained_on_path is None else os.path.join(self.trained_on_path, 'ewc_data')
+
+    def _load_fisher_and_params(self):
+        fold = self.already_trained_on[str(self.fold)]
+        if fold.get('fisher_at') is None or fold.get('params_at') is None:
+            return False
+        self.fisher = self._load_side_data(fold['fisher_at'])
+        self.params = self._load_side_data(fold['params_at'])
+        return True
 
     def initialize(self, training=True, force_load_plans=False, num_epochs=500, prev_trainer_path=None,
                    call_for_eval=False):
         super().initialize(training, force_load_plans, num_epochs, prev_trainer_path, call_for_eval)
+        if prev_trainer_path is not None:            # EWC.py:104-115
+            self._load_fisher_and_params()
         self.loss = DC_and_CE_loss({'batch_dice': self.batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})
         self.loss = EWCLoss(self.loss, self.ds_loss_weights, self.ewc_lambda, self.fisher, self.params,
                             self.network.named_parameters())
@@ -61,7 +84,26 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
         self.fisher[task] = OrderedDict()
         self.params[task] = OrderedDict()
         self.after_train()
+        self.save_fisher_and_params()
         return ret
+
+    def save_fisher_and_params(self):
+        """EWC.py:205-228: dump both dictionaries, record where in ``already_trained_on`` (first time only), rewrite the
+        ``<ext>_trained_on.pkl`` file and the ``.pkl`` next to the final checkpoint so that a restore finds them."""
+        if self.ewc_data_path is None:
+            return
+        os.makedirs(self.ewc_data_path, exist_ok=True)
+        self._dump_side_data(os.path.join(self.ewc_data_path, 'fisher_values.pkl'), self.fisher)
+        self._dump_side_data(os.path.join(self.ewc_data_path, 'param_values.pkl'), self.params)
+        fold = self.already_trained_on[str(self.fold)]
+        if fold['fisher_at'] is None or fold['params_at'] is None:
+            fold['fisher_at'] = os.path.join(self.ewc_data_path, 'fisher_values.pkl')
+            fold['params_at'] = os.path.join(self.ewc_data_path, 'param_values.pkl')
+            self._write_trained_on_file()
+            self.update_init_args()
+            if self.output_folder is not None:
+                os.makedirs(self.output_folder, exist_ok=True)
+                self.save_init_args(os.path.join(self.output_folder, "model_final_checkpoint.model"))
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, detach=True, no_loss=False):
         loss = super().run_iteration(data_generator, do_backprop, run_online_evaluation, detach, no_loss)

@@ -22,7 +22,13 @@ own ``run_iteration`` / ``calculate_target_logits`` produced):
 MI355X-first differences that do not change results:
   * teacher logits and predictions stay in HBM (288 GB) instead of round-tripping through host memory
     (``.cpu()`` at LWF.py:343, HF.py:254); the KL is one fused device reduction instead of CPU fp32 ops.
+Restore support (LWF.py:60-87,203-251,262-275,427-448): at the end of the freeze run the whole MultiHead_Module is saved as
+``model_freezed.model`` and recorded in ``already_trained_on`` (``freeze_run_finished``, ``ftasks_at_time_of_checkpoint``,
+``factive_task_at_time_of_checkpoint``, ``freezed_model_at``); a trainer constructed from that record skips the freeze run,
+recomputes the teacher logits from the saved network (``_load_model_and_update_target_logits``) and continues with the LwF phase.
 """
+import os
+
 import torch
 
 from ....losses import DC_and_CE_loss, MultipleOutputLossLWF as LwFloss
@@ -50,7 +56,14 @@ class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
         super().__init__(split, task, *args, **kwargs)
         self.lwf_temperature = lwf_temperature
         self.same_batch_predictions = same_batch_predictions
-        self.freeze_run = True
+        # LWF.py:44-66: the method's entries of the fold's ``already_trained_on`` record
+        fold = self.already_trained_on.setdefault(str(self.fold), {})
+        fold.setdefault('used_lwf_temperature', self.lwf_temperature)
+        fold.setdefault('freeze_run_finished', False)
+        fold.setdefault('ftasks_at_time_of_checkpoint', list())
+        fold.setdefault('factive_task_at_time_of_checkpoint', None)
+        fold.setdefault('freezed_model_at', None)
+        self.freeze_run = not fold['freeze_run_finished']          # LWF.py:77
         self.do_val = False
         self.batch_idx = 0
         self.target_logits = None
@@ -69,32 +82,96 @@ class nnUNetTrainerLWF(nnUNetTrainerMultiHead):
             self.reinitialize(task)
         if str(task) not in self.mh_network.heads:
             self.mh_network.add_new_task(task, use_init=not self.transfer_heads)
+            self.freeze_run = True                                 # LWF.py:152: a new task starts with its freeze run
+        fold = self.already_trained_on[str(self.fold)]
         if len(self.mh_network.heads) == 1:
-            # very first task: conventional training (LWF.py:173-184)
+            # very first task: conventional training (LWF.py:168-184)
+            fold['freeze_run_finished'] = True
             self.freeze_run = False
             self.loss = self.loss_orig
             self.network = self.mh_network.assemble_model(task)
             ret = super().run_training(task, output_folder)
             self.freeze_run = True
+            self._reset_restore_record()
             return ret
-        # ---- phase 1: head-only training, body frozen, plain loss (LWF.py:189-201)
-        self.freeze_run = True
-        self.network = self.mh_network.assemble_model(task, freeze_body=True)
-        self.loss = self.loss_orig
-        self._run_epoch_loop()
-        self.epoch = 0
-        self.all_tr_losses, self.all_val_losses = [], []
-        self.freeze_run = False
-        # ---- phase 2: teacher logits of EVERY head with the pre-LwF body (LWF.py:236-251)
-        self.network = self.mh_network.assemble_model(task, freeze_body=False)
-        self.target_logits = calculate_target_logits(self.mh_network, self.tr_gen, self.num_batches_per_epoch, self.fp16)
+        if fold['freeze_run_finished'] and fold.get('freezed_model_at'):
+            # restored after the freeze run of THIS task had finished (LWF.py:186-190): teacher logits from the saved network
+            self.freeze_run = False
+            self._load_model_and_update_target_logits()
+        else:
+            # ---- phase 1: head-only training, body frozen, plain loss (LWF.py:189-201)
+            self.freeze_run = True
+            self.network = self.mh_network.assemble_model(task, freeze_body=True)
+            self.loss = self.loss_orig
+            self._run_epoch_loop()
+            self.epoch = 0
+            self.all_tr_losses, self.all_val_losses = [], []
+            self.freeze_run = False
+            self._save_freezed_model()
+            # ---- phase 2: teacher logits of EVERY head with the pre-LwF body (LWF.py:236-251)
+            self.network = self.mh_network.assemble_model(task, freeze_body=False)
+            self.target_logits = calculate_target_logits(self.mh_network, self.tr_gen, self.num_batches_per_epoch, self.fp16)
         # ---- phase 3: train everything with the LwF loss (LWF.py:253-261)
         self.network.train()
         self.loss = self.LwFloss
         self.batch_idx = 0
         ret = super().run_training(task, output_folder)
         self.freeze_run = True
+        self._reset_restore_record()
         return ret
+
+    def _save_freezed_model(self):
+        """LWF.py:220-239: the MultiHead_Module at the end of the freeze run -- ``model.* / body.* / heads.<task>.*``, no optimiser
+        state -- as ``model_freezed.model`` in the output folder, and the record a restore needs."""
+        fold = self.already_trained_on[str(self.fold)]
+        fold['freeze_run_finished'] = True
+        fold['ftasks_at_time_of_checkpoint'] = list(self.mh_network.heads.keys())
+        fold['factive_task_at_time_of_checkpoint'] = self.mh_network.active_task
+        if self.output_folder is None:
+            return
+        os.makedirs(self.output_folder, exist_ok=True)
+        self._write_trained_on_file()
+        self.update_init_args()
+        path = os.path.join(self.output_folder, "model_freezed.model")
+        keep = (fold.get('tasks_at_time_of_checkpoint'), fold.get('active_task_at_time_of_checkpoint'), fold.get('checkpoint_should_exist'))
+        self.save_checkpoint(path, False)
+        # save_checkpoint records the REGULAR checkpoint's head list; this file is not one (LWF.py:237 calls the grandparent's)
+        fold['tasks_at_time_of_checkpoint'], fold['active_task_at_time_of_checkpoint'], fold['checkpoint_should_exist'] = keep
+        fold['freezed_model_at'] = path
+        self._write_trained_on_file()
+
+    def _load_model_and_update_target_logits(self):
+        """LWF.py:427-448: the saved end-of-freeze-run state produces the teacher logits; the trainer's own weights (they come from
+        the regular checkpoint) are untouched afterwards.  The reference loads the state into a ``copy.deepcopy`` of the
+        MultiHead_Module; here the module's tensors are views of one parameter arena, so the saved state is loaded INTO it and the
+        current one put back -- same logits, no second network in HBM."""
+        fold = self.already_trained_on[str(self.fold)]
+        saved = torch.load(fold['freezed_model_at'], map_location='cpu', weights_only=False)
+        mh = self.mh_network
+        current = {k: v.detach().clone() for k, v in mh.state_dict().items()}
+        heads, active = list(mh.heads.keys()), mh.active_task
+        mh.add_n_tasks_and_activate(fold['ftasks_at_time_of_checkpoint'], fold['factive_task_at_time_of_checkpoint'])
+        curr = set(mh.state_dict().keys())
+        mh.load_state_dict({(k[7:] if (k not in curr and k.startswith("module.")) else k): v for k, v in saved["state_dict"].items()})
+        mh.model.mark_params_changed()
+        self.target_logits = calculate_target_logits(mh, self.tr_gen, self.num_batches_per_epoch, self.fp16)
+        mh.add_n_tasks_and_activate(heads, active)
+        mh.load_state_dict(current)
+        mh.model.mark_params_changed()
+        self.network = mh.model
+
+    def _reset_restore_record(self):
+        """LWF.py:262-275: the freeze-run record is per task."""
+        fold = self.already_trained_on[str(self.fold)]
+        fold['freeze_run_finished'] = False
+        fold['ftasks_at_time_of_checkpoint'] = list()
+        fold['factive_task_at_time_of_checkpoint'] = None
+        fold['freezed_model_at'] = None
+        if self.output_folder is not None:
+            self._write_trained_on_file()
+            self.update_init_args()
+            os.makedirs(self.output_folder, exist_ok=True)
+            self.save_init_args(os.path.join(self.output_folder, "model_final_checkpoint.model"))
 
     def _lwf_active(self):
         """LWF.py:303,309: the LwF branch runs unless freeze_run / do_val, and only with more than one head."""

@@ -13,6 +13,7 @@ the reference's data dicts ``{'data','target','keys'}`` (MH.py:606-608).
 from __future__ import annotations
 
 import warnings
+import os
 from collections import OrderedDict
 from typing import Callable, Optional
 
@@ -75,6 +76,13 @@ class nnUNetTrainerMultiHead:
         self.deterministic_wgrad = deterministic_wgrad
         self.already_trained_on = already_trained_on or OrderedDict()
         self.tasks_list_with_char = tasks_list_with_char
+        # MH.py:125-129: ``<extension>_trained_on.pkl`` and the side data of the regularising trainers (``ewc_data/``, ``rw_data/``)
+        # live two levels above the fold's output folder.  (The reference inserts its task-sequence folders there through
+        # ``_build_output_path``; that directory layout belongs to its run scripts, SURVEY.md section 2 "side", and a caller who wants
+        # it sets ``trained_on_path`` after construction.)  Without an output folder nothing is written.
+        self.output_folder = output_folder
+        self.trained_on_path = None if output_folder is None else \
+            os.path.dirname(os.path.dirname(os.path.realpath(output_folder)))
         # upstream nnUNetTrainerV2 constants
         self.initial_lr, self.weight_decay = 1e-2, 3e-5
         self.max_grad_norm = 12.0       # clip_grad_norm_(parameters, 12) of the iteration (MH.py:629,640); None: no clipping
@@ -482,6 +490,63 @@ class nnUNetTrainerMultiHead:
         self.network = self.mh_network.assemble_model(active)
         self.network.train()
         return ret_joined
+
+    # ------------------------------------------------------------------------------------------ side data of a finished task
+    def update_init_args(self):
+        """MH.py:1199-1208: position 12 of the stored constructor arguments is ``already_trained_on``."""
+        init = list(self.init_args)
+        init[12] = self.already_trained_on
+        self.init_args = tuple(init)
+
+    def save_init_args(self, fname):
+        """MH.py:1210-1222: (re)write ``fname + '.pkl'`` -- constructor arguments, class, plans -- next to a checkpoint."""
+        import pickle
+        info = OrderedDict(init=self.init_args, name=self.__class__.__name__, plans=self.plans)
+        info["class"] = str(self.__class__)
+        with open(fname + ".pkl", "wb") as f:
+            pickle.dump(info, f)
+
+    def _write_trained_on_file(self):
+        """``<extension>_trained_on.pkl`` (MH.py:380,872,1125: ``write_pickle``; the EWC / RW / LwF trainers write the same name
+        with ``save_json``, EWC.py:224 -- SURVEY.md Appendix C -- and the base class overwrites it with a pickle at the next
+        checkpoint: the pickle is what is written here)."""
+        if self.trained_on_path is None:
+            return
+        import pickle
+        os.makedirs(self.trained_on_path, exist_ok=True)
+        with open(os.path.join(self.trained_on_path, self.extension + '_trained_on.pkl'), "wb") as f:
+            pickle.dump(self.already_trained_on, f)
+
+    @staticmethod
+    def read_trained_on_file(path):
+        """``<extension>_trained_on.pkl`` as a dictionary, whichever of its two writers produced it: ``write_pickle`` (MH.py:380) or
+        ``save_json`` under the same name (EWC.py:224, RW.py:296, LWF.py:233)."""
+        import json
+        import pickle
+        with open(path, "rb") as f:
+            raw = f.read()
+        try:
+            return pickle.loads(raw)
+        except Exception:
+            return json.loads(raw.decode())
+
+    @staticmethod
+    def _dump_side_data(path, per_task):
+        """``write_pickle`` of a dict task -> parameter name -> tensor (EWC.py:215-216, RW.py:283-285), as CPU tensors: the reference
+        calls ``.cpu()`` and drops the result (EWC.py:206-211), so ITS pickles hold device tensors and only load on a machine with
+        the same device; both kinds load here."""
+        import pickle
+        out = OrderedDict((task, OrderedDict((k, v.detach().cpu().clone()) for k, v in d.items())) for task, d in per_task.items())
+        with open(path, "wb") as f:
+            pickle.dump(out, f)
+
+    def _load_side_data(self, path):
+        """``load_pickle`` + ``to_cuda`` (EWC.py:70-78)."""
+        import pickle
+        with open(path, "rb") as f:
+            d = pickle.load(f)
+        return OrderedDict((task, OrderedDict((k, torch.as_tensor(v).to(self.device)) for k, v in per.items()))
+                           for task, per in d.items())
 
     def save_checkpoint(self, fname=None, save_optimizer=True):
         """MH.py:1164-1197 -> upstream ``NetworkTrainer.save_checkpoint`` / ``nnUNetTrainer.save_checkpoint``: the WHOLE

@@ -15,6 +15,7 @@ Reference behaviours reproduced in parity mode:
     as the EWC trainer does).  Value semantics only: the reference additionally iterates the parameters of the network
     object that existed at ``initialize`` time (a deepcopy generation behind the trained one).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -36,13 +37,52 @@ class nnUNetTrainerRW(nnUNetTrainerMultiHead):
         self.alpha, self.rw_lambda, self.fisher_update_after = rw_alpha, rw_lambda, fisher_update_after
         assert self.alpha > 0 and self.alpha <= 1, "rw_alpha should be between 0 and 1: [0, 1]."
         self.refresh_network_params = refresh_network_params
+        # RW.py:46-68: the method's entries of the fold's ``already_trained_on`` record
+        fold = self.already_trained_on.setdefault(str(self.fold), {})
+        fold.setdefault('used_alpha', self.alpha)
+        fold.setdefault('used_rw_lambda', self.rw_lambda)
+        fold.setdefault('update_fisher_after', self.fisher_update_after)
+        for key in ('fisher_at', 'params_at', 'scores_at'):
+            fold.setdefault(key, None)
+        # RW.py:77-84: empty dictionaries, or what an earlier run of this trainer left on disk
         self.fisher, self.params, self.scores = OrderedDict(), OrderedDict(), OrderedDict()
+        self._load_f_p_s_values()
+        self.rw_data_path = None if self.trained_on_path is None else os.path.join(self.trained_on_path, 'rw_data')
         self.prev_param, self.count = None, 0
         self._f_flat = self._s_flat = self._prev_flat = None
+
+    def _load_f_p_s_values(self):
+        fold = self.already_trained_on[str(self.fold)]
+        if any(fold.get(k) is None for k in ('fisher_at', 'params_at', 'scores_at')):
+            return False
+        self.fisher = self._load_side_data(fold['fisher_at'])
+        self.params = self._load_side_data(fold['params_at'])
+        self.scores = self._load_side_data(fold['scores_at'])
+        return True
+
+    def save_f_p_s_values(self):
+        """RW.py:266-300: dump the three dictionaries and record where (first time only)."""
+        if self.rw_data_path is None:
+            return
+        os.makedirs(self.rw_data_path, exist_ok=True)
+        names = {'fisher_at': 'fisher_values.pkl', 'params_at': 'param_values.pkl', 'scores_at': 'score_values.pkl'}
+        for key, d in (('fisher_at', self.fisher), ('params_at', self.params), ('scores_at', self.scores)):
+            self._dump_side_data(os.path.join(self.rw_data_path, names[key]), d)
+        fold = self.already_trained_on[str(self.fold)]
+        if any(fold[k] is None for k in names):
+            for k, n in names.items():
+                fold[k] = os.path.join(self.rw_data_path, n)
+            self._write_trained_on_file()
+            self.update_init_args()
+            if self.output_folder is not None:
+                os.makedirs(self.output_folder, exist_ok=True)
+                self.save_init_args(os.path.join(self.output_folder, "model_final_checkpoint.model"))
 
     def initialize(self, training=True, force_load_plans=False, num_epochs=500, prev_trainer_path=None,
                    call_for_eval=False):
         super().initialize(training, force_load_plans, num_epochs, prev_trainer_path, call_for_eval)
+        if prev_trainer_path is not None:            # RW.py:101-106
+            self._load_f_p_s_values()
         assert self.fisher_update_after < self.num_batches_per_epoch, \
             "How should the fisher values and importance scores be calculated if update_after is greater than the number of iterations per epochs.."
         self.loss = DC_and_CE_loss({'batch_dice': self.batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})
@@ -87,6 +127,7 @@ class nnUNetTrainerRW(nnUNetTrainerMultiHead):
             prev_scores = {k: v.clone() for k, v in self.scores[last].items()}
             for k, v in list(self.scores[self.task].items()):
                 self.scores[self.task][k] = 0.5 * (prev_scores[k] + (v - minim) / (maxim - minim + EPSILON))
+        self.save_f_p_s_values()                     # RW.py:206
         return ret
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, detach=True, no_loss=False):

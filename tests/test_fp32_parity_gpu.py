@@ -7,6 +7,7 @@ With fp32 activations and fp64 fixed-order accumulation the HIP path follows the
     relative L2 -- the quantities the fp16-storage mode only reaches to ~1e-2;
   * two identical steps give bit-identical gradients (no atomics anywhere on this path)."""
 import json
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -511,3 +512,98 @@ def test_lwf_phase1_matches_reference(golden_dir, fp16):
     assert _rel(arr, "phase1::final_theta", after, meta["names"]) < tol
     head_names = [n for n, _ in tr.mh_network.heads["taskB"].named_parameters()]
     assert _rel(arr, "phase1::headB", dict(tr.mh_network.heads["taskB"].named_parameters()), head_names) < 10 * tol   # refreshed (LWF.py:308)
+
+
+@pytest.mark.parametrize("ext", ["ewc", "rw"])
+def test_restored_trainer_continues_bit_for_bit(ref, tmp_path, ext):
+    """VERDICT r5 task 6 / SURVEY.md 8 row f4: task A -> side data + checkpoint on disk -> a NEW trainer built from the stored record
+    (``already_trained_on`` of the checkpoint's ``.pkl``, EWC.py:66-78) + ``load_checkpoint_ram`` -> task B.  Its task-B losses equal
+    the losses of the trainer that was never torn down BIT FOR BIT (fp32 storage mode: fixed-order reductions), i.e. the regulariser
+    survives the round trip through ``ewc_data/*.pkl`` / ``rw_data/*.pkl`` exactly."""
+    import pickle
+    meta, arr = ref
+    out = tmp_path / "results" / "TaskA_TaskB" / "fold_0"
+    seeds = {"taskA": 1000, "taskB": 2000}
+    kw = dict(fisher_update_after=2, rw_alpha=0.9, rw_lambda=0.4) if ext == "rw" else {}
+    tr = _trainer(ext, seeds, 6, arr, 3, output_folder=str(out), **kw)
+    tr.run_training("taskA")
+    sub = "ewc_data" if ext == "ewc" else "rw_data"
+    assert os.path.isfile(tr.already_trained_on["0"]["fisher_at"]) and sub in tr.already_trained_on["0"]["fisher_at"]
+    fname = str(out / "model_final_checkpoint.model")
+    tr.save_checkpoint(fname)
+    losses = _record(tr)
+    tr.run_training("taskB")
+    assert len(losses) == 3 and tr.loss.tasks
+    # ---- a fresh process would do exactly this
+    info = pickle.load(open(fname + ".pkl", "rb"))
+    rec = info["init"][12]
+    assert rec["0"]["fisher_at"] and rec["0"]["finished_training_on"] == ["taskA"]
+    tr2 = _trainer(ext, seeds, 6, arr, 3, output_folder=str(out), already_trained_on=rec, **kw)
+    assert list(tr2.fisher.keys()) == ["taskA", "taskB"]      # the first trainer rewrote the files when it finished task B
+    for d in (tr2.fisher, tr2.params) + ((tr2.scores,) if ext == "rw" else ()):
+        d.pop("taskB", None)                                  # (the files were rewritten when the first trainer finished task B)
+    tr2.load_checkpoint_ram(torch.load(fname, weights_only=False))
+    tr2.epoch = 0
+    losses2 = _record(tr2)
+    tr2.run_training("taskB")
+    print(f"{ext}: task-B losses un-restored {losses} restored {losses2}")
+    assert losses2 == losses
+
+
+def test_lwf_restore_after_the_freeze_run_recomputes_the_same_teacher_logits(ref, tmp_path):
+    """LWF.py:220-239,427-448: ``model_freezed.model`` written at the end of the freeze run + the record in ``already_trained_on``; a new
+    trainer built from that record skips the freeze run, loads the saved MultiHead_Module state for the teacher pass only and ends
+    with the teacher logits the uninterrupted trainer computed -- bit for bit (fp32 storage), its own weights untouched."""
+    import copy
+    meta, arr = ref
+    out = tmp_path / "results" / "TaskA_TaskB" / "fold_0"
+    seeds = {"taskA": 1000, "taskB": 2000}
+    tr = _trainer("lwf", seeds, 40, arr, 2, output_folder=str(out))
+    tr.run_training("taskA")
+    snap = {}
+    orig = tr._save_freezed_model
+
+    def wrapped():
+        orig()
+        snap["rec"] = copy.deepcopy(tr.already_trained_on)
+        snap["state"] = {k: v.detach().clone() for k, v in tr.mh_network.state_dict().items()}
+    tr._save_freezed_model = wrapped
+    from lifelong_nnunet_amd.training.network_training.lwf import nnUNetTrainerLWF as lwf_mod
+    seen = {}
+    orig_calc = lwf_mod.calculate_target_logits
+
+    def calc(mh, gen, n, fp16=True, gpu_id=0):
+        out_ = orig_calc(mh, gen, n, fp16, gpu_id)
+        seen.setdefault("logits", {k: [t.clone() for t in v] for k, v in out_.items()})
+        return out_
+    lwf_mod.calculate_target_logits = calc
+    try:
+        tr.run_training("taskB")
+    finally:
+        lwf_mod.calculate_target_logits = orig_calc
+    rec = snap["rec"]
+    assert rec["0"]["freeze_run_finished"] is True and os.path.isfile(rec["0"]["freezed_model_at"])
+    assert rec["0"]["ftasks_at_time_of_checkpoint"] == ["taskA", "taskB"] and rec["0"]["factive_task_at_time_of_checkpoint"] == "taskB"
+    assert tr.already_trained_on["0"]["freeze_run_finished"] is False and tr.already_trained_on["0"]["freezed_model_at"] is None
+    disk = torch.load(rec["0"]["freezed_model_at"], weights_only=False)
+    assert disk["optimizer_state_dict"] is None and all(torch.equal(disk["state_dict"][k], v.cpu()) for k, v in snap["state"].items())
+    # ---- restore: same record, DIFFERENT weights in the live network (what a later regular checkpoint would hold)
+    tr2 = _trainer("lwf", seeds, 40, arr, 2, output_folder=str(out), already_trained_on=rec)
+    assert tr2.freeze_run is False
+    tr2.mh_network.add_new_task("taskB", use_init=False)
+    with torch.no_grad():
+        tr2.network.arena.theta.mul_(0.5)
+    tr2.network.mark_params_changed()
+    tr2.mh_network.update_after_iteration()
+    mine = {k: v.detach().clone() for k, v in tr2.mh_network.state_dict().items()}
+    # the uninterrupted trainer's generator stood behind the two freeze-run iterations when phase 2 started
+    tr2.task = "taskB"
+    tr2.tr_gen = iter(_batches(seeds["taskB"], 40)[2:])
+    tr2._load_model_and_update_target_logits()
+    assert list(tr2.target_logits.keys()) == list(seen["logits"].keys()) == ["taskA", "taskB"]
+    for k in seen["logits"]:
+        assert len(tr2.target_logits[k]) == len(seen["logits"][k]) == 2
+        for a, b in zip(tr2.target_logits[k], seen["logits"][k]):
+            assert torch.equal(a, b)
+    for k, v in tr2.mh_network.state_dict().items():
+        assert torch.equal(v, mine[k]), k
