@@ -72,6 +72,9 @@ int lnn_pack_weights_batched(lnn_stream_t s, const float* src_base, void* dst_ba
  * x: (N,Di,Hi,Wi,C) ld_x ; y/dy: (N,Do,Ho,Wo,K) ld_y with Do = (Di-1)/s+1.
  * wp_fwd  = lnn_pack_weights(w, 27, K, C, C*27, 27, 1);  wp_dgrad = lnn_pack_weights(w, 27, C, K, 27, C*27, 1)
  * C == 1 (image input) is handled by a dedicated path in fwd / wgrad (x is then (N,Di,Hi,Wi) fp16).
+ * Limits (explicit LNN_ERR_BAD_ARG, no slower fallback since round 5): the stride-1 weight gradient addresses a tile through 32-bit
+ * buffer-descriptor offsets, so six consecutive z-planes of x (Hi*Wi*ld_x*2 bytes each) must stay below 2 GB; the z-streaming and
+ * macro-tile forward / data-gradient kernels need one z-plane / one sample below 2 GB and otherwise hand the layer to the tile kernel.
  * ---------------------------------------------------------------------------------------------- */
 int lnn_conv3d_fwd(lnn_stream_t s, const void* x_h, int ld_x, const void* wp_fwd_h, const float* bias,
                    void* y_h, int ld_y, int N, int Di, int Hi, int Wi, int C, int K, int stride);

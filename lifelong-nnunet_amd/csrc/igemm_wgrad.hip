@@ -819,17 +819,6 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_s2s_kernel(const WgradPara
         return prep(tile_next);
     };
     auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
-    // RUN: state of the plane fetches of the tile being prefetched (set before its first issue point)
-    const half_t* rq_ptr = nullptr;
-    int rq_so = 0, rq_iz = 0, rq_qv = OOB;
-    const unsigned ldsw = lds0 + wave * 1024;
-    auto dma_q_run = [&]() {
-        const uint4v rs = wg_rsrc_n(rq_ptr, (unsigned)rq_iz < (unsigned)p.Qd ? 0x7fffffffu : 0u);
-        if (wave < 7) wg_dma16(rs, ldsw + rq_so, rq_qv);
-        rq_ptr += qplane;
-        ++rq_iz;
-        rq_so = rq_so + SLOTB == NSLOT * SLOTB ? 0 : rq_so + SLOTB;
-    };
     auto dma_q = [&](const Tile& t, int rel, int slot, int k) {    // piece run k of Q plane `rel` (0 .. EXT-1) of tile t -> ring slot
         if (k * 8 + wave >= NPI) return;
         const int iz = 2 * t.lz - p.pad_lo + rel;

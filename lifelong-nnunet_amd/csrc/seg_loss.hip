@@ -234,7 +234,10 @@ __device__ __forceinline__ void softmax_regs(const float (&x)[KMAX], int K, floa
 //   back through 2^(t + e) ~= 2^t (1 + e ln 2): ~1 ulp like expf, 5 operations;  1 / s = v_rcp_f32 + one Newton step;
 //   log(s) = v_log_f32(s) ln 2 (s in [1, K]: absolute error ~1e-7).
 __device__ __forceinline__ float exp_le0(float d) {
-    d = fmaxf(d, -126.f);         // exp(-126) is 0 in fp32 already; a logit of -inf would make the residual below inf - inf = NaN
+    // exp(-126) is 0 in fp32 already; a logit of -inf would make the residual below inf - inf = NaN.  A select, not fmaxf: fmaxf
+    // returns the non-NaN operand and a NaN logit (a blown-up step) would become probability 0 and a FINITE loss where torch's
+    // softmax / cross_entropy give NaN -- the comparison is false for NaN, so it propagates as in the reference.
+    d = d < -126.f ? -126.f : d;
     const float t = d * 1.44269504088896341f;
     float e = __builtin_fmaf(d, 1.44269504088896341f, -t);
     e = __builtin_fmaf(d, 1.92596299112661746e-8f, e);

@@ -17,6 +17,8 @@ import copy
 from collections import OrderedDict
 from typing import Type
 
+import warnings
+
 import torch
 from torch import nn
 
@@ -35,6 +37,7 @@ class MultiHead_Module(nn.Module):
     # What a NESTED split ('tu.1', ...) does after construction: True = the reference's behaviour (see _reference_resplit), False = the
     # construction-time partition is kept.  Top-level splits ('seg_outputs', 'tu', ...) are not affected.
     reference_nested_resplit = True
+    _warned_nested_resplit = False
 
     def __init__(self, class_object: Type[nn.Module], split_at, task, prev_trainer=None, *args, **kwargs):
         super().__init__()
@@ -135,6 +138,13 @@ class MultiHead_Module(nn.Module):
         them back over the trained ones, and ``add_new_task(use_init=True)`` raises (``state_init`` has the construction-time keys).
         ``MultiHead_Module.reference_nested_resplit = False`` keeps the construction-time partition instead (every tensor from the
         split on is per-task and is refreshed from the running model -- what the reference's documentation describes)."""
+        if not MultiHead_Module._warned_nested_resplit:
+            MultiHead_Module._warned_nested_resplit = True
+            warnings.warn(
+                f"MultiHead_Module(split_at={'.'.join(self.split)!r}): reproducing the reference's nested re-split (MHM.py:159-160, mutable "
+                "default arguments): from now on every tensor is body, the active head is reset to its construction-time values on each "
+                "update_after_iteration, and add_new_task(use_init=True) raises.  Set MultiHead_Module.reference_nested_resplit = False "
+                "for the documented semantics (per-task tensors from the split on).", stacklevel=3)
         parent = '.'.join(self.split[:-1]) + '.'
         self._head_names = [n for n in self._head_names if n.startswith(parent)]
         self._body_names = [n for n, _ in self.model.named_parameters()]

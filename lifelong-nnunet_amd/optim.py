@@ -145,6 +145,36 @@ class DeferredLoss:
     def __format__(self, spec):
         return format(float(self.value()), spec)
 
+    # a subclass's run_iteration may compare or do arithmetic on what the base class returns (the reference returns a numpy scalar
+    # there, MH.py:655): every numeric protocol entry resolves the copy and delegates to that scalar
+    def __bool__(self):
+        return bool(self.value())
+
+    def __neg__(self):
+        return -self.value()
+
+    def __abs__(self):
+        return abs(self.value())
+
+    def __hash__(self):
+        return hash(float(self.value()))
+
+
+def _deferred_binop(name):
+    def op(self, other):
+        other = other.value() if isinstance(other, DeferredLoss) else other
+        return getattr(self.value(), name)(other)
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "mod", "pow"):
+    setattr(DeferredLoss, f"__{_n}__", _deferred_binop(f"__{_n}__"))
+    setattr(DeferredLoss, f"__r{_n}__", _deferred_binop(f"__r{_n}__"))
+for _n in ("lt", "le", "gt", "ge", "eq", "ne"):
+    setattr(DeferredLoss, f"__{_n}__", _deferred_binop(f"__{_n}__"))
+del _n
+
 
 class FusedSGD:
     """SGD(momentum=0.99, nesterov=True) over the flat arena with ``torch.optim.SGD``'s surface
@@ -230,13 +260,20 @@ class FusedSGD:
             return h
         if self._host_ring is None:
             self._host_ring = [torch.empty(3, dtype=torch.float64).pin_memory() for _ in range(4)]
+            self._ring_handles = [None] * len(self._host_ring)
         self._ctrl_buf[2:3].copy_(loss.detach().reshape(1))
         host = self._host_ring[self._ring_i]
-        self._ring_i = (self._ring_i + 1) % len(self._host_ring)
+        # the slot's previous user (four steps ago) takes its numbers with it before the slot is overwritten: a handle that a caller
+        # kept unresolved for more than four steps still returns ITS step's values
+        prev = self._ring_handles[self._ring_i]
+        if prev is not None:
+            prev.get()
         host.copy_(self._ctrl_buf[:3], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._async = h = AsyncCtrl(host, ev)
+        self._ring_handles[self._ring_i] = h
+        self._ring_i = (self._ring_i + 1) % len(self._host_ring)
         return h
 
     def read_ctrl(self):

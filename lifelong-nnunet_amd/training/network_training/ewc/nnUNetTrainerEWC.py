@@ -146,9 +146,11 @@ class nnUNetTrainerEWC(nnUNetTrainerMultiHead):
             if exchange:
                 self.dp.begin()
                 self.network.on_grad_progress = self.dp.progress
-            self.amp_grad_scaler.scale(loss).backward()
-            if exchange:
+            try:
+                self.amp_grad_scaler.scale(loss).backward()
+            finally:
                 self.network.on_grad_progress = None
+            if exchange:
                 self.dp.finish()
             if self.fisher_mode == "accumulate":
                 nat.call("lnn_fisher_accumulate", arena.grad, facc, arena.size, unscale, 1.0 / n)

@@ -254,10 +254,14 @@ class nnUNetTrainerMultiHead:
             if self.dp is not None:
                 self.dp.begin()
                 self.network.on_grad_progress = self.dp.progress
-            self.amp_grad_scaler.backward(l)           # = scale(l).backward(), the scale as the seed gradient
+            try:
+                self.amp_grad_scaler.backward(l)       # = scale(l).backward(), the scale as the seed gradient
+            finally:
+                # also when backward raises and the caller carries on: a backward outside run_iteration exchanges nothing unless it
+                # asks to (a stale callback would all-reduce against the bucket state of THIS iteration)
+                self.network.on_grad_progress = None
             world_avg = 1.0
             if self.dp is not None:
-                self.network.on_grad_progress = None   # (a backward outside run_iteration exchanges nothing unless it asks to)
                 self.dp.finish()
                 world_avg = self.dp.averaging_factor
             inv = world_avg / scale

@@ -854,3 +854,32 @@ def test_lwf_restore_record(tmp_path):
     assert tr2.freeze_run is False
     tr2._reset_restore_record()
     assert rec["0"]["freeze_run_finished"] is False and rec["0"]["freezed_model_at"] is None
+
+
+def test_deferred_loss_behaves_like_the_numpy_scalar_the_reference_returns():
+    """``run_iteration`` returns a DeferredLoss inside the epoch loop (MH.py:655 returns a numpy scalar there); an override
+    that compares it, does arithmetic on it or asks numpy about it must keep working."""
+    from lifelong_nnunet_amd.optim import DeferredLoss
+
+    class Ctrl:
+        def get(self):
+            return (4.0, 0.0, 0.75)
+    d = DeferredLoss(Ctrl())
+    assert d > 0.5 and d < 1 and d >= 0.75 and d <= 0.75 and d == 0.75 and d != 0.5
+    assert d + 1 == 1.75 and 1 + d == 1.75 and 2 * d == 1.5 and d * 2 == 1.5 and d - 0.25 == 0.5 and 1 - d == 0.25 and d / 3 == np.float32(0.75) / 3
+    assert -d == -0.75 and abs(-1 * d) == 0.75 and d ** 2 == 0.5625 and bool(d) and not np.isnan(d) and np.isfinite(d)
+    assert float(d) == 0.75 and f"{d:.2f}" == "0.75" and np.mean([d, DeferredLoss(Ctrl())]) == 0.75
+    assert DeferredLoss(Ctrl()) + DeferredLoss(Ctrl()) == 1.5 and max(d, 0.5) is d
+
+
+def test_nested_resplit_quirk_is_announced_once():
+    """reproducing the reference's nested re-split silently turns every tensor into body -- say so, once."""
+    import warnings as w
+    MultiHead_Module._warned_nested_resplit = False
+    mh = MultiHead_Module(Generic_UNet, "tu.1", "taskA", None, 1, 8, 3, 2, device="cpu")
+    with w.catch_warnings(record=True) as rec:
+        w.simplefilter("always")
+        mh.update_after_iteration()
+        mh.update_after_iteration()
+    msgs = [str(r.message) for r in rec if "nested re-split" in str(r.message)]
+    assert len(msgs) == 1 and "reference_nested_resplit = False" in msgs[0]
