@@ -689,6 +689,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if tr.dp is not None:
+        tr.dp.collect_timing = True          # two event records per step around the wait for the gradient exchange
     eng = list(tr.network._engines.values())[0]
     probe = None
     if rank == 0 and not args.no_roofline:
@@ -720,7 +722,24 @@ def main():
         torch.cuda.synchronize()
         eng.probe, eng.overlap_wgrad = None, keep_ov
     ranks_seen, devices_seen = 1, 1
+    dp_report = None
+    if tr.dp is not None:
+        # what the gradient exchange did in the timed steps, per rank: buckets launched from inside backward vs by finish(), and how
+        # long the step's stream actually WAITED for the exchange (HIP events around the wait: the part of the all-reduce that
+        # backward did not cover).  Makes an N > 1 scaling number diagnosable: LNN_DP_BUCKET_MB / LNN_DP_STREAM select the alternatives.
+        st = tr.dp.stats(synchronize=True)
+        dp_report = {"bucket_mb": st["bucket_mb"], "buckets": st["buckets"], "stream": st["stream"],
+                     "buckets_sent_in_backward": st["buckets_sent_in_backward"], "buckets_sent_by_finish": st["buckets_sent_by_finish"],
+                     "exposed_comm_ms": st.get("exposed_comm_ms"), "exposed_comm_ms_max_step": st.get("exposed_comm_ms_max")}
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
+        per = [None] * world
+        dist.all_gather_object(per, (dt / args.steps * 1e3, None if dp_report is None else dp_report["exposed_comm_ms"]))
+        rank_ms = [p_[0] for p_ in per]
+        if dp_report is not None:
+            ex = [p_[1] for p_ in per if p_[1] is not None]
+            dp_report["exposed_comm_ms_per_rank"] = [p_[1] for p_ in per]
+            dp_report["exposed_comm_ms"] = max(ex) if ex else None       # the slowest rank's (rank 0's own value is in the list)
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -751,6 +770,11 @@ def main():
                    "conv_stack_frac_of_mfma_peak": patches_per_s / world * flops_patch / 1e12 / PEAK_MFMA_F16_TFLOPS},
     }
     out["config"].update(extra_cfg)
+    # every measurement switch that is set: empty = the shipped path
+    out["config"]["lnn_env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("LNN_")}
+    out["ms_per_step_rank_min"], out["ms_per_step_rank_max"] = min(rank_ms), max(rank_ms)
+    if dp_report is not None:
+        out["data_parallel"] = dp_report
     out["config"]["loss_fetch"] = "asynchronous: consumed by the next iteration's loss-scale decision (the trainer's epoch loop)"
     if world == 1 and not args.no_extras:
         tr.defer_loss_fetch = False

@@ -29,7 +29,6 @@
 // ds_read_b128 touch 16 consecutive positions up to row wraps -> conflict free for every tap shift (two lanes collide only if
 // their positions are congruent mod 16).  The key is applied to the SOURCE half each DMA lane fetches (linear LDS writes).
 #include "igemm_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -38,13 +37,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 template <int N>
 __device__ __forceinline__ void mt_wait_vm() {     // literal counts only (see igemm_conv_v9.hip)
-    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 10, "extend the table");
+    static_assert(N == 0 || N == 4 || N == 6 || N == 8, "extend the table");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 }
 
 __device__ __forceinline__ void mt_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voffset) {
@@ -67,10 +64,11 @@ struct MTLaunch {
     int nbands;        // N * zb * yb
 };
 
-// PIPE: the fragments of iteration it + 1 are read WHILE the MFMAs of iteration it issue (each column tile's B fragment is re-read
-// for the next tap as soon as its two MFMAs are out; the next weight pair goes to a second register pair) -- the wave no longer
-// depends on its SIMD partner to cover the LDS latency.  PIPE = false keeps the plain read-then-multiply order (A/B: LNN_MT_PIPE=0).
-template <int WN, bool PIPE>
+// The fragments of iteration it + 1 are read WHILE the MFMAs of iteration it issue: each column tile's B fragment is re-read for the next
+// tap as soon as its two MFMAs are out, the next weight pair goes to a second register pair -- the wave does not depend on its SIMD
+// partner to cover the LDS latency.  (The plain read-then-multiply order, 210 instead of 252 registers, measured 5-8 % slower on the
+// level-3 layers and 0-4 % on level 4, profiles/r06_kbench_mt_first.txt; removed.)
+template <int WN>
 __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams p, const MTLaunch q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const aring = smem + 2 * MT_HALO;
@@ -166,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
             for (int i = 0; i < 16; ++i) acc[rb][ct][i] = 0.f;
 
     const int c_begin = part * q.cpp, nc = q.cpp;
-    half8 fa[PIPE ? 2 : 1][2], fb[WN];
+    half8 fa[2][2], fb[WN];
     int rslot = 0;                                       // ring slot (bytes) of the iteration whose fragments are read next
     int rbuf = 0;                                        // halo buffer the current chunk reads
     auto load_a = [&](int set) {                         // set compile-time
@@ -200,8 +198,8 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
         for (int ct = 0; ct < WN; ++ct) load_b(0, ct);
 #pragma unroll
         for (int it = 0; it < MT_NIT; ++it) {
-            const int cur = PIPE ? (it & 1) : 0, nxt = PIPE ? ((it + 1) & 1) : 0;
-            if (PIPE && it + 1 < MT_NIT) {
+            const int cur = it & 1, nxt = (it + 1) & 1;
+            if (it + 1 < MT_NIT) {
                 // weights of iteration it + 1 (issued MT_AR - 1 refills ago): younger than them are the two later iterations (4) and,
                 // for it + 1 <= 3 -- issued in the previous chunk -- the next chunk's halo (4)
                 if (it + 1 <= MT_AR - 1) mt_wait_vm<2 * (MT_AR - 2) + MT_NH>();
@@ -214,24 +212,12 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
                     acc[rb][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][rb], fb[ct], acc[rb][ct], 0, 0, 0);
-                if (PIPE) {
-                    if (it + 1 < MT_NIT) load_b(it + 1, ct);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if (it + 1 < MT_NIT) load_b(it + 1, ct);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             // refill the slot just consumed with iteration i + MT_AR (= it + 4 of this chunk, or it - 3 of the next one)
             if (it + MT_AR < MT_NIT) dma_a(it + MT_AR, chunk, true);
             else dma_a(it + MT_AR - MT_NIT, chunk + 1, c + 1 < nc);
-            if (!PIPE && it + 1 < MT_NIT) {
-                // fragments of iteration it + 1: allowed in flight = the two later weight iterations + this one's refill (6), + the
-                // next chunk's halo while it is younger than A(it + 1)
-                if (it + 1 <= MT_AR - 1) mt_wait_vm<2 * (MT_AR - 1) + MT_NH>();
-                else mt_wait_vm<2 * (MT_AR - 1)>();
-                load_a(0);
-#pragma unroll
-                for (int ct = 0; ct < WN; ++ct) load_b(it + 1, ct);
-            }
         }
         if (c + 1 < nc) {
             // next chunk: A((c+1)*7) (issued at it = 3) landed, and with it the older halo(c + 1); every wave is done reading
@@ -344,14 +330,14 @@ bool mt_geometry(const ConvParams& p, int& WN, int& TY, double& eff) {
     return WN != 0;
 }
 
-template <int WN, bool PIPE>
+template <int WN>
 int launch_mt(hipStream_t s, ConvParams& p, const MTLaunch& q, int grid, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_mt_kernel<WN, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, MT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_mt_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize, MT_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_conv_mt_kernel<WN, PIPE>), dim3(grid), dim3(512), MT_LDS, s, p, q);
+    hipLaunchKernelGGL((igemm_conv_mt_kernel<WN>), dim3(grid), dim3(512), MT_LDS, s, p, q);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }
@@ -415,10 +401,7 @@ int lnn_launch_conv_s1_mt(hipStream_t s, ConvParams& p, float* ws, long ws_elems
     p.scratch = ks > 1 ? ws : nullptr;
     q.cpp = (p.C / 16) / ks;
     const int grid = q.mblk * q.nbands * ks;
-    static int pipe = -1;
-    if (pipe < 0) { const char* e = getenv("LNN_MT_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; }
-    const int rc = pipe ? (WN == 5 ? launch_mt<5, true>(s, p, q, grid, name) : launch_mt<4, true>(s, p, q, grid, name))
-                        : (WN == 5 ? launch_mt<5, false>(s, p, q, grid, name) : launch_mt<4, false>(s, p, q, grid, name));
+    const int rc = WN == 5 ? launch_mt<5>(s, p, q, grid, name) : launch_mt<4>(s, p, q, grid, name);
     if (rc != LNN_OK || ks == 1) return rc;
     return lnn_launch_splitk_finalize(s, p, name);
 }

@@ -73,6 +73,17 @@ def _worker(rank, world, port, out):
             assert tr.network.on_grad_progress is None
             assert abs(tr.last_inv_scale * tr.amp_grad_scaler.get_scale() - 0.5) < 1e-12
         res[ext] = len(state["launched"])
+        # VERDICT r5 task 7: the exchange reports what it did, in both stream modes (LNN_DP_STREAM; on host tensors the mode only
+        # changes which stream object is handed on -- the bucket order and counts must not depend on it)
+        st = tr.dp.stats()
+        assert st["stream"] == "wgrad" and st["buckets_sent_in_backward"] == len(tr.dp.buckets) and st["buckets_sent_by_finish"] == 0
+        tr.dp.stream_mode = "own"
+        tr.run_iteration(tr.tr_gen, True)
+        assert bool((arena.grad == 3.0).all()), (ext, "own")
+        st = tr.dp.stats()
+        assert st["stream"] == "own" and st["buckets_sent_in_backward"] == len(tr.dp.buckets) and st["buckets_sent_by_finish"] == 0
+        assert [b[:2] for b in state["launched"]] == tr.dp.buckets
+        tr.dp.stream_mode = "wgrad"
         if ext == "ewc":
             tr.num_batches_per_epoch = 3
             for mode in ("parity", "accumulate"):

@@ -3,6 +3,8 @@ equivalence it relies on -- N ranks on shards == 1 rank on the concatenated batc
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -68,3 +70,29 @@ def test_two_rank_allreduce_equals_full_batch_gradient():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert out["rel"] < 1e-5      # fp32 round-off only
+
+
+def test_data_parallel_switches_are_read_from_the_environment(monkeypatch):
+    """LNN_DP_BUCKET_MB / LNN_DP_STREAM (parallel.py): defaults = the shipped plan (32 MB buckets, all-reduce from the weight-gradient
+    stream); bad values are errors, not silently ignored."""
+    import torch
+    from lifelong_nnunet_amd.parallel import GradAllReducer
+    g = torch.zeros(3 * (1 << 20))                         # 12 MB of fp32
+    monkeypatch.delenv("LNN_DP_BUCKET_MB", raising=False)
+    monkeypatch.delenv("LNN_DP_STREAM", raising=False)
+    r = GradAllReducer(g)
+    assert r.stream_mode == "wgrad" and r.bucket_bytes == 32 << 20 and len(r.buckets) == 1
+    monkeypatch.setenv("LNN_DP_BUCKET_MB", "4")
+    monkeypatch.setenv("LNN_DP_STREAM", "own")
+    r = GradAllReducer(g)
+    assert r.stream_mode == "own" and len(r.buckets) == 3 and r.buckets[0] == (2 << 20, 3 << 20)
+    assert r.stats() == {"buckets": 3, "bucket_mb": 4.0, "stream": "own", "buckets_sent_in_backward": 0, "buckets_sent_by_finish": 0}
+    r.begin(); r.progress(2 << 20); r.finish()
+    assert r.stats()["buckets_sent_in_backward"] == 1 and r.stats()["buckets_sent_by_finish"] == 2
+    monkeypatch.setenv("LNN_DP_STREAM", "third")
+    with pytest.raises(ValueError):
+        GradAllReducer(g)
+    monkeypatch.setenv("LNN_DP_STREAM", "wgrad")
+    monkeypatch.setenv("LNN_DP_BUCKET_MB", "-1")
+    with pytest.raises(ValueError):
+        GradAllReducer(g)
