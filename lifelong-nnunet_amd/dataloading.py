@@ -17,7 +17,7 @@ in tests/test_host_logic.py):
   * deep-supervision targets: the segmentation resized with order 0 to ``patch / 2^i`` (``DownsampleSegForDSTransform2``;
     ``skimage.transform.resize`` pixel-centre mapping, i.e. the voxel at ``floor(2^i * (o + 0.5))``).
 
-NOT built: the batchgenerators augmentation pipeline (spatial / intensity transforms), the
+NOT built (a hook takes one: ``PreprocessedDataProvider(train_transform=...)``): the batchgenerators augmentation pipeline (spatial / intensity transforms), the
 2-D loader, cascade inputs.  ``PreprocessedDataProvider`` adapts the loader to the trainers' ``data_provider(task, split,
 plans)`` contract and yields the dictionary the iteration consumes (MH.py:606-608).
 
@@ -186,13 +186,20 @@ def downsample_seg_for_ds(seg: np.ndarray, num_pool: int, pool_op_kernel_sizes=N
 
 class PreprocessedDataProvider:
     """``data_provider(task, split, plans)`` for the trainers: ``folders[task]`` = that task's preprocessed folder
-    (``<preprocessing_output_dir>/<task>/<data_identifier>_stage<k>``).  No augmentation: final patches are cropped
-    directly (``basic_generator_patch_size == patch_size``)."""
+    (``<preprocessing_output_dir>/<task>/<data_identifier>_stage<k>``).  No augmentation of its own: final patches are cropped
+    directly (``basic_generator_patch_size == patch_size``).  ``train_transform`` / ``val_transform`` are the hook at the point where
+    the reference wraps its loaders in upstream's augmentation pipeline (MH.py:904-922 -> ``get_moreDA_augmentation``): a
+    batchgenerators-style callable ``transform(**batch) -> batch`` over the loader's dictionary (``data`` (B,C,D,H,W) float32, ``seg``
+    (B,1,D,H,W) with -1 outside the volume, ``properties``, ``keys``; numpy), applied BEFORE the two steps upstream's pipeline ends
+    with, which stay here: label -1 -> 0 and the deep-supervision down-sampling of ``seg``.  A ``batchgenerators`` ``Compose`` of
+    spatial / intensity transforms drops in unchanged."""
 
-    def __init__(self, folders: Dict[str, str], fold=0, oversample_foreground_percent=0.33, unpack=True, extra_train: Dict = None):
+    def __init__(self, folders: Dict[str, str], fold=0, oversample_foreground_percent=0.33, unpack=True, extra_train: Dict = None,
+                 train_transform=None, val_transform=None):
         self.folders, self.fold, self.oversample = dict(folders), fold, oversample_foreground_percent
         self.unpack = unpack
         self.extra_train = extra_train or {}         # task -> dataset entries mixed in (rehearsal, REH.py:130-136)
+        self.train_transform, self.val_transform = train_transform, val_transform
 
     # ---- the three hooks nnUNetTrainerRehearsal uses to build its fused training set from real folders (REH.py:105-164)
     def dataset_for(self, task):
@@ -207,7 +214,8 @@ class PreprocessedDataProvider:
     def generator_for(self, dataset, plans, split="train"):
         loader = DataLoader3D(dataset, plans["patch_size"], plans["patch_size"], plans["batch_size"], False,
                               oversample_foreground_percent=self.oversample, pad_mode="constant", memmap_mode='r')
-        return _DictAdapter(loader, plans["num_pool"], plans.get("pool_op_kernel_sizes"))
+        return _DictAdapter(loader, plans["num_pool"], plans.get("pool_op_kernel_sizes"),
+                            self.train_transform if split == "train" else self.val_transform)
 
     def __call__(self, task, split, plans):
         tr, val = do_split(self.dataset_for(task), self.fold, self.splits_file_for(task))
@@ -218,8 +226,8 @@ class PreprocessedDataProvider:
 
 
 class _DictAdapter:
-    def __init__(self, loader, num_pool, pool_op_kernel_sizes=None):
-        self.loader, self.num_pool, self.pools = loader, num_pool, pool_op_kernel_sizes
+    def __init__(self, loader, num_pool, pool_op_kernel_sizes=None, transform=None):
+        self.loader, self.num_pool, self.pools, self.transform = loader, num_pool, pool_op_kernel_sizes, transform
 
     def __iter__(self):
         return self
@@ -227,6 +235,8 @@ class _DictAdapter:
     def __next__(self):
         import torch
         b = next(self.loader)
+        if self.transform is not None:
+            b = self.transform(**b)
         seg = np.maximum(b['seg'], 0)               # -1 (outside the volume) trains as background, as upstream's
         targets = downsample_seg_for_ds(seg, self.num_pool, self.pools)     # RemoveLabelTransform(-1, 0) does
         return {'data': torch.from_numpy(b['data']), 'target': [torch.from_numpy(t) for t in targets],

@@ -23,12 +23,34 @@ import torch
 from torch import nn
 
 
-def _set_nested(root: nn.Module, dotted: str, param: nn.Parameter):
+_MODULE_FIELDS = set(nn.Module().__dict__.keys())
+
+
+def _shell_like(ref: nn.Module) -> nn.Module:
+    """An EMPTY module of ``ref``'s class (no parameters, no children) carrying its plain attributes, plus copies of its
+    parameter-free leaf children (``lrelu`` of a ``ConvDropoutNormNonlin``): the bodies and heads the reference splits off are module
+    trees (MHM.py:159-324) -- ``heads[task].children()`` yields ``seg_outputs`` as the ModuleList it is in the model, a decoder block as a
+    ``StackedConvLayers`` -- and code written against them walks those trees (``replace_layers``, MHM.py:544-572)."""
+    new = ref.__class__.__new__(ref.__class__)
+    nn.Module.__init__(new)
+    for k, v in ref.__dict__.items():
+        if k not in _MODULE_FIELDS:
+            new.__dict__[k] = copy.copy(v)
+    for name, child in ref.named_children():
+        if next(child.parameters(), None) is None and next(child.children(), None) is None:
+            setattr(new, name, copy.deepcopy(child))
+    return new
+
+
+def _set_nested(root: nn.Module, dotted: str, param: nn.Parameter, like: nn.Module = None):
+    """Register ``param`` under its dotted name below ``root``, creating the containers on the way: typed like the modules at the same
+    paths of ``like`` (the network) when given, plain ``nn.Module`` holders otherwise."""
     parts = dotted.split(".")
-    m = root
+    m, ref = root, like
     for p in parts[:-1]:
+        ref = getattr(ref, p, None) if ref is not None else None
         if not hasattr(m, p):
-            setattr(m, p, nn.Module())
+            setattr(m, p, _shell_like(ref) if isinstance(ref, nn.Module) else nn.Module())
         m = getattr(m, p)
     m.register_parameter(parts[-1], param)
 
@@ -119,7 +141,7 @@ class MultiHead_Module(nn.Module):
         params = dict(self.model.named_parameters())
         self.body = nn.Module()
         for n in self._body_names:
-            _set_nested(self.body, n, params[n])
+            _set_nested(self.body, n, params[n], self.model)
         self._body_detached = False
 
     def _reference_resplit(self):
@@ -156,7 +178,7 @@ class MultiHead_Module(nn.Module):
         params = dict((self.model if model is None else model).named_parameters())
         head = nn.Module()
         for n in self._head_names:
-            _set_nested(head, n, nn.Parameter(params[n].detach().clone(), requires_grad=params[n].requires_grad))
+            _set_nested(head, n, nn.Parameter(params[n].detach().clone(), requires_grad=params[n].requires_grad), self.model)
         return head
 
     # ------------------------------------------------------------------------------------------ API
@@ -175,7 +197,7 @@ class MultiHead_Module(nn.Module):
             if [n for n, _ in head.named_parameters()] != self._head_names:
                 head = nn.Module()
                 for n in self._head_names:
-                    _set_nested(head, n, nn.Parameter(self.state_init[n].clone()))
+                    _set_nested(head, n, nn.Parameter(self.state_init[n].clone()), self.model)
                 self.heads[str(self.active_task)] = head
             else:
                 with torch.no_grad():
@@ -224,14 +246,14 @@ class MultiHead_Module(nn.Module):
             last = self.heads[list(self.heads.keys())[-1]]
             new = nn.Module()
             for n, p in last.named_parameters():
-                _set_nested(new, n, nn.Parameter(p.detach().clone()))
+                _set_nested(new, n, nn.Parameter(p.detach().clone()), self.model)
             self.heads[str(task)] = new
             if use_init:        # MHM.py:448-452: registered first, so a refused state_init (nested split after a re-split) leaves it behind
                 new.load_state_dict(self.state_init)
         else:
             new = nn.Module()
             for n, p in model.named_parameters():
-                _set_nested(new, n, nn.Parameter(p.detach().clone()))
+                _set_nested(new, n, nn.Parameter(p.detach().clone()), self.model)
             self.heads[str(task)] = new
 
     def add_n_tasks_and_activate(self, list_of_tasks, activate_with, remove_old_tasks=True):
@@ -273,9 +295,11 @@ class MultiHead_Module(nn.Module):
         self._body_detached = True
 
     def replace_layers(self, model, old, new):
-        """Every child of ``model`` (recursively) that is an instance of ``old`` is replaced by ``new`` (MHM.py:544-572).  The heads
-        and the body of THIS class hold bare parameters (the convolutions run in the HIP engine, not in ``nn.Conv3d`` modules), so the
-        method is only meaningful for modules the caller brings."""
+        """Every child of ``model`` (recursively) that is an instance of ``old`` is replaced by ``new`` (MHM.py:544-572).  The body and
+        the heads of THIS class are module trees of the network's own classes (``StackedConvLayers`` / ``ConvDropoutNormNonlin`` /
+        ``nn.Sequential`` / ``nn.ModuleList`` / ``nn.LeakyReLU``; the leaves that hold ``weight`` / ``bias`` are parameter holders, the
+        convolutions themselves run in the HIP engine), so the walk finds them as it finds the reference's -- e.g. every ``nn.LeakyReLU``
+        of a head -- but swapping a parameter holder for an ``nn.Conv3d`` does not change what the engine computes."""
         assert model is not None and new is not None and old is not None, \
             "To replace a Module, the layers need to be Modules as well as the model.."
         for name, module in model.named_children():

