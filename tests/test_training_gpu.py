@@ -119,7 +119,9 @@ def test_sliding_window_inference_matches_oracle():
         seg_o, prob_o = oinf.predict_3d_tiled(onet, vol, (16, 16, 16), 0.5, mirror, axes, True)
         seg_g, prob_g = predict_3D(net, vol, do_mirroring=mirror, mirror_axes=axes, step_size=0.5, patch_size=(16, 16, 16))
         assert prob_g.shape == prob_o.shape == (3, 24, 40, 20) and seg_g.shape == (24, 40, 20)
-        assert float(np.abs(prob_g - prob_o).max()) < 2e-2            # fp16 activations vs fp32 oracle
+        # fp16 activations vs fp32 oracle: measured 7e-4 / 1.6e-3 / 2.7e-3 for the three mirroring modes (round 6; mirroring averages the
+        # rounding of up to eight passes) -- the gate was 2e-2 until round 5
+        assert float(np.abs(prob_g - prob_o).max()) < 5e-3
         assert abs(float(prob_g.sum(0).mean()) - 1.0) < 1e-5          # blended probabilities still sum to one
         agree = float((seg_g == seg_o).mean())
         d = dice_per_class(seg_g, seg_o, 3)
@@ -129,7 +131,7 @@ def test_sliding_window_inference_matches_oracle():
     small = torch.randn((1, 16, 10, 16), generator=g).numpy()
     seg_o, prob_o = oinf.predict_3d_tiled(onet, small, (16, 16, 16), 0.5, False, (), True)
     seg_g, prob_g = predict_3D(net, small, do_mirroring=False, mirror_axes=(), step_size=0.5, patch_size=(16, 16, 16))
-    assert prob_g.shape == (3, 16, 10, 16) and float(np.abs(prob_g - prob_o).max()) < 2e-2
+    assert prob_g.shape == (3, 16, 10, 16) and float(np.abs(prob_g - prob_o).max()) < 5e-3
 
 
 def test_sliding_window_kernels_exact_properties():
