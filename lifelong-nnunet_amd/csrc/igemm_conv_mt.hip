@@ -37,23 +37,27 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 template <int N>
 __device__ __forceinline__ void mt_wait_vm() {     // literal counts only (see igemm_conv_v9.hip)
-    static_assert(N == 0 || N == 4 || N == 6 || N == 8, "extend the table");
+    static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 10 || N == 12, "extend the table");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
-__device__ __forceinline__ void mt_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voffset, 0, 0, 0);
+// 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16); address = descriptor base + voffset (per lane; 0x80000000 =
+// out of range -> zeros land) + soffset (wave-uniform).  ONE descriptor per tensor for the whole launch: the per-fragment / per-chunk
+// part of the address is the scalar offset -- rebuilding a 64-bit descriptor per DMA was ~40 scalar instructions per iteration.
+__device__ __forceinline__ void mt_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
 constexpr int MT_NW = 8;                    // waves per block
 constexpr int MT_NH = 4;                    // halo DMA instructions per wave and chunk: 8 x 4 x 32 = 1024 positions
 constexpr int MT_HALO = MT_NW * MT_NH * 1024;
-constexpr int MT_AR = 4;                    // weight-fragment ring slots per wave (one slot = the two 1 KB fragments of an iteration)
-constexpr int MT_ABYTES = MT_NW * MT_AR * 2048;
-constexpr int MT_LDS = 2 * MT_HALO + MT_ABYTES;         // 128 KB
+// weight-fragment ring: MT_AR slots per wave (one slot = the two 1 KB fragments of an iteration), template parameter of the kernel
+constexpr int mt_lds(int AR) { return 2 * MT_HALO + MT_NW * AR * 2048; }       // AR = 4: 128 KB, AR = 6: 160 KB (all of a CU's LDS)
 constexpr int MT_NIT = 7;                   // tap iterations per wave and chunk (4 x 7 = 28 >= 27: the last quarter's 7th is a zero tap)
 
 struct MTLaunch {
@@ -68,8 +72,9 @@ struct MTLaunch {
 // tap as soon as its two MFMAs are out, the next weight pair goes to a second register pair -- the wave does not depend on its SIMD
 // partner to cover the LDS latency.  (The plain read-then-multiply order, 210 instead of 252 registers, measured 5-8 % slower on the
 // level-3 layers and 0-4 % on level 4, profiles/r06_kbench_mt_first.txt; removed.)
-template <int WN>
+template <int WN, int MT_AR>
 __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams p, const MTLaunch q) {
+    static_assert(MT_AR >= 3 && MT_AR <= 7, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const aring = smem + 2 * MT_HALO;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,15 +105,26 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
         hvoff[k] = ok ? (((iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + half * 8) * 2 : (int)0x80000000;
     }
     const long sample_elems = (long)p.Di * p.Hi * p.Wi * p.ld_x;
+    // ONE descriptor per input tensor (sample n), built where it is used from loop-invariant scalars; a chunk's channel offset is the
+    // scalar offset of its loads
+    const half_t* const xn = p.x + (long)n * sample_elems;
+    const half_t* const xn2 = (p.x2 ? p.x2 : p.x) + (long)n * sample_elems;
+    const int xbytes = (int)(sample_elems * 2);
     int hbuf = 0;                                        // byte offset of the halo buffer the NEXT halo DMA fills
     auto dma_halo = [&](int chunk, bool live) {          // chunk = absolute 16-channel chunk index
         const int c0 = chunk * 16;
         const bool part2 = c0 >= p.csplit;
-        const half_t* base = (part2 ? p.x2 : p.x) + (long)n * sample_elems + (part2 ? c0 - p.csplit : c0);
-        const int nrec = live ? (int)((sample_elems - (part2 ? c0 - p.csplit : c0)) * 2) : 0;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
+        const int so = live ? (part2 ? c0 - p.csplit : c0) * 2 : 0;
+        const int nrec = live ? xbytes : 0;              // dead chunk: zero records -> every lane out of range (zeros land, no traffic)
+        if (part2) {                                     // (wave-uniform branch: never a select between descriptor OBJECTS -- hipcc wraps
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn2, 0, nrec, 0x00020000);   // such a load in a waterfall loop)
 #pragma unroll
-        for (int k = 0; k < MT_NH; ++k) mt_dma16(rs, smem + hbuf + (wave * MT_NH + k) * 1024, hvoff[k]);
+            for (int k = 0; k < MT_NH; ++k) mt_dma16(rs, smem + hbuf + (wave * MT_NH + k) * 1024, hvoff[k], so);
+        } else {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, nrec, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < MT_NH; ++k) mt_dma16(rs, smem + hbuf + (wave * MT_NH + k) * 1024, hvoff[k], so);
+        }
         hbuf ^= MT_HALO;
     };
 
@@ -129,30 +145,34 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
         tapslot[it] = tap < 27 ? (flip ? 26 - tap : tap) : -1;
         toffb[it] = tap < 27 ? (((dz - 1) * q.PY + (dy - 1)) * PX + (dx - 1)) * 32 : 0;
     }
-    const half_t* const wblk = p.wp + (long)(m0 >> 5) * rb_stride;
+    // ONE descriptor for the whole panel; fragment (row block, chunk, tap slot) = scalar byte offset (the panel is < 2 GB, checked by
+    // lnn_conv_s1_mt_supported); a dead fragment (zero tap, second row block beyond Mpad, past the last chunk) has zero records:
+    // every lane is out of range and zeros land
+    const int wbytes = (int)((long)(p.Mpad >> 5) * rb_stride * 2);
+    const int wbase = (int)((long)(m0 >> 5) * rb_stride * 2), rb_bytes = (int)(rb_stride * 2);
     int aslot = 0;                                       // ring slot (bytes) the NEXT weight DMA fills
     auto dma_a = [&](int it, int chunk, bool live) {     // it compile-time after unrolling
         const bool ok = live && tapslot[it] >= 0;
-        const half_t* f0 = wblk + ((long)chunk * 27 + (ok ? tapslot[it] : 0)) * 512;
-        __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)f0, 0, ok ? 1024 : 0, 0x00020000);
-        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + rb_stride), 0, (ok && rb1_live) ? 1024 : 0, 0x00020000);
+        const int so = ok ? wbase + (chunk * 27 + tapslot[it]) * 1024 : 0;
+        const bool ok1 = ok && rb1_live;
+        // the two row blocks' descriptors differ in their record count only (a scalar select on one descriptor word)
+        __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, ok ? wbytes : 0, 0x00020000);
+        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, ok1 ? wbytes : 0, 0x00020000);
         char* dst = aring + wave * (MT_AR * 2048) + aslot;
-        mt_dma16(r0, dst, avoff);
-        mt_dma16(r1, dst + 1024, avoff);
-        aslot = (aslot + 2048) & (MT_AR * 2048 - 1);
+        mt_dma16(r0, dst, avoff, so);
+        mt_dma16(r1, dst + 1024, avoff, ok1 ? so + rb_bytes : 0);
+        aslot = aslot + 2048 == MT_AR * 2048 ? 0 : aslot + 2048;
     };
 
     // ---- B-fragment lane addresses: centre position of the lane's voxel in every column tile ------------------------
     const int nv = q.TY * p.Lw;                          // voxels of a sub-tile
-    int lb[WN], ooff[WN];
+    int lb[WN];
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
         const int vv = ct * 32 + v;
         const int vc = vv < nv ? vv : nv - 1;
         const int yy = vc / p.Lw, xx = vc - yy * p.Lw;
         lb[ct] = (((sub + 1) * q.PY + (yy + 1)) * PX + (xx + 1)) * 32 + hk * 16;
-        const int oz = z0 + sub, oy = y0 + yy;
-        ooff[ct] = (vv < nv && oz < p.Ld && oy < p.Lh) ? ((oz * p.Ho + oy) * p.Wo + xx) : -1;
     }
 
     floatx16 acc[2][WN];
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
         const char* ab = aring + wave * (MT_AR * 2048) + rslot + lane * 16;
         fa[set][0] = *reinterpret_cast<const half8*>(ab);
         fa[set][1] = *reinterpret_cast<const half8*>(ab + 1024);
-        rslot = (rslot + 2048) & (MT_AR * 2048 - 1);
+        rslot = rslot + 2048 == MT_AR * 2048 ? 0 : rslot + 2048;
     };
     auto load_b = [&](int it, int ct) {                  // it, ct compile-time
         const int bb = lb[ct] + rbuf + toffb[it];
@@ -179,12 +199,10 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
     };
 
     // ---- prologue: halo of the first chunk, the first MT_AR weight iterations -----------------------------------------
-    // (weight iterations are numbered i = c * 7 + it over the part's chunks; the first MT_AR = 4 are (chunk 0, it 0..3))
+    // (weight iterations are numbered i = c * 7 + it over the part's chunks; the first MT_AR are (chunk 0, it 0 .. MT_AR - 1))
     dma_halo(c_begin, true);
-    dma_a(0, c_begin, true);
-    dma_a(1, c_begin, true);
-    dma_a(2, c_begin, true);
-    dma_a(3, c_begin, true);
+#pragma unroll
+    for (int i = 0; i < MT_AR; ++i) dma_a(i, c_begin, true);
     mt_wait_vm<2 * (MT_AR - 1)>();                       // halo(0) and A(0) landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     dma_halo(c_begin + 1, nc > 1);
@@ -236,6 +254,14 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
     // Q's region, source slot 3 - a.  Region of (sub, Q): [3 slots][WN tiles][64 lanes x 16 B].
     const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
     const long vbase = (long)n * p.Do * p.Ho * p.Wo;
+    int ooff[WN];                                        // output voxel of the lane in every column tile (-1: outside the volume); computed
+#pragma unroll                                           // here, not before the loop: five registers less across it
+    for (int ct = 0; ct < WN; ++ct) {
+        const int vv = ct * 32 + v;
+        const int yy = vv / p.Lw, xx = vv - yy * p.Lw;
+        const int oz = z0 + sub, oy = y0 + yy;
+        ooff[ct] = (vv < nv && oz < p.Ld && oy < p.Lh) ? ((oz * p.Ho + oy) * p.Wo + xx) : -1;
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         if (rb) __builtin_amdgcn_s_barrier();            // round 0's readers are done
@@ -330,14 +356,14 @@ bool mt_geometry(const ConvParams& p, int& WN, int& TY, double& eff) {
     return WN != 0;
 }
 
-template <int WN>
+template <int WN, int AR>
 int launch_mt(hipStream_t s, ConvParams& p, const MTLaunch& q, int grid, const char* name) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_mt_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize, MT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_mt_kernel<WN, AR>), hipFuncAttributeMaxDynamicSharedMemorySize, mt_lds(AR));
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_conv_mt_kernel<WN>), dim3(grid), dim3(512), MT_LDS, s, p, q);
+    hipLaunchKernelGGL((igemm_conv_mt_kernel<WN, AR>), dim3(grid), dim3(512), mt_lds(AR), s, p, q);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }
@@ -360,7 +386,8 @@ bool lnn_conv_s1_mt_supported(const ConvParams& p) {
     if (p.csplit != 0x7fffffff && p.csplit % 16 != 0) return false;
     if (p.msplit != 0x7fffffff && p.msplit % 32 != 0) return false;
     if (p.Di != p.Do || p.Hi != p.Ho || p.Wi != p.Wo) return false;
-    if ((double)p.Di * p.Hi * p.Wi * p.ld_x * 2.0 >= 2147483648.0) return false;
+    if ((double)p.Di * p.Hi * p.Wi * p.ld_x * 2.0 >= 2147483648.0) return false;        // one descriptor per sample
+    if ((double)p.Mpad * p.KCpad * 27 * 2.0 >= 2147483648.0) return false;                  // one descriptor for the weight panel
     int wn, ty; double eff;
     return mt_geometry(p, wn, ty, eff);
 }
@@ -401,7 +428,9 @@ int lnn_launch_conv_s1_mt(hipStream_t s, ConvParams& p, float* ws, long ws_elems
     p.scratch = ks > 1 ? ws : nullptr;
     q.cpp = (p.C / 16) / ks;
     const int grid = q.mblk * q.nbands * ks;
-    const int rc = WN == 5 ? launch_mt<5>(s, p, q, grid, name) : launch_mt<4>(s, p, q, grid, name);
+    // ring depth 4 (3 iterations ahead); 6 -- all 160 KB of LDS -- measured +1-2 % on level 3, +-0 on level 4
+    // (profiles/r06_kbench_mt_descriptor_ring_ab.txt); what bounds the loop: profiles/r06_mt_ablation.txt
+    const int rc = WN == 5 ? launch_mt<5, 4>(s, p, q, grid, name) : launch_mt<4, 4>(s, p, q, grid, name);
     if (rc != LNN_OK || ks == 1) return rc;
     return lnn_launch_splitk_finalize(s, p, name);
 }
