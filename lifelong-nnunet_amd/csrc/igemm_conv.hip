@@ -184,8 +184,10 @@ bool use_v9(const ConvParams& p) {
     }
     if (v == 0) return false;
     if (v == 1) return true;
-    // automatic: long z columns only (the column walk has ~4 plane steps of fixed cost per item)
-    return p.Ld >= 32;
+    // automatic: not on short z columns (the column walk has ~4 plane steps of fixed cost per item).  16 since round 6: on the
+    // 20-plane levels of a Task005_Prostate-shaped plan (64 / 128 channels @ 20x160x128 / 20x80x64) the z-streaming kernel runs
+    // 780-1020 TFLOP/s where the tile kernel ran 420-700 (step 19.26 -> 17.64 ms, gpurun_out/r6f)
+    return p.Ld >= 16;
 }
 
 // stride-2 conv forward: z-streaming kernel (igemm_down2s.hip) for 32 / 64 input channels with >= 16 output planes;
@@ -389,6 +391,38 @@ extern "C" int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const vo
     return lnn_instnorm_stats(s, y, N, V, K, eps, mean, rstd, ws);          // kernel without the fused epilogue: separate pass
 }
 
+// conv + InstanceNorm + LeakyReLU of one ConvDropoutNormNonlin block (test_MultiHead_Module.py:287-291) in one call: y = conv(x) + bias,
+// mean / rstd of y per (sample, channel), z = LeakyReLU(gamma * (y - mean) * rstd + beta).  Up to lnn_instnorm_small_volume() output
+// voxels per sample (the two lowest levels of the 160x192x160 plan) the convolution's split-K slices, the statistics and the
+// normalisation are ONE launch behind the convolution (norm_act.hip: in_small_fwd_kernel) instead of four; larger volumes: exactly
+// lnn_conv3d_fwd_in_stats + lnn_instnorm_lrelu_fwd.
+extern "C" int lnn_conv3d_fwd_in_lrelu(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
+                                       const float* bias, void* y, int N, int Di, int Hi, int Wi, int C, int K, int stride, float eps,
+                                       float* mean, float* rstd, const float* gamma, const float* beta, float slope, void* z, int ld_z,
+                                       double* ws, float* splitk_ws, long splitk_elems) {
+    LNN_REQUIRE(mean && rstd && ws && gamma && beta && z, "lnn_conv3d_fwd_in_lrelu: null output / parameter / workspace");
+    LNN_REQUIRE(stride == 1 || stride == 2, "lnn_conv3d_fwd_in_lrelu: stride %d unsupported", stride);
+    const long V = (long)((Di - 1) / stride + 1) * ((Hi - 1) / stride + 1) * ((Wi - 1) / stride + 1);
+    static int no_small = -1;
+    if (no_small < 0) { const char* e = getenv("LNN_IN_SMALL"); no_small = (e && e[0] == '0') ? 1 : 0; }
+    if (V > lnn_instnorm_small_volume() || no_small) {
+        if (int e = lnn_conv3d_fwd_in_stats(s, x_a, x_b, ld_x, c_a, wp, bias, y, N, Di, Hi, Wi, C, K, stride, eps, mean, rstd, ws,
+                                            splitk_ws, splitk_elems)) return e;
+        return lnn_instnorm_lrelu_fwd(s, y, z, ld_z, N, V, K, mean, rstd, gamma, beta, slope);
+    }
+    if (x_b) {
+        if (int e = check_cat(x_b, c_a, C, stride, "lnn_conv3d_fwd_in_lrelu")) return e;
+        LNN_REQUIRE(ld_x >= c_a && ld_x >= C - c_a, "lnn_conv3d_fwd_in_lrelu: ld_x %d smaller than a part (%d / %d)", ld_x, c_a, C - c_a);
+    }
+    SplitKDeferred& d = lnn_splitk_deferred();
+    d = SplitKDeferred{};
+    d.armed = true;
+    const int rc = conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, K, N, Di, Hi, Wi, C, K, stride, nullptr, nullptr, splitk_ws, splitk_elems);
+    d.armed = false;
+    if (rc) return rc;
+    return lnn_launch_in_small_fwd((hipStream_t)s, y, d.taken ? &d : nullptr, z, ld_z, N, V, K, eps, gamma, beta, slope, mean, rstd);
+}
+
 namespace {
 int conv3d_dgrad_impl(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, void* dx2, int c_a, int ld_dx, int N,
                       int Di, int Hi, int Wi, int C, int K, int stride, int accumulate, float* splitk_ws = nullptr,
@@ -490,6 +524,31 @@ extern "C" int lnn_conv3d_dgrad_in_bwd_sums(lnn_stream_t s_, const void* dy, int
     p.red_u = (const half_t*)u; p.red_mean = mean; p.red_rstd = rstd; p.red_gamma = gamma; p.red_beta = beta; p.red_slope = slope;
     if (int e = lnn_launch_conv_s1_v9(s, p, "lnn_conv3d_dgrad_in_bwd_sums(s1,v9,reduce)")) return e;
     return lnn_launch_in_bwd_sums_raw(s, pws, p.stats_nblk, N, C, mean, rstd, ws, dgamma, dbeta, grad_unscale);
+}
+
+// Data gradient of a stride-1 3x3x3 convolution TOGETHER with the whole InstanceNorm + LeakyReLU backward of the block that produced
+// its input (small volumes only: V = Di Hi Wi <= lnn_instnorm_small_volume()): afterwards u -- that block's convolution output on
+// entry -- holds dL/du in place and dgamma / dbeta (+)= its affine gradients, as after lnn_conv3d_dgrad_ws(stride 1, no accumulate)
+// into dx + lnn_instnorm_lrelu_bwd(u, dx, ...).  When the data gradient splits its contraction the normalisation kernel adds the fp32
+// slices itself (same slice order and fp16 rounding as the finalize kernel): dL/dz is then never written and dx is left untouched --
+// its contents are unspecified after this call.
+extern "C" int lnn_conv3d_dgrad_in_bwd(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int Di,
+                                       int Hi, int Wi, int C, int K, void* u, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, float slope, float* dgamma, float* dbeta, float grad_unscale, double* ws,
+                                       float* splitk_ws, long splitk_elems) {
+    LNN_REQUIRE(u && lnn_aligned16(u) && mean && rstd && gamma && beta && ws, "lnn_conv3d_dgrad_in_bwd: null / misaligned parameter");
+    const long V = (long)Di * Hi * Wi;
+    LNN_REQUIRE(V <= lnn_instnorm_small_volume(), "lnn_conv3d_dgrad_in_bwd: %ld voxels per sample (limit %d): use lnn_conv3d_dgrad_in_bwd_sums",
+                V, lnn_instnorm_small_volume());
+    LNN_REQUIRE(C % 8 == 0, "lnn_conv3d_dgrad_in_bwd: %d channels (multiple of 8)", C);
+    SplitKDeferred& d = lnn_splitk_deferred();
+    d = SplitKDeferred{};
+    d.armed = true;
+    const int rc = conv3d_dgrad_impl(s_, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, 1, 0, splitk_ws, splitk_elems);
+    d.armed = false;
+    if (rc) return rc;
+    return lnn_launch_in_small_bwd((hipStream_t)s_, u, dx, ld_dx, d.taken ? &d : nullptr, N, V, C, mean, rstd, gamma, beta, slope, ws, dgamma,
+                                   dbeta, grad_unscale);
 }
 
 extern "C" int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx_a, void* dx_b, int ld_dx,

@@ -7,7 +7,8 @@
 // tiles of OUTPUT per CU.  The tile kernels (igemm_conv_v7 / v8: 8x8x8 voxels x 32 / 64 channels per unit, one or two
 // accumulators per wave, 1.0 - 1.5 KB of LDS reads per MFMA, the halo re-staged for every 32 output channels) ran them at
 // 500 - 670 TFLOP/s, the flattened-voxel kernel (igemm_gen) level 4 at ~200.  What this kernel does instead:
-//   * a block owns 64 output channels x one BAND of voxels: 2 planes x TY rows x all W columns; a plane of the band is one
+//   * a block owns 64 output channels x one BAND of voxels: 2 planes x TY rows x TX columns (TX = W, all columns, on every level of
+//     the 160x192x160 plan; W / 2, W / 3 ... on the wide planes of anisotropic plans, see mt_geometry); a plane of the band is one
 //     SUB-TILE of WN x 32 voxels (flattened (y, x): 8 rows x 20 = 160 = 5 MFMA column tiles at level 3, 12 x 10 = 120 -> 4 at
 //     level 4, no padding planes);
 //   * its 8 waves are 2 sub-tiles x 4 TAP QUARTERS (taps 7 kq .. 7 kq + 6 of the 27): every wave holds the FULL 64 x (32 WN)
@@ -62,8 +63,8 @@ constexpr int MT_NIT = 7;                   // tap iterations per wave and chunk
 
 struct MTLaunch {
     int mblk;          // 64-channel output blocks
-    int zb, yb;        // bands per sample along z / y
-    int TY, PY, PX, P; // band rows, halo rows / columns / positions
+    int zb, yb, xb;    // bands per sample along z / y / x
+    int TY, TX, PY, PX, P; // band rows / columns, halo rows / columns / positions
     int cpp;           // 16-channel chunks per K part
     int nbands;        // N * zb * yb
 };
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
     const int mb = b % q.mblk; b /= q.mblk;
     const int band = b % q.nbands;
     const int part = b / q.nbands;
-    const int ybi = band % q.yb, zbi = (band / q.yb) % q.zb, n = band / (q.yb * q.zb);
-    const int z0 = zbi * 2, y0 = ybi * q.TY;
+    const int xbi = band % q.xb, bzy = band / q.xb;
+    const int ybi = bzy % q.yb, zbi = (bzy / q.yb) % q.zb, n = bzy / (q.yb * q.zb);
+    const int z0 = zbi * 2, y0 = ybi * q.TY, x0 = xbi * q.TX;
     const int m0 = mb * 64;
     const int PX = q.PX, PYX = q.PY * q.PX;
     const bool flip = p.taps.slot[0] != 0;               // data gradient: tap offset d' uses weight slot 26 - d'
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
     for (int k = 0; k < MT_NH; ++k) {
         const int pos = (wave * MT_NH + k) * 32 + (lane >> 1);
         const int pz = pos / PYX, rem = pos - pz * PYX, py = rem / PX, px = rem - py * PX;
-        const int iz = z0 - 1 + pz, iy = y0 - 1 + py, ix = px - 1;
+        const int iz = z0 - 1 + pz, iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = pos < q.P && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         const int half = (lane & 1) ^ ((pos >> 3) & 1);
         hvoff[k] = ok ? (((iz * p.Hi + iy) * p.Wi + ix) * p.ld_x + half * 8) * 2 : (int)0x80000000;
@@ -165,13 +167,13 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
     };
 
     // ---- B-fragment lane addresses: centre position of the lane's voxel in every column tile ------------------------
-    const int nv = q.TY * p.Lw;                          // voxels of a sub-tile
+    const int nv = q.TY * q.TX;                          // voxels of a sub-tile
     int lb[WN];
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
         const int vv = ct * 32 + v;
         const int vc = vv < nv ? vv : nv - 1;
-        const int yy = vc / p.Lw, xx = vc - yy * p.Lw;
+        const int yy = vc / q.TX, xx = vc - yy * q.TX;
         lb[ct] = (((sub + 1) * q.PY + (yy + 1)) * PX + (xx + 1)) * 32 + hk * 16;
     }
 
@@ -258,9 +260,9 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_mt_kernel(const ConvParams 
 #pragma unroll                                           // here, not before the loop: five registers less across it
     for (int ct = 0; ct < WN; ++ct) {
         const int vv = ct * 32 + v;
-        const int yy = vv / p.Lw, xx = vv - yy * p.Lw;
-        const int oz = z0 + sub, oy = y0 + yy;
-        ooff[ct] = (vv < nv && oz < p.Ld && oy < p.Lh) ? ((oz * p.Ho + oy) * p.Wo + xx) : -1;
+        const int yy = vv / q.TX, xx = vv - yy * q.TX;
+        const int oz = z0 + sub, oy = y0 + yy, ox = x0 + xx;
+        ooff[ct] = (vv < nv && oz < p.Ld && oy < p.Lh && ox < p.Lw) ? ((oz * p.Ho + oy) * p.Wo + ox) : -1;
     }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -342,16 +344,23 @@ int mt_num_cu() {
     return lnn_cu_budget(num_cu);
 }
 
-// band geometry for a (H, W) plane: the (WN, TY) with the fewest MFMA columns per plane whose halo fits the LDS image
-bool mt_geometry(const ConvParams& p, int& WN, int& TY, double& eff) {
-    WN = 0; TY = 0; eff = 0.0;
-    for (int wn = 4; wn <= 5; ++wn) {
-        int ty = (32 * wn) / p.Lw;
-        if (ty > p.Lh) ty = p.Lh;
-        while (ty >= 1 && 4L * (ty + 2) * (p.Lw + 2) > MT_NW * MT_NH * 32) --ty;
-        if (ty < 1) continue;
-        const double e = (double)p.Lh * p.Lw / ((double)lnn_cdiv(p.Lh, ty) * 32 * wn);
-        if (e > eff + 1e-9) { eff = e; WN = wn; TY = ty; }
+// band geometry for a (H, W) plane: the (WN, TY, TX) with the fewest MFMA columns per plane whose halo fits the LDS image.  A band
+// covers TY rows x TX columns; TX = W (all columns) wherever that fills the columns best -- every level of the 160x192x160 plan --
+// and W / 2, W / 3, ... on wide planes (80x64, 160x128: the middle levels of anisotropic plans, whose 20 planes are too few for the
+// z-streaming kernel).  Ties go to the wider band (less halo per voxel).
+bool mt_geometry(const ConvParams& p, int& WN, int& TY, int& TX, double& eff) {
+    WN = 0; TY = 0; TX = 0; eff = 0.0;
+    for (int nx = 1; nx <= 16; ++nx) {
+        const int tx = lnn_cdiv(p.Lw, nx);
+        if (nx > 1 && tx == lnn_cdiv(p.Lw, nx - 1)) continue;
+        for (int wn = 5; wn >= 4; --wn) {               // ties go to the wider sub-tile (10 MFMAs per 7 fragment reads)
+            int ty = (32 * wn) / tx;
+            if (ty > p.Lh) ty = p.Lh;
+            while (ty >= 1 && 4L * (ty + 2) * (tx + 2) > MT_NW * MT_NH * 32) --ty;
+            if (ty < 1) continue;
+            const double e = (double)p.Lh * p.Lw / ((double)lnn_cdiv(p.Lh, ty) * lnn_cdiv(p.Lw, tx) * 32 * wn);
+            if (e > eff + 1e-9) { eff = e; WN = wn; TY = ty; TX = tx; }
+        }
     }
     return WN != 0;
 }
@@ -370,8 +379,19 @@ int launch_mt(hipStream_t s, ConvParams& p, const MTLaunch& q, int grid, const c
 
 }  // namespace
 
+SplitKDeferred& lnn_splitk_deferred() {
+    static thread_local SplitKDeferred d;
+    return d;
+}
+
 int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name) {
     const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+    SplitKDeferred& d = lnn_splitk_deferred();
+    if (d.armed && !p.accumulate && p.y2 == nullptr && p.ld_y == p.M && p.M % 8 == 0) {
+        // the consumer adds the slices itself (norm_act.hip, small volumes): nothing to launch
+        d.taken = true; d.ksplit = p.ksplit; d.Mpad = p.Mpad; d.nvox = nvox; d.scratch = p.scratch; d.bias = p.bias;
+        return LNN_OK;
+    }
     const long total = nvox * (p.Mpad >> 2);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, s, p, nvox);
@@ -388,22 +408,22 @@ bool lnn_conv_s1_mt_supported(const ConvParams& p) {
     if (p.Di != p.Do || p.Hi != p.Ho || p.Wi != p.Wo) return false;
     if ((double)p.Di * p.Hi * p.Wi * p.ld_x * 2.0 >= 2147483648.0) return false;        // one descriptor per sample
     if ((double)p.Mpad * p.KCpad * 27 * 2.0 >= 2147483648.0) return false;                  // one descriptor for the weight panel
-    int wn, ty; double eff;
-    return mt_geometry(p, wn, ty, eff);
+    int wn, ty, tx; double eff;
+    return mt_geometry(p, wn, ty, tx, eff);
 }
 
 // fraction of the MFMA columns that carry real voxels (band geometry x plane-pair padding): the automatic selection asks for >= 0.7
 double lnn_conv_s1_mt_efficiency(const ConvParams& p) {
-    int wn, ty; double eff;
-    if (!lnn_conv_s1_mt_supported(p) || !mt_geometry(p, wn, ty, eff)) return 0.0;
+    int wn, ty, tx; double eff;
+    if (!lnn_conv_s1_mt_supported(p) || !mt_geometry(p, wn, ty, tx, eff)) return 0.0;
     return eff * p.Ld / (2.0 * lnn_cdiv(p.Ld, 2));
 }
 
 // K parts this launch would use with a workspace of ws_elems floats (1 = no split)
 int lnn_conv_s1_mt_ksplit(const ConvParams& p, const float* ws, long ws_elems) {
-    int wn, ty; double eff;
-    if (!mt_geometry(p, wn, ty, eff)) return 1;
-    const long items = (long)lnn_cdiv(p.Mpad, 64) * p.N * lnn_cdiv(p.Ld, 2) * lnn_cdiv(p.Lh, ty);
+    int wn, ty, tx; double eff;
+    if (!mt_geometry(p, wn, ty, tx, eff)) return 1;
+    const long items = (long)lnn_cdiv(p.Mpad, 64) * p.N * lnn_cdiv(p.Ld, 2) * lnn_cdiv(p.Lh, ty) * lnn_cdiv(p.Lw, tx);
     const int nchunks = p.C / 16;
     const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
     const int cus = mt_num_cu();
@@ -416,13 +436,13 @@ int lnn_conv_s1_mt_ksplit(const ConvParams& p, const float* ws, long ws_elems) {
 
 int lnn_launch_conv_s1_mt(hipStream_t s, ConvParams& p, float* ws, long ws_elems, const char* name) {
     LNN_REQUIRE(lnn_conv_s1_mt_supported(p), "%s: shape not supported by the macro-tile kernel", name);
-    int WN, TY; double eff;
-    mt_geometry(p, WN, TY, eff);
+    int WN, TY, TX; double eff;
+    mt_geometry(p, WN, TY, TX, eff);
     MTLaunch q;
     q.mblk = lnn_cdiv(p.Mpad, 64);
-    q.zb = lnn_cdiv(p.Ld, 2); q.yb = lnn_cdiv(p.Lh, TY);
-    q.TY = TY; q.PY = TY + 2; q.PX = p.Lw + 2; q.P = 4 * q.PY * q.PX;
-    q.nbands = p.N * q.zb * q.yb;
+    q.zb = lnn_cdiv(p.Ld, 2); q.yb = lnn_cdiv(p.Lh, TY); q.xb = lnn_cdiv(p.Lw, TX);
+    q.TY = TY; q.TX = TX; q.PY = TY + 2; q.PX = TX + 2; q.P = 4 * q.PY * q.PX;
+    q.nbands = p.N * q.zb * q.yb * q.xb;
     const int ks = lnn_conv_s1_mt_ksplit(p, ws, ws_elems);
     p.ksplit = ks;
     p.scratch = ks > 1 ? ws : nullptr;

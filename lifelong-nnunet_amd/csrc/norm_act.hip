@@ -765,6 +765,249 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_bwd_apply_kernel(half_t* __re
     }
 }
 
+// ---- small volumes (the two lowest levels of the U: <= 2048 voxels per sample) ---------------------------------------------------
+// There a normalisation is a few hundred KB and every launch of the multi-block passes costs its fixed ~6 us: statistics, finalize and
+// normalise (forward; + the split-K finalize of the convolution in front) / reduce, sums and apply (backward) were 3-4 dependent
+// launches per layer, ~25 us for what is ~5 us of work.  One launch each: a 512-thread block owns ONE channel octet of one sample
+// (forward) or of every sample in turn (backward: the affine gradients are an ordered sum over the samples), keeps its <= 4 rows per
+// thread in registers between the reduction and the normalisation, reduces through wave shuffles + one LDS step in fp64.
+constexpr int SNT = 512, SR = 4;
+constexpr int SMALL_V = SNT * SR;
+
+// fp64 totals of 16 per-thread values over the block: afterwards dtot[j] (shared) holds total j; thread j < 16 gets it returned too
+__device__ __forceinline__ double small_block_sum16(float (&v)[16], double* red, double* dtot) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = wave_sum(v[j]);
+    __syncthreads();                       // (the previous round's readers of red / dtot are done)
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[j * (SNT / 64) + wid] = (double)v[j];
+    }
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int w = 0; w < SNT / 64; ++w) t += red[threadIdx.x * (SNT / 64) + w];
+        dtot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    return t;
+}
+
+// Forward: [split-K slices + bias -> y |  y] -> statistics -> mean / rstd -> z = LeakyReLU(gamma * xhat + beta).  grid (C / 8, N).
+// SPLIT: the convolution left `ksplit` fp32 slices scratch[part][n * V + v][Mpad] (lnn_launch_splitk_finalize deferred): they are
+// added in slice order, + bias, rounded to fp16 = y (written: the backward and the weight gradient read it), exactly what the finalize
+// kernel + the statistics pass would have produced.
+template <bool SPLIT>
+__global__ __launch_bounds__(SNT) void in_small_fwd_kernel(half_t* __restrict__ y, const float* __restrict__ scratch, int ksplit,
+                                                           long nvox, int Mpad, const float* __restrict__ bias,
+                                                           half_t* __restrict__ z, int ld_z, int V, int C, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float slope, float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[16 * (SNT / 64)];
+    __shared__ double dtot[16];
+    __shared__ float bc[16];
+    const int c0 = blockIdx.x * 8, n = blockIdx.y;
+    // rows r = tid + k SNT; rows beyond V read row V - 1 again (every load unconditional: all of a thread's loads are in flight
+    // together) and take no part in the sums / stores
+    long vox[SR];
+    bool live[SR];
+#pragma unroll
+    for (int k = 0; k < SR; ++k) {
+        const int r = threadIdx.x + k * SNT;
+        live[k] = r < V;
+        vox[k] = (long)n * V + (live[k] ? r : V - 1);
+    }
+    half8 x[SR];
+    if constexpr (SPLIT) {
+        floatx4 a[SR], b[SR];
+#pragma unroll
+        for (int k = 0; k < SR; ++k) {
+            const float* sp = scratch + vox[k] * Mpad + c0;
+            a[k] = *reinterpret_cast<const floatx4*>(sp);
+            b[k] = *reinterpret_cast<const floatx4*>(sp + 4);
+        }
+        const long sstride = nvox * Mpad;
+        // slices added in order (the finalize kernel's sum); four slices of every row in flight per trip
+#pragma unroll 4
+        for (int q = 1; q < ksplit; ++q) {
+            floatx4 ta[SR], tb[SR];
+#pragma unroll
+            for (int k = 0; k < SR; ++k) {
+                const float* sp = scratch + (long)q * sstride + vox[k] * Mpad + c0;
+                ta[k] = *reinterpret_cast<const floatx4*>(sp);
+                tb[k] = *reinterpret_cast<const floatx4*>(sp + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < SR; ++k) { a[k] += ta[k]; b[k] += tb[k]; }
+        }
+        floatx4 ba = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
+        if (bias) { ba = *reinterpret_cast<const floatx4*>(bias + c0); bb = *reinterpret_cast<const floatx4*>(bias + c0 + 4); }
+#pragma unroll
+        for (int k = 0; k < SR; ++k) {
+            a[k] += ba; b[k] += bb;
+            x[k] = half8{(half_t)a[k][0], (half_t)a[k][1], (half_t)a[k][2], (half_t)a[k][3],
+                         (half_t)b[k][0], (half_t)b[k][1], (half_t)b[k][2], (half_t)b[k][3]};
+            if (live[k]) *reinterpret_cast<half8*>(y + vox[k] * C + c0) = x[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SR; ++k) x[k] = *reinterpret_cast<const half8*>(y + vox[k] * C + c0);
+    }
+    float part[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < SR; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = live[k] ? (float)x[k][e] : 0.f;
+            part[e] += f;
+            part[8 + e] += f * f;
+        }
+    small_block_sum16(part, red, dtot);
+    if (threadIdx.x < 8) {
+        const int e = threadIdx.x;
+        const double m = dtot[e] / (double)V;
+        double var = dtot[8 + e] / (double)V - m * m;
+        if (var < 0) var = 0;
+        const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+        mean[n * C + c0 + e] = mf; rstd[n * C + c0 + e] = rf;
+        const float sc = gamma[c0 + e] * rf;
+        bc[e] = sc;
+        bc[8 + e] = beta[c0 + e] - mf * sc;
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = bc[e]; sh[e] = bc[8 + e]; }
+#pragma unroll
+    for (int k = 0; k < SR; ++k) {
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = (float)x[k][e] * sc[e] + sh[e];
+            o[e] = (half_t)(t > 0.f ? t : t * slope);
+        }
+        if (live[k]) *reinterpret_cast<half8*>(z + vox[k] * ld_z + c0) = o;
+    }
+}
+
+// Backward: g = dz * lrelu'(gamma xhat + beta); s1 = sum g, s2 = sum g xhat per (n, c); dy = gamma rstd (g - s1 / V - xhat s2 / V) in
+// place over y; d gamma / d beta = ordered sums over the samples, one add per channel (as in_bwd_sums_block).  grid (C / 8).
+// SPLIT: dz is what a split-K data gradient left in its fp32 slices scratch[part][n * V + v][Mpad] (finalize deferred; dz is read by
+// nobody else, so its fp16 tensor is never written).
+template <bool SPLIT>
+__global__ __launch_bounds__(SNT) void in_small_bwd_kernel(half_t* __restrict__ y, const half_t* __restrict__ dz, int ld_dz,
+                                                           const float* __restrict__ scratch, int ksplit, long nvox, int Mpad,
+                                                           int N, int V, int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float slope, double* __restrict__ ws,
+                                                           float* dgamma, float* dbeta, float unscale) {
+    __shared__ double red[16 * (SNT / 64)];
+    __shared__ double dtot[16];
+    __shared__ float bc[16];
+    const int c0 = blockIdx.x * 8;
+    float ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; }
+    const float invV = 1.0f / (float)V;
+    double gacc = 0;                      // thread j < 8: sum over n of s1 of channel j; 8 <= j < 16: of s2 of channel j - 8
+    for (int n = 0; n < N; ++n) {
+        float mu[8], rs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = mean[n * C + c0 + e]; rs[e] = rstd[n * C + c0 + e]; }
+        long vox[SR];
+        bool live[SR];
+#pragma unroll
+        for (int k = 0; k < SR; ++k) {
+            const int r = threadIdx.x + k * SNT;
+            live[k] = r < V;
+            vox[k] = (long)n * V + (live[k] ? r : V - 1);          // (unconditional loads, see the forward kernel)
+        }
+        half8 xv[SR], gv[SR];             // y rows and dz rows (fp16: what the finalize kernel would have stored)
+#pragma unroll
+        for (int k = 0; k < SR; ++k) xv[k] = *reinterpret_cast<const half8*>(y + vox[k] * C + c0);
+        if constexpr (SPLIT) {
+            floatx4 a[SR], b[SR];
+#pragma unroll
+            for (int k = 0; k < SR; ++k) {
+                const float* sp = scratch + vox[k] * Mpad + c0;
+                a[k] = *reinterpret_cast<const floatx4*>(sp);
+                b[k] = *reinterpret_cast<const floatx4*>(sp + 4);
+            }
+            const long sstride = nvox * Mpad;
+#pragma unroll 2
+            for (int q = 1; q < ksplit; ++q) {
+                floatx4 ta[SR], tb[SR];
+#pragma unroll
+                for (int k = 0; k < SR; ++k) {
+                    const float* sp = scratch + (long)q * sstride + vox[k] * Mpad + c0;
+                    ta[k] = *reinterpret_cast<const floatx4*>(sp);
+                    tb[k] = *reinterpret_cast<const floatx4*>(sp + 4);
+                }
+#pragma unroll
+                for (int k = 0; k < SR; ++k) { a[k] += ta[k]; b[k] += tb[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < SR; ++k)
+                gv[k] = half8{(half_t)a[k][0], (half_t)a[k][1], (half_t)a[k][2], (half_t)a[k][3],
+                              (half_t)b[k][0], (half_t)b[k][1], (half_t)b[k][2], (half_t)b[k][3]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < SR; ++k) gv[k] = *reinterpret_cast<const half8*>(dz + vox[k] * ld_dz + c0);
+        }
+        float part[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < SR; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = ((float)xv[k][e] - mu[e]) * rs[e];
+                const float pre = ga[e] * h + be[e];
+                const float gg = live[k] ? (float)gv[k][e] * (pre > 0.f ? 1.f : slope) : 0.f;
+                part[e] += gg;
+                part[8 + e] += gg * h;
+            }
+        const double t = small_block_sum16(part, red, dtot);
+        if (threadIdx.x < 16) {
+            bc[threadIdx.x] = (float)(t * (double)invV);
+            gacc += t;
+            ws[((long)n * C + c0 + (threadIdx.x & 7)) * 3 + (threadIdx.x >> 3)] = t;
+        }
+        __syncthreads();
+        float m1[8], m2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m1[e] = bc[e]; m2[e] = bc[8 + e]; }
+#pragma unroll
+        for (int k = 0; k < SR; ++k) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = ((float)xv[k][e] - mu[e]) * rs[e];
+                const float pre = ga[e] * h + be[e];
+                const float gg = (float)gv[k][e] * (pre > 0.f ? 1.f : slope);
+                o[e] = (half_t)(ga[e] * rs[e] * (gg - m1[e] - h * m2[e]));
+            }
+            if (live[k]) *reinterpret_cast<half8*>(y + vox[k] * C + c0) = o;
+        }
+    }
+    if (threadIdx.x < 8) {
+        if (dbeta) atomicAdd(dbeta + c0 + threadIdx.x, (float)(gacc * unscale));
+    } else if (threadIdx.x < 16) {
+        if (dgamma) atomicAdd(dgamma + c0 + threadIdx.x - 8, (float)(gacc * unscale));
+    }
+}
+
+// LNN_IN_SMALL=0: the multi-launch passes on every volume (A/B switch, measurements only)
+bool small_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LNN_IN_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+
 int blocks_for(long V, int C) {
     const int vpb = NT / (C / 8);
     long b = (V + (long)vpb * 8 - 1) / ((long)vpb * 8);  // ~8 passes per block
@@ -781,6 +1024,39 @@ int check_common(const void* y, int N, long V, int C, const char* what) {
 }
 
 }  // namespace
+
+extern "C" int lnn_instnorm_small_volume(void) { return SMALL_V; }
+
+int lnn_launch_in_small_fwd(hipStream_t s, void* y, const SplitKDeferred* sk, void* z, int ld_z, int N, long V, int C, float eps,
+                            const float* gamma, const float* beta, float slope, float* mean, float* rstd) {
+    if (int e = check_common(y, N, V, C, "lnn_conv3d_fwd_in_lrelu(norm)")) return e;
+    LNN_REQUIRE(V <= SMALL_V, "lnn_conv3d_fwd_in_lrelu(norm): %ld voxels per sample exceed the single-launch limit %d", V, SMALL_V);
+    LNN_REQUIRE(z != nullptr && lnn_aligned16(z) && ld_z >= C && ld_z % 8 == 0, "lnn_conv3d_fwd_in_lrelu(norm): bad z / ld_z");
+    LNN_REQUIRE(mean && rstd && gamma && beta, "lnn_conv3d_fwd_in_lrelu(norm): null parameter");
+    const dim3 grid(C / 8, N);
+    if (sk)
+        hipLaunchKernelGGL((in_small_fwd_kernel<true>), grid, dim3(SNT), 0, s, (half_t*)y, sk->scratch, sk->ksplit, sk->nvox, sk->Mpad,
+                           sk->bias, (half_t*)z, ld_z, (int)V, C, eps, gamma, beta, slope, mean, rstd);
+    else
+        hipLaunchKernelGGL((in_small_fwd_kernel<false>), grid, dim3(SNT), 0, s, (half_t*)y, (const float*)nullptr, 1, 0L, 0,
+                           (const float*)nullptr, (half_t*)z, ld_z, (int)V, C, eps, gamma, beta, slope, mean, rstd);
+    LNN_CHECK_LAUNCH("lnn_conv3d_fwd_in_lrelu(norm)");
+    return LNN_OK;
+}
+
+int lnn_launch_in_small_bwd(hipStream_t s, void* y, const void* dz, int ld_dz, const SplitKDeferred* sk, int N, long V, int C,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, double* ws,
+                            float* dgamma, float* dbeta, float unscale) {
+    LNN_REQUIRE(V <= SMALL_V, "lnn_instnorm_lrelu_bwd(small): %ld voxels per sample exceed the single-launch limit %d", V, SMALL_V);
+    if (sk)
+        hipLaunchKernelGGL((in_small_bwd_kernel<true>), dim3(C / 8), dim3(SNT), 0, s, (half_t*)y, (const half_t*)nullptr, 0, sk->scratch,
+                           sk->ksplit, sk->nvox, sk->Mpad, N, (int)V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, unscale);
+    else
+        hipLaunchKernelGGL((in_small_bwd_kernel<false>), dim3(C / 8), dim3(SNT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz,
+                           (const float*)nullptr, 1, 0L, 0, N, (int)V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, unscale);
+    LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(small)");
+    return LNN_OK;
+}
 
 int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd) {
     hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(lnn_cdiv(N * C, FEB)), dim3(256), 0, s, pws, nslots, N * C, V, eps, mean, rstd);
@@ -865,6 +1141,8 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
     if (int e = check_common(y, N, V, C, "lnn_instnorm_lrelu_bwd")) return e;
     LNN_REQUIRE(dz != nullptr && lnn_aligned16(dz) && ld_dz >= C && ld_dz % 8 == 0, "lnn_instnorm_lrelu_bwd: bad dz / ld_dz");
     LNN_REQUIRE(mean && rstd && gamma && beta && ws, "lnn_instnorm_lrelu_bwd: null parameter");
+    if (V <= SMALL_V && !dbias && small_enabled())      // the lowest levels: reduce + sums + apply in one launch
+        return lnn_launch_in_small_bwd(s, y, dz, ld_dz, nullptr, N, V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, grad_unscale);
     float* pws = reinterpret_cast<float*>(ws + (size_t)N * C * 3);
     const int nblk = blocks_for(V, C);
     const dim3 grid(nblk, N);

@@ -467,6 +467,9 @@ class UNetEngine:
         # second block of a stage: pass 1 of the FIRST block's InstanceNorm backward rides the data gradient that produces its dL/dz
         # (lnn_conv3d_dgrad_in_bwd_sums; fused inside the z-streaming kernel where an instance exists): A/B switch
         self.fuse_in_bwd_reduce = os.environ.get("LNN_NO_FUSED_IN_BWD_REDUCE", "0") != "1"
+        # volumes up to this many voxels per sample run their normalisation (and the split-K finalize in front of it) as ONE launch per
+        # direction (csrc/norm_act.hip in_small_*; LNN_IN_SMALL=0: the multi-launch passes everywhere, A/B switch)
+        self.small_v = nat.query("lnn_instnorm_small_volume") if os.environ.get("LNN_IN_SMALL", "1") != "0" else 0
         # measurement hook (bench.py): {"layer": <block prefix>} -> the forward conv / data-gradient / weight-gradient calls of
         # that block are bracketed with timing events ON THE STREAM THEY LAUNCH ON, appended to probe["fwd" | "dgrad" | "wgrad"]
         self.probe = None
@@ -559,6 +562,17 @@ class UNetEngine:
                 C = item.cout
                 V = item.z.V
                 mean, rstd = item.mean, item.rstd
+                seg = self._seg_after.get(id(item))
+                seg_fused = seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512
+                if item.iso and self.fuse_in_stats and V <= self.small_v and not seg_fused:
+                    # the lowest levels (<= 2048 voxels per sample): the convolution's split-K slices, the statistics and the
+                    # normalisation are one launch behind the convolution instead of four (lnn_conv3d_fwd_in_lrelu)
+                    self._probed("fwd", item, lambda: nat.call(
+                        "lnn_conv3d_fwd_in_lrelu", xin, item.x2, ldx, item.x.C if item.x2 is not None else 0,
+                        self._wp(item.wp_fwd), self.pview(item.b), item.y, N, D, H, W, item.cin_k, C, item.stride, IN_EPS, mean, rstd,
+                        self.pview(item.gamma), self.pview(item.beta), LRELU_SLOPE, item.z, item.z.ld, ws, splitk_ws,
+                        splitk_ws.numel()))
+                    continue
                 if not item.iso:
                     # per-axis kernel / stride from the plans: generic-geometry kernel, statistics as a separate pass
                     self._probed("fwd", item, lambda: nat.call(
@@ -580,8 +594,7 @@ class UNetEngine:
                         nat.call("lnn_conv3d_fwd", xin, ldx, self._wp(item.wp_fwd), self.pview(item.b), item.y, C,
                                  N, D, H, W, item.cin_k, C, item.stride)
                     nat.call("lnn_instnorm_stats", item.y, N, V, C, IN_EPS, mean, rstd, ws)
-                seg = self._seg_after.get(id(item))
-                if seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512:
+                if seg_fused:
                     # decoder block that feeds a seg head: InstanceNorm + LeakyReLU + the 1x1x1 head in one pass over y
                     # (measured in round 5: NOT writing the last block's normalised tensor -- nobody reads it in a plain training
                     # step -- changes nothing, 20.01 vs 20.02 / 19.94 ms: the pass is bound by its instruction stream, not by its
@@ -692,6 +705,7 @@ class UNetEngine:
         seg_u = len(self.segs)
         pending = {}          # id(block) -> (seg head, dlogits): heads whose backward runs inside their block's norm backward
         presummed = set()     # id(block): pass 1 of its normalisation backward was taken by the data gradient that produced its dL/dz
+        normed = set()        # id(block): its WHOLE normalisation backward was (small volumes, lnn_conv3d_dgrad_in_bwd)
         for item in reversed(self.order):
             if progress is not None and item is not self.order[-1]:
                 # everything after this item in the arena is final once main (norm / bias / seg gradients) and side
@@ -744,6 +758,8 @@ class UNetEngine:
                             unpack(item)
                     on_side(lambda: self._probed("wgrad", item, first_wgrad))
                     continue
+                elif id(item) in normed:
+                    pass
                 elif id(item) in presummed:
                     self._probed("in_bwd", item, lambda: nat.call(
                         "lnn_instnorm_lrelu_bwd_apply", item.y, item.gz, item.gz.ld, N, V, K,
@@ -788,6 +804,18 @@ class UNetEngine:
                         "lnn_conv3d_dgrad_g", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
                         N, D, H, W, C, K, *item.kernel, *item.strides, 1 if item.gx_accumulate else 0, splitk_ws,
                         splitk_ws.numel()))
+                elif (self.fuse_in_bwd_reduce and item.x_block is not None and item.stride == 1 and item.gx2 is None and item.iso
+                      and not item.gx_accumulate and not self.numeric_conv_bias_grad and item.x_block.z.V <= self.small_v
+                      and not item.x_block.first):
+                    # the lowest levels: dL/dz of the stage's first block is consumed from the data gradient's split-K slices by that
+                    # block's WHOLE normalisation backward, one launch (lnn_conv3d_dgrad_in_bwd); its turn in the loop skips the pass
+                    xb = item.x_block
+                    self._probed("dgrad", item, lambda: nat.call(
+                        "lnn_conv3d_dgrad_in_bwd", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld,
+                        N, D, H, W, C, K, xb.y, xb.mean, xb.rstd, self.pview(xb.gamma),
+                        self.pview(xb.beta), LRELU_SLOPE, self.pview(xb.gamma, self.grad), self.pview(xb.beta, self.grad), 1.0, ws,
+                        splitk_ws, splitk_ws.numel()))
+                    normed.add(id(xb))
                 elif (self.fuse_in_bwd_reduce and item.x_block is not None and item.stride == 1 and item.gx2 is None
                       and not item.gx_accumulate and not self.numeric_conv_bias_grad):
                     # dL/dz of the stage's first block AND pass 1 of its normalisation backward (nothing between here and that

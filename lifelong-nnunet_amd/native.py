@@ -56,6 +56,9 @@ SIGNATURES = {
     "lnn_instnorm_lrelu_bwd_sums": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p, _p, _f, _p]),
     "lnn_conv3d_dgrad_in_bwd_sums": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _p, _l]),
     "lnn_instnorm_lrelu_bwd_apply": (_i, [_p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _f, _p]),
+    "lnn_instnorm_small_volume": (_i, []),
+    "lnn_conv3d_fwd_in_lrelu": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _p, _p, _l]),
+    "lnn_conv3d_dgrad_in_bwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _p, _l]),
     "lnn_conv3d_wgrad_c1_in_bwd": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _l]),
     "lnn_seg1x1_fwd": (_i, [_p, _p, _i, _p, _p, _i, _l, _i, _i]),
     "lnn_seg1x1_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _l, _i, _i, _i, _f, _p]),

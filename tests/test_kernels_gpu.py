@@ -1006,11 +1006,11 @@ def test_deep_layers_at_bench_shapes(name, Ca, Cb, K, D, H, W, which):
 
 
 @pytest.mark.parametrize("C,K,D,H,W,acc", [(32, 96, 3, 9, 10, 0), (64, 64, 5, 12, 10, 1), (16, 40, 3, 24, 20, 1), (48, 32, 7, 6, 5, 0),
-                                            (32, 64, 4, 8, 40, 0)])
+                                            (32, 64, 4, 8, 40, 0), (32, 64, 3, 10, 64, 0), (48, 40, 4, 7, 45, 1), (16, 32, 2, 20, 128, 0)])
 def test_macro_tile_kernel_split_k_and_ragged_bands(C, K, D, H, W, acc):
     """igemm_conv_mt.hip pinned on small volumes: odd plane counts (the last band has one live plane), a last row band shorter than
     TY, output channels that are not a multiple of 64 (the second row block of a channel block is dead), 40-wide rows (the widest
-    band the 32 KB halo image holds), the K split over chunks with a NaN-filled workspace (fixed-order finalize: bit-reproducible),
+    band the 32 KB halo image holds in one piece), wider planes cut into column bands (64 -> 2 x 32, 128 -> 4 x 32, a ragged 45 -> 3 x 15), the K split over chunks with a NaN-filled workspace (fixed-order finalize: bit-reproducible),
     accumulate into an existing gradient."""
     N = 2
     g = torch.Generator().manual_seed(C * K + W)
@@ -1046,3 +1046,4 @@ def test_macro_tile_kernel_split_k_and_ragged_bands(C, K, D, H, W, acc):
     assert torch.equal(ys[1], ys[2]) and torch.equal(dxs[1], dxs[2])        # split-K: slices added in a fixed order
     if not acc:
         assert torch.all(dxs[0][..., C:] == 0)                                   # channel padding of the buffer untouched
+

@@ -96,7 +96,11 @@ def test_forward_plan_of_a_training_step(dry):
     segf = _calls(dry, "lnn_instnorm_lrelu_seg_fwd")
     assert len(segf) == 3 and all(c[3][1] is not None for c in segf)
     nconv = sum(isinstance(i, ConvBlock) for i in eng.order)
-    assert len(_calls(dry, "lnn_instnorm_lrelu_fwd")) == nconv - 3 and not _calls(dry, "lnn_seg1x1_fwd")
+    # (blocks of <= lnn_instnorm_small_volume() voxels per sample that feed no fused head: conv + statistics + normalise in one call)
+    small = _calls(dry, "lnn_conv3d_fwd_in_lrelu")
+    nsmall = sum(isinstance(i, ConvBlock) and i.z.V <= eng.small_v and id(i) not in eng._seg_after for i in eng.order)
+    assert len(small) == nsmall > 0
+    assert len(_calls(dry, "lnn_instnorm_lrelu_fwd")) == nconv - 3 - nsmall and not _calls(dry, "lnn_seg1x1_fwd")
     dry.clear()
     w = [torch.zeros(3, s.cin, 1, 1, 1) for s in eng.segs]
     eng.forward(x, seg_weights=w, body=False)
@@ -104,7 +108,7 @@ def test_forward_plan_of_a_training_step(dry):
     dry.clear()
     eng.forward(x, seg_weights=w, body=True)
     assert not _calls(dry, "lnn_instnorm_lrelu_seg_fwd") and len(_calls(dry, "lnn_seg1x1_fwd")) == 3
-    assert len(_calls(dry, "lnn_instnorm_lrelu_fwd")) == nconv
+    assert len(_calls(dry, "lnn_instnorm_lrelu_fwd")) + len(_calls(dry, "lnn_conv3d_fwd_in_lrelu")) == nconv
 
 
 def _wgrads(rec):

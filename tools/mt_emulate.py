@@ -18,16 +18,23 @@ HALO = NW * NH * 1024
 
 
 def geometry(Lh, Lw):
+    """(efficiency, WN, TY, TX) as csrc/igemm_conv_mt.hip:mt_geometry."""
     best = None
-    for wn in (4, 5):
-        ty = min(Lh, (32 * wn) // Lw)
-        while ty >= 1 and 4 * (ty + 2) * (Lw + 2) > NW * NH * 32:
-            ty -= 1
-        if ty < 1:
+    prev = None
+    for nx in range(1, 17):
+        tx = -(-Lw // nx)
+        if tx == prev:
             continue
-        e = Lh * Lw / (-(-Lh // ty) * 32 * wn)
-        if best is None or e > best[0] + 1e-9:
-            best = (e, wn, ty)
+        prev = tx
+        for wn in (5, 4):
+            ty = min(Lh, (32 * wn) // tx)
+            while ty >= 1 and 4 * (ty + 2) * (tx + 2) > NW * NH * 32:
+                ty -= 1
+            if ty < 1:
+                continue
+            e = Lh * Lw / (-(-Lh // ty) * -(-Lw // tx) * 32 * wn)
+            if best is None or e > best[0] + 1e-9:
+                best = (e, wn, ty, tx)
     return best
 
 
@@ -47,12 +54,12 @@ def emulate(x, x2, csplit, wp, flip, M, ksplit=1):
     C = wp_C[0]
     Mpad = -(-M // 32) * 32
     KCpad = -(-C // 16) * 16
-    _, WN, TY = geometry(H, W)
-    PY, PX = TY + 2, W + 2
+    _, WN, TY, TX = geometry(H, W)
+    PY, PX = TY + 2, TX + 2
     PYX = PY * PX
     P = 4 * PYX
     mblk = -(-Mpad // 64)
-    zb, yb = -(-D // 2), -(-H // TY)
+    zb, yb, xb = -(-D // 2), -(-H // TY), -(-W // TX)
     nchunks = C // 16
     cpp = nchunks // ksplit
     kc16 = KCpad // 16
@@ -61,8 +68,8 @@ def emulate(x, x2, csplit, wp, flip, M, ksplit=1):
     lanes = np.arange(64)
     hk, v = lanes >> 5, lanes & 31
     xs = [x.reshape(N, -1), None if x2 is None else x2.reshape(N, -1)]
-    for part, mb, n, zbi, ybi in itertools.product(range(ksplit), range(mblk), range(N), range(zb), range(yb)):
-        z0, y0, m0 = zbi * 2, ybi * TY, mb * 64
+    for part, mb, n, zbi, ybi, xbi in itertools.product(range(ksplit), range(mblk), range(N), range(zb), range(yb), range(xb)):
+        z0, y0, x0, m0 = zbi * 2, ybi * TY, xbi * TX, mb * 64
         acc = np.zeros((NW, 2, WN, 32, 32))          # [wave][rb][ct][mfma row][col]
         for c in range(cpp):
             chunk = part * cpp + c
@@ -77,7 +84,7 @@ def emulate(x, x2, csplit, wp, flip, M, ksplit=1):
                     pos = (wave * NH + k) * 32 + (lanes >> 1)
                     pz, rem = pos // PYX, pos % PYX
                     py, px = rem // PX, rem % PX
-                    iz, iy, ix = z0 - 1 + pz, y0 - 1 + py, px - 1
+                    iz, iy, ix = z0 - 1 + pz, y0 - 1 + py, x0 - 1 + px
                     ok = (pos < P) & (iz >= 0) & (iz < D) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W)
                     half = (lanes & 1) ^ ((pos >> 3) & 1)
                     voff = (((iz * H + iy) * W + ix) * ld + half * 8)          # halves
@@ -87,7 +94,7 @@ def emulate(x, x2, csplit, wp, flip, M, ksplit=1):
                             lds[base[l]:base[l] + 8] = src[coff + voff[l]: coff + voff[l] + 8]
             for wave in range(NW):
                 sub, kq = wave >> 2, wave & 3
-                nv = TY * W
+                nv = TY * TX
                 for it in range(NIT):
                     tap = kq * NIT + it
                     if tap >= 27:
@@ -106,7 +113,7 @@ def emulate(x, x2, csplit, wp, flip, M, ksplit=1):
                         for ct in range(WN):
                             vv = ct * 32 + v
                             vc = np.minimum(vv, nv - 1)
-                            yy, xx = vc // W, vc % W
+                            yy, xx = vc // TX, vc % TX
                             lb = (((sub + 1) * PY + (yy + 1)) * PX + (xx + 1)) * 32 + hk * 16
                             bb = lb + toffb
                             addr = bb ^ ((bb >> 4) & 16)
@@ -124,16 +131,16 @@ def emulate(x, x2, csplit, wp, flip, M, ksplit=1):
                         tot[ch] += acc[sub * 4 + kq, rb, ct]
                     for col in range(32):
                         vv = ct * 32 + col
-                        if vv >= TY * W:
+                        if vv >= TY * TX:
                             continue
-                        yy, xx = vv // W, vv % W
-                        oz, oy = z0 + sub, y0 + yy
-                        if oz >= D or oy >= H:
+                        yy, xx = vv // TX, vv % TX
+                        oz, oy, ox = z0 + sub, y0 + yy, x0 + xx
+                        if oz >= D or oy >= H or ox >= W:
                             continue
                         for chn in range(32):
                             m = m0 + rb * 32 + chn
                             if m < M:
-                                y[n, oz, oy, xx, m] += tot[chn, col]
+                                y[n, oz, oy, ox, m] += tot[chn, col]
     return y
 
 
@@ -174,5 +181,7 @@ if __name__ == "__main__":
             check(1, 32, 96, 2, 9, 10, ksplit=2),
             check(2, 32, 32, 5, 12, 10, dgrad=True),
             check(1, 32, 64, 4, 8, 20, cat=True),
-            check(1, 16, 40, 3, 24, 20)]
+            check(1, 16, 40, 3, 24, 20),
+            check(1, 16, 32, 2, 10, 64),                    # x bands: 64 columns -> 4 x 16
+            check(1, 16, 32, 3, 7, 45, dgrad=True)]         # ragged x bands
     sys.exit(0 if max(errs) < 1e-5 else 1)
