@@ -221,16 +221,15 @@ int lnn_conv3d_dgrad_in_bwd_sums(lnn_stream_t s, const void* dy, int ld_dy, cons
 int lnn_instnorm_lrelu_bwd_apply(lnn_stream_t s, void* y_h, const void* dz_h, int ld_dz, int N, long V, int C, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, float slope, double* ws);
 /* Small volumes (the two lowest levels of a 160x192x160 plan: <= lnn_instnorm_small_volume() = 2048 voxels per sample).  There a
- * ConvDropoutNormNonlin block (test_MultiHead_Module.py:287-291, 394-415) is a few hundred KB and launch-latency-bound: conv (split
- * over its contraction) -> split-K finalize -> statistics -> statistics finalize -> normalise were five dependent launches forward,
- * data gradient -> finalize -> reduce -> sums -> apply five backward.
+ * ConvDropoutNormNonlin block (test_MultiHead_Module.py:287-291, 394-415) is ~1.5 MB and launch-latency-bound: statistics ->
+ * statistics finalize -> normalise were three dependent ~6 us launches behind the convolution, reduce -> sums -> apply three in the
+ * backward.
  * lnn_conv3d_fwd_in_lrelu = lnn_conv3d_fwd_in_stats + lnn_instnorm_lrelu_fwd (same outputs: y, mean, rstd, z; x_b / c_a: second part
- * of a channel concatenation or NULL / 0): on small volumes the slices of the convolution, the statistics and the normalisation are
- * ONE launch behind the convolution; on larger volumes it IS the two calls.
- * lnn_conv3d_dgrad_in_bwd (small volumes only, else LNN_ERR_BAD_ARG) = lnn_conv3d_dgrad_ws(stride 1, no accumulate) +
- * lnn_instnorm_lrelu_bwd(u, dx, ...) for the block whose convolution output is u: afterwards u holds dL/du in place, dgamma / dbeta
- * (+)= the affine gradients, ws[(n C + c) 3 + {0, 1}] the sums.  dL/dz is consumed from the data gradient's fp32 slices where it
- * splits; dx is scratch for the unsplit case and its contents are unspecified afterwards.
+ * of a channel concatenation or NULL / 0): on small volumes the normalisation is ONE launch behind the convolution; on larger
+ * volumes it IS the two calls.
+ * lnn_conv3d_dgrad_in_bwd (small volumes only, else LNN_ERR_BAD_ARG) = lnn_conv3d_dgrad_ws(stride 1, no accumulate) into dx +
+ * lnn_instnorm_lrelu_bwd(u, dx, ...) for the block whose convolution output is u: afterwards dx holds dL/dz, u holds dL/du in place,
+ * dgamma / dbeta (+)= the affine gradients, ws[(n C + c) 3 + {0, 1}] the sums.
  * lnn_instnorm_lrelu_bwd itself takes the one-launch path on small volumes (dbias == NULL). */
 int lnn_instnorm_small_volume(void);
 int lnn_conv3d_fwd_in_lrelu(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp, const float* bias,

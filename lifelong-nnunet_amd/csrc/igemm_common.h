@@ -58,24 +58,12 @@ bool lnn_conv_s1_v9_red_supported(const ConvParams& p);      // a fused-reduce i
 // igemm_conv_mt.hip: scratch slices -> fp16 output (+ bias, + old value when accumulating)
 // norm_act.hip: mean / rstd from per-slot partial sums pws[a][slot][n*C + c] (the finalize half of lnn_instnorm_stats)
 int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name);
-// A caller that consumes the split-K slices itself (norm_act.hip: the small-volume normalisation kernels add them while they read their
-// input) arms this before the convolution launch: lnn_launch_splitk_finalize then records where the slices are instead of launching the
-// finalize kernel (single output tensor, no accumulation; otherwise it launches as usual and `taken` stays false).  Thread-local.
-struct SplitKDeferred {
-    bool armed = false, taken = false;
-    int ksplit = 0, Mpad = 0;
-    long nvox = 0;
-    const float* scratch = nullptr;
-    const float* bias = nullptr;
-};
-SplitKDeferred& lnn_splitk_deferred();
-// norm_act.hip, small volumes (<= lnn_instnorm_small_volume() voxels per sample): statistics + normalise + LeakyReLU (+ the deferred
-// split-K finalize of the convolution that produced y) in ONE launch; the whole InstanceNorm + LeakyReLU backward in ONE launch
-int lnn_launch_in_small_fwd(hipStream_t s, void* y, const SplitKDeferred* sk, void* z, int ld_z, int N, long V, int C, float eps,
-                            const float* gamma, const float* beta, float slope, float* mean, float* rstd);
-int lnn_launch_in_small_bwd(hipStream_t s, void* y, const void* dz, int ld_dz, const SplitKDeferred* sk, int N, long V, int C,
-                            const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, double* ws,
-                            float* dgamma, float* dbeta, float unscale);
+// norm_act.hip, small volumes (<= lnn_instnorm_small_volume() voxels per sample): statistics + normalise + LeakyReLU in ONE launch;
+// the whole InstanceNorm + LeakyReLU backward in ONE launch
+int lnn_launch_in_small_fwd(hipStream_t s, const void* y, void* z, int ld_z, int N, long V, int C, float eps, const float* gamma,
+                            const float* beta, float slope, float* mean, float* rstd);
+int lnn_launch_in_small_bwd(hipStream_t s, void* y, const void* dz, int ld_dz, int N, long V, int C, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, float slope, double* ws, float* dgamma, float* dbeta, float unscale);
 int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, int N, int C, long V, float eps, float* mean, float* rstd);
 int lnn_launch_in_bwd_sums_raw(hipStream_t s, const float* pws, int nslots, int N, int C, const float* mean, const float* rstd,
                                double* ws, float* dgamma, float* dbeta, float unscale);

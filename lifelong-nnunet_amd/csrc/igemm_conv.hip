@@ -393,8 +393,8 @@ extern "C" int lnn_conv3d_fwd_in_stats(lnn_stream_t s, const void* x_a, const vo
 
 // conv + InstanceNorm + LeakyReLU of one ConvDropoutNormNonlin block (test_MultiHead_Module.py:287-291) in one call: y = conv(x) + bias,
 // mean / rstd of y per (sample, channel), z = LeakyReLU(gamma * (y - mean) * rstd + beta).  Up to lnn_instnorm_small_volume() output
-// voxels per sample (the two lowest levels of the 160x192x160 plan) the convolution's split-K slices, the statistics and the
-// normalisation are ONE launch behind the convolution (norm_act.hip: in_small_fwd_kernel) instead of four; larger volumes: exactly
+// voxels per sample (the two lowest levels of the 160x192x160 plan) the statistics, their finalize and the normalisation are ONE
+// launch behind the convolution (norm_act.hip: in_small_fwd_kernel) instead of three; larger volumes: exactly
 // lnn_conv3d_fwd_in_stats + lnn_instnorm_lrelu_fwd.
 extern "C" int lnn_conv3d_fwd_in_lrelu(lnn_stream_t s, const void* x_a, const void* x_b, int ld_x, int c_a, const void* wp,
                                        const float* bias, void* y, int N, int Di, int Hi, int Wi, int C, int K, int stride, float eps,
@@ -414,13 +414,9 @@ extern "C" int lnn_conv3d_fwd_in_lrelu(lnn_stream_t s, const void* x_a, const vo
         if (int e = check_cat(x_b, c_a, C, stride, "lnn_conv3d_fwd_in_lrelu")) return e;
         LNN_REQUIRE(ld_x >= c_a && ld_x >= C - c_a, "lnn_conv3d_fwd_in_lrelu: ld_x %d smaller than a part (%d / %d)", ld_x, c_a, C - c_a);
     }
-    SplitKDeferred& d = lnn_splitk_deferred();
-    d = SplitKDeferred{};
-    d.armed = true;
-    const int rc = conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, K, N, Di, Hi, Wi, C, K, stride, nullptr, nullptr, splitk_ws, splitk_elems);
-    d.armed = false;
-    if (rc) return rc;
-    return lnn_launch_in_small_fwd((hipStream_t)s, y, d.taken ? &d : nullptr, z, ld_z, N, V, K, eps, gamma, beta, slope, mean, rstd);
+    if (int rc = conv3d_fwd_impl(s, x_a, x_b, c_a, ld_x, wp, bias, y, K, N, Di, Hi, Wi, C, K, stride, nullptr, nullptr, splitk_ws, splitk_elems))
+        return rc;
+    return lnn_launch_in_small_fwd((hipStream_t)s, y, z, ld_z, N, V, K, eps, gamma, beta, slope, mean, rstd);
 }
 
 namespace {
@@ -527,11 +523,9 @@ extern "C" int lnn_conv3d_dgrad_in_bwd_sums(lnn_stream_t s_, const void* dy, int
 }
 
 // Data gradient of a stride-1 3x3x3 convolution TOGETHER with the whole InstanceNorm + LeakyReLU backward of the block that produced
-// its input (small volumes only: V = Di Hi Wi <= lnn_instnorm_small_volume()): afterwards u -- that block's convolution output on
-// entry -- holds dL/du in place and dgamma / dbeta (+)= its affine gradients, as after lnn_conv3d_dgrad_ws(stride 1, no accumulate)
-// into dx + lnn_instnorm_lrelu_bwd(u, dx, ...).  When the data gradient splits its contraction the normalisation kernel adds the fp32
-// slices itself (same slice order and fp16 rounding as the finalize kernel): dL/dz is then never written and dx is left untouched --
-// its contents are unspecified after this call.
+// its input (small volumes only: V = Di Hi Wi <= lnn_instnorm_small_volume()): afterwards dx holds dL/dz, u -- that block's
+// convolution output on entry -- dL/du in place, and dgamma / dbeta (+)= its affine gradients: lnn_conv3d_dgrad_ws(stride 1, no
+// accumulate) into dx + lnn_instnorm_lrelu_bwd(u, dx, ...) with the three passes of the latter as one launch.
 extern "C" int lnn_conv3d_dgrad_in_bwd(lnn_stream_t s_, const void* dy, int ld_dy, const void* wp, void* dx, int ld_dx, int N, int Di,
                                        int Hi, int Wi, int C, int K, void* u, const float* mean, const float* rstd, const float* gamma,
                                        const float* beta, float slope, float* dgamma, float* dbeta, float grad_unscale, double* ws,
@@ -541,14 +535,8 @@ extern "C" int lnn_conv3d_dgrad_in_bwd(lnn_stream_t s_, const void* dy, int ld_d
     LNN_REQUIRE(V <= lnn_instnorm_small_volume(), "lnn_conv3d_dgrad_in_bwd: %ld voxels per sample (limit %d): use lnn_conv3d_dgrad_in_bwd_sums",
                 V, lnn_instnorm_small_volume());
     LNN_REQUIRE(C % 8 == 0, "lnn_conv3d_dgrad_in_bwd: %d channels (multiple of 8)", C);
-    SplitKDeferred& d = lnn_splitk_deferred();
-    d = SplitKDeferred{};
-    d.armed = true;
-    const int rc = conv3d_dgrad_impl(s_, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, 1, 0, splitk_ws, splitk_elems);
-    d.armed = false;
-    if (rc) return rc;
-    return lnn_launch_in_small_bwd((hipStream_t)s_, u, dx, ld_dx, d.taken ? &d : nullptr, N, V, C, mean, rstd, gamma, beta, slope, ws, dgamma,
-                                   dbeta, grad_unscale);
+    if (int rc = conv3d_dgrad_impl(s_, dy, ld_dy, wp, dx, nullptr, 0, ld_dx, N, Di, Hi, Wi, C, K, 1, 0, splitk_ws, splitk_elems)) return rc;
+    return lnn_launch_in_small_bwd((hipStream_t)s_, u, dx, ld_dx, N, V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, grad_unscale);
 }
 
 extern "C" int lnn_conv3d_dgrad_cat(lnn_stream_t s, const void* dy, int ld_dy, const void* wp, void* dx_a, void* dx_b, int ld_dx,

@@ -379,19 +379,8 @@ int launch_mt(hipStream_t s, ConvParams& p, const MTLaunch& q, int grid, const c
 
 }  // namespace
 
-SplitKDeferred& lnn_splitk_deferred() {
-    static thread_local SplitKDeferred d;
-    return d;
-}
-
 int lnn_launch_splitk_finalize(hipStream_t s, const ConvParams& p, const char* name) {
     const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
-    SplitKDeferred& d = lnn_splitk_deferred();
-    if (d.armed && !p.accumulate && p.y2 == nullptr && p.ld_y == p.M && p.M % 8 == 0) {
-        // the consumer adds the slices itself (norm_act.hip, small volumes): nothing to launch
-        d.taken = true; d.ksplit = p.ksplit; d.Mpad = p.Mpad; d.nvox = nvox; d.scratch = p.scratch; d.bias = p.bias;
-        return LNN_OK;
-    }
     const long total = nvox * (p.Mpad >> 2);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, s, p, nvox);

@@ -766,238 +766,209 @@ __global__ __launch_bounds__(NT) void in_lrelu_seg_bwd_apply_kernel(half_t* __re
 }
 
 // ---- small volumes (the two lowest levels of the U: <= 2048 voxels per sample) ---------------------------------------------------
-// There a normalisation is a few hundred KB and every launch of the multi-block passes costs its fixed ~6 us: statistics, finalize and
-// normalise (forward; + the split-K finalize of the convolution in front) / reduce, sums and apply (backward) were 3-4 dependent
-// launches per layer, ~25 us for what is ~5 us of work.  One launch each: a 512-thread block owns ONE channel octet of one sample
-// (forward) or of every sample in turn (backward: the affine gradients are an ordered sum over the samples), keeps its <= 4 rows per
-// thread in registers between the reduction and the normalisation, reduces through wave shuffles + one LDS step in fp64.
-constexpr int SNT = 512, SR = 4;
-constexpr int SMALL_V = SNT * SR;
+// There a normalisation is ~1.5 MB and every launch of the multi-block passes costs its fixed ~6 us: statistics, finalize and normalise
+// (forward) / reduce, sums and apply (backward) were 3 dependent launches per layer for ~3 us of work.  One launch each: a 512-thread
+// block owns 32 CHANNELS of one sample (forward) or of every sample in turn (backward: the affine gradients are an ordered sum over
+// the samples): thread = (row lane 0..127, channel octet 0..3), so a wave-wide load covers 16 rows x 64 contiguous bytes; the rows
+// are read a second time (from the L2) for the normalisation; sums: butterfly over the row lanes of a wave, then one LDS step in
+// fp64.  (A first version gave a block ONE octet -- every lane of a load in its own cache line -- and
+// also added the convolution's split-K slices itself: 30-70 us per launch, profiles/r06_small_volume_norm.txt; the slices are 8-25 MB
+// and need the whole chip, so lnn_launch_splitk_finalize stays a launch of its own.)
+constexpr int SNT = 512, SRL = SNT / 4;        // threads, row lanes
+constexpr int SMALL_V = SRL * 16;              // 2048: at most 16 rows per thread and pass
 
-// fp64 totals of 16 per-thread values over the block: afterwards dtot[j] (shared) holds total j; thread j < 16 gets it returned too
-__device__ __forceinline__ double small_block_sum16(float (&v)[16], double* red, double* dtot) {
+// fp64 totals of 16 per-thread values (2 sums x 8 channels of the thread's octet) over the 128 row lanes: afterwards
+// dtot[octet * 16 + j] (shared) holds total j of the octet.  Lanes of one octet within a wave: tid & 3 fixed -> butterfly over
+// lane bits 2..5, then the 8 waves meet in LDS.
+__device__ __forceinline__ void small_block_sum16(float (&v)[16], double* red, double* dtot) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = wave_sum(v[j]);
-    __syncthreads();                       // (the previous round's readers of red / dtot are done)
-    if (lane == 0) {
+    for (int j = 0; j < 16; ++j) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) red[j * (SNT / 64) + wid] = (double)v[j];
+        for (int o = 32; o >= 4; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
+    }
+    __syncthreads();                       // (the previous round's readers of red / dtot are done)
+    if (lane < 4) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[((lane * 16) + j) * (SNT / 64) + wid] = (double)v[j];
     }
     __syncthreads();
-    double t = 0;
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 64) {
+        double t = 0;
 #pragma unroll
         for (int w = 0; w < SNT / 64; ++w) t += red[threadIdx.x * (SNT / 64) + w];
         dtot[threadIdx.x] = t;
     }
     __syncthreads();
-    return t;
 }
 
-// Forward: [split-K slices + bias -> y |  y] -> statistics -> mean / rstd -> z = LeakyReLU(gamma * xhat + beta).  grid (C / 8, N).
-// SPLIT: the convolution left `ksplit` fp32 slices scratch[part][n * V + v][Mpad] (lnn_launch_splitk_finalize deferred): they are
-// added in slice order, + bias, rounded to fp16 = y (written: the backward and the weight gradient read it), exactly what the finalize
-// kernel + the statistics pass would have produced.
-template <bool SPLIT>
-__global__ __launch_bounds__(SNT) void in_small_fwd_kernel(half_t* __restrict__ y, const float* __restrict__ scratch, int ksplit,
-                                                           long nvox, int Mpad, const float* __restrict__ bias,
-                                                           half_t* __restrict__ z, int ld_z, int V, int C, float eps,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+// Forward: statistics of y -> mean / rstd -> z = LeakyReLU(gamma * xhat + beta).  grid (C / 32, N); C % 32 == 0 not required: octets
+// beyond C are idle lanes.  Rows r = rl + k SRL, SU rows per trip with all their loads in flight (rows beyond V read row V - 1 again:
+// unconditional loads; they take no part in the sums / stores); the second pass re-reads y (L2-resident: the tensor is ~1.5 MB).
+constexpr int SU = 4;
+__global__ __launch_bounds__(SNT) void in_small_fwd_kernel(const half_t* __restrict__ y, half_t* __restrict__ z, int ld_z, int V, int C,
+                                                           float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float slope, float* __restrict__ mean, float* __restrict__ rstd) {
-    __shared__ double red[16 * (SNT / 64)];
-    __shared__ double dtot[16];
-    __shared__ float bc[16];
-    const int c0 = blockIdx.x * 8, n = blockIdx.y;
-    // rows r = tid + k SNT; rows beyond V read row V - 1 again (every load unconditional: all of a thread's loads are in flight
-    // together) and take no part in the sums / stores
-    long vox[SR];
-    bool live[SR];
-#pragma unroll
-    for (int k = 0; k < SR; ++k) {
-        const int r = threadIdx.x + k * SNT;
-        live[k] = r < V;
-        vox[k] = (long)n * V + (live[k] ? r : V - 1);
-    }
-    half8 x[SR];
-    if constexpr (SPLIT) {
-        floatx4 a[SR], b[SR];
-#pragma unroll
-        for (int k = 0; k < SR; ++k) {
-            const float* sp = scratch + vox[k] * Mpad + c0;
-            a[k] = *reinterpret_cast<const floatx4*>(sp);
-            b[k] = *reinterpret_cast<const floatx4*>(sp + 4);
-        }
-        const long sstride = nvox * Mpad;
-        // slices added in order (the finalize kernel's sum); four slices of every row in flight per trip
-#pragma unroll 4
-        for (int q = 1; q < ksplit; ++q) {
-            floatx4 ta[SR], tb[SR];
-#pragma unroll
-            for (int k = 0; k < SR; ++k) {
-                const float* sp = scratch + (long)q * sstride + vox[k] * Mpad + c0;
-                ta[k] = *reinterpret_cast<const floatx4*>(sp);
-                tb[k] = *reinterpret_cast<const floatx4*>(sp + 4);
-            }
-#pragma unroll
-            for (int k = 0; k < SR; ++k) { a[k] += ta[k]; b[k] += tb[k]; }
-        }
-        floatx4 ba = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
-        if (bias) { ba = *reinterpret_cast<const floatx4*>(bias + c0); bb = *reinterpret_cast<const floatx4*>(bias + c0 + 4); }
-#pragma unroll
-        for (int k = 0; k < SR; ++k) {
-            a[k] += ba; b[k] += bb;
-            x[k] = half8{(half_t)a[k][0], (half_t)a[k][1], (half_t)a[k][2], (half_t)a[k][3],
-                         (half_t)b[k][0], (half_t)b[k][1], (half_t)b[k][2], (half_t)b[k][3]};
-            if (live[k]) *reinterpret_cast<half8*>(y + vox[k] * C + c0) = x[k];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < SR; ++k) x[k] = *reinterpret_cast<const half8*>(y + vox[k] * C + c0);
-    }
+    __shared__ double red[64 * (SNT / 64)];
+    __shared__ double dtot[64];
+    __shared__ float bc[64];
+    const int oc = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int n = blockIdx.y;
+    const bool chan_ok = blockIdx.x * 32 + oc * 8 < C;
+    const int c0 = chan_ok ? blockIdx.x * 32 + oc * 8 : 0;
+    const half_t* yn = y + (long)n * V * C + c0;
+    half_t* zn = z + (long)n * V * ld_z + c0;
     float part[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[e] = 0.f;
+    for (int r0 = rl; r0 < V; r0 += SU * SRL) {
+        half8 x[SU];
 #pragma unroll
-    for (int k = 0; k < SR; ++k)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float f = live[k] ? (float)x[k][e] : 0.f;
-            part[e] += f;
-            part[8 + e] += f * f;
+        for (int k = 0; k < SU; ++k) {
+            const int r = r0 + k * SRL;
+            x[k] = *reinterpret_cast<const half8*>(yn + (r < V ? r : V - 1) * C);
         }
+#pragma unroll
+        for (int k = 0; k < SU; ++k) {
+            const bool live = r0 + k * SRL < V && chan_ok;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = live ? (float)x[k][e] : 0.f;
+                part[e] += f;
+                part[8 + e] += f * f;
+            }
+        }
+    }
     small_block_sum16(part, red, dtot);
-    if (threadIdx.x < 8) {
-        const int e = threadIdx.x;
-        const double m = dtot[e] / (double)V;
-        double var = dtot[8 + e] / (double)V - m * m;
-        if (var < 0) var = 0;
-        const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
-        mean[n * C + c0 + e] = mf; rstd[n * C + c0 + e] = rf;
-        const float sc = gamma[c0 + e] * rf;
-        bc[e] = sc;
-        bc[8 + e] = beta[c0 + e] - mf * sc;
+    if (threadIdx.x < 32) {                  // thread = channel of the block's 32
+        const int o = threadIdx.x >> 3, e = threadIdx.x & 7, c = blockIdx.x * 32 + threadIdx.x;
+        if (c < C) {
+            const double m = dtot[o * 16 + e] / (double)V;
+            double var = dtot[o * 16 + 8 + e] / (double)V - m * m;
+            if (var < 0) var = 0;
+            const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+            mean[n * C + c] = mf; rstd[n * C + c] = rf;
+            const float sc = gamma[c] * rf;
+            bc[threadIdx.x] = sc;
+            bc[32 + threadIdx.x] = beta[c] - mf * sc;
+        }
     }
     __syncthreads();
+    if (!chan_ok) return;
     float sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = bc[e]; sh[e] = bc[8 + e]; }
+    for (int e = 0; e < 8; ++e) { sc[e] = bc[oc * 8 + e]; sh[e] = bc[32 + oc * 8 + e]; }
+    for (int r0 = rl; r0 < V; r0 += SU * SRL) {
+        half8 x[SU];
 #pragma unroll
-    for (int k = 0; k < SR; ++k) {
-        half8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float t = (float)x[k][e] * sc[e] + sh[e];
-            o[e] = (half_t)(t > 0.f ? t : t * slope);
+        for (int k = 0; k < SU; ++k) {
+            const int r = r0 + k * SRL;
+            x[k] = *reinterpret_cast<const half8*>(yn + (r < V ? r : V - 1) * C);
         }
-        if (live[k]) *reinterpret_cast<half8*>(z + vox[k] * ld_z + c0) = o;
+#pragma unroll
+        for (int k = 0; k < SU; ++k) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = (float)x[k][e] * sc[e] + sh[e];
+                o[e] = (half_t)(t > 0.f ? t : t * slope);
+            }
+            const int r = r0 + k * SRL;
+            if (r < V) *reinterpret_cast<half8*>(zn + r * ld_z) = o;
+        }
     }
 }
 
 // Backward: g = dz * lrelu'(gamma xhat + beta); s1 = sum g, s2 = sum g xhat per (n, c); dy = gamma rstd (g - s1 / V - xhat s2 / V) in
-// place over y; d gamma / d beta = ordered sums over the samples, one add per channel (as in_bwd_sums_block).  grid (C / 8).
-// SPLIT: dz is what a split-K data gradient left in its fp32 slices scratch[part][n * V + v][Mpad] (finalize deferred; dz is read by
-// nobody else, so its fp16 tensor is never written).
-template <bool SPLIT>
-__global__ __launch_bounds__(SNT) void in_small_bwd_kernel(half_t* __restrict__ y, const half_t* __restrict__ dz, int ld_dz,
-                                                           const float* __restrict__ scratch, int ksplit, long nvox, int Mpad,
-                                                           int N, int V, int C, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float slope, double* __restrict__ ws,
-                                                           float* dgamma, float* dbeta, float unscale) {
-    __shared__ double red[16 * (SNT / 64)];
-    __shared__ double dtot[16];
-    __shared__ float bc[16];
-    const int c0 = blockIdx.x * 8;
+// place over y; d gamma / d beta = ordered sums over the samples, one add per channel (as in_bwd_sums_block).  grid (C / 32).
+__global__ __launch_bounds__(SNT) void in_small_bwd_kernel(half_t* __restrict__ y, const half_t* __restrict__ dz, int ld_dz, int N, int V,
+                                                           int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                           double* __restrict__ ws, float* dgamma, float* dbeta, float unscale) {
+    __shared__ double red[64 * (SNT / 64)];
+    __shared__ double dtot[64];
+    __shared__ float bc[64];
+    const int oc = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const bool chan_ok = blockIdx.x * 32 + oc * 8 < C;
+    const int c0 = chan_ok ? blockIdx.x * 32 + oc * 8 : 0;
     float ga[8], be[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; }
     const float invV = 1.0f / (float)V;
-    double gacc = 0;                      // thread j < 8: sum over n of s1 of channel j; 8 <= j < 16: of s2 of channel j - 8
+    double gacc = 0;                      // thread t < 64: sum over n of total (t & 15) of octet t >> 4 (s1 of 8 channels, then s2)
     for (int n = 0; n < N; ++n) {
         float mu[8], rs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mu[e] = mean[n * C + c0 + e]; rs[e] = rstd[n * C + c0 + e]; }
-        long vox[SR];
-        bool live[SR];
-#pragma unroll
-        for (int k = 0; k < SR; ++k) {
-            const int r = threadIdx.x + k * SNT;
-            live[k] = r < V;
-            vox[k] = (long)n * V + (live[k] ? r : V - 1);          // (unconditional loads, see the forward kernel)
-        }
-        half8 xv[SR], gv[SR];             // y rows and dz rows (fp16: what the finalize kernel would have stored)
-#pragma unroll
-        for (int k = 0; k < SR; ++k) xv[k] = *reinterpret_cast<const half8*>(y + vox[k] * C + c0);
-        if constexpr (SPLIT) {
-            floatx4 a[SR], b[SR];
-#pragma unroll
-            for (int k = 0; k < SR; ++k) {
-                const float* sp = scratch + vox[k] * Mpad + c0;
-                a[k] = *reinterpret_cast<const floatx4*>(sp);
-                b[k] = *reinterpret_cast<const floatx4*>(sp + 4);
-            }
-            const long sstride = nvox * Mpad;
-#pragma unroll 2
-            for (int q = 1; q < ksplit; ++q) {
-                floatx4 ta[SR], tb[SR];
-#pragma unroll
-                for (int k = 0; k < SR; ++k) {
-                    const float* sp = scratch + (long)q * sstride + vox[k] * Mpad + c0;
-                    ta[k] = *reinterpret_cast<const floatx4*>(sp);
-                    tb[k] = *reinterpret_cast<const floatx4*>(sp + 4);
-                }
-#pragma unroll
-                for (int k = 0; k < SR; ++k) { a[k] += ta[k]; b[k] += tb[k]; }
-            }
-#pragma unroll
-            for (int k = 0; k < SR; ++k)
-                gv[k] = half8{(half_t)a[k][0], (half_t)a[k][1], (half_t)a[k][2], (half_t)a[k][3],
-                              (half_t)b[k][0], (half_t)b[k][1], (half_t)b[k][2], (half_t)b[k][3]};
-        } else {
-#pragma unroll
-            for (int k = 0; k < SR; ++k) gv[k] = *reinterpret_cast<const half8*>(dz + vox[k] * ld_dz + c0);
-        }
+        half_t* yn = y + (long)n * V * C + c0;
+        const half_t* dn = dz + (long)n * V * ld_dz + c0;
         float part[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) part[e] = 0.f;
+        for (int r0 = rl; r0 < V; r0 += SU * SRL) {
+            half8 xv[SU], gv[SU];
 #pragma unroll
-        for (int k = 0; k < SR; ++k)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float h = ((float)xv[k][e] - mu[e]) * rs[e];
-                const float pre = ga[e] * h + be[e];
-                const float gg = live[k] ? (float)gv[k][e] * (pre > 0.f ? 1.f : slope) : 0.f;
-                part[e] += gg;
-                part[8 + e] += gg * h;
+            for (int k = 0; k < SU; ++k) {
+                const int r = r0 + k * SRL, rc = r < V ? r : V - 1;
+                xv[k] = *reinterpret_cast<const half8*>(yn + rc * C);
+                gv[k] = *reinterpret_cast<const half8*>(dn + rc * ld_dz);
             }
-        const double t = small_block_sum16(part, red, dtot);
-        if (threadIdx.x < 16) {
+#pragma unroll
+            for (int k = 0; k < SU; ++k) {
+                const bool live = r0 + k * SRL < V && chan_ok;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float h = ((float)xv[k][e] - mu[e]) * rs[e];
+                    const float pre = ga[e] * h + be[e];
+                    const float gg = live ? (float)gv[k][e] * (pre > 0.f ? 1.f : slope) : 0.f;
+                    part[e] += gg;
+                    part[8 + e] += gg * h;
+                }
+            }
+        }
+        small_block_sum16(part, red, dtot);
+        if (threadIdx.x < 64) {
+            const double t = dtot[threadIdx.x];
+            const int o = threadIdx.x >> 4, j = threadIdx.x & 15, c = blockIdx.x * 32 + o * 8 + (j & 7);
             bc[threadIdx.x] = (float)(t * (double)invV);
             gacc += t;
-            ws[((long)n * C + c0 + (threadIdx.x & 7)) * 3 + (threadIdx.x >> 3)] = t;
+            if (c < C) ws[((long)n * C + c) * 3 + (j >> 3)] = t;
         }
         __syncthreads();
-        float m1[8], m2[8];
+        if (chan_ok) {
+            float m1[8], m2[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { m1[e] = bc[e]; m2[e] = bc[8 + e]; }
+            for (int e = 0; e < 8; ++e) { m1[e] = bc[oc * 16 + e]; m2[e] = bc[oc * 16 + 8 + e]; }
+            for (int r0 = rl; r0 < V; r0 += SU * SRL) {
+                half8 xv[SU], gv[SU];
 #pragma unroll
-        for (int k = 0; k < SR; ++k) {
-            half8 o;
+                for (int k = 0; k < SU; ++k) {
+                    const int r = r0 + k * SRL, rc = r < V ? r : V - 1;
+                    xv[k] = *reinterpret_cast<const half8*>(yn + rc * C);
+                    gv[k] = *reinterpret_cast<const half8*>(dn + rc * ld_dz);
+                }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float h = ((float)xv[k][e] - mu[e]) * rs[e];
-                const float pre = ga[e] * h + be[e];
-                const float gg = (float)gv[k][e] * (pre > 0.f ? 1.f : slope);
-                o[e] = (half_t)(ga[e] * rs[e] * (gg - m1[e] - h * m2[e]));
+                for (int k = 0; k < SU; ++k) {
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float h = ((float)xv[k][e] - mu[e]) * rs[e];
+                        const float pre = ga[e] * h + be[e];
+                        const float gg = (float)gv[k][e] * (pre > 0.f ? 1.f : slope);
+                        o[e] = (half_t)(ga[e] * rs[e] * (gg - m1[e] - h * m2[e]));
+                    }
+                    const int r = r0 + k * SRL;
+                    if (r < V) *reinterpret_cast<half8*>(yn + r * C) = o;
+                }
             }
-            if (live[k]) *reinterpret_cast<half8*>(y + vox[k] * C + c0) = o;
         }
     }
-    if (threadIdx.x < 8) {
-        if (dbeta) atomicAdd(dbeta + c0 + threadIdx.x, (float)(gacc * unscale));
-    } else if (threadIdx.x < 16) {
-        if (dgamma) atomicAdd(dgamma + c0 + threadIdx.x - 8, (float)(gacc * unscale));
+    if (threadIdx.x < 64) {
+        const int o = threadIdx.x >> 4, j = threadIdx.x & 15, c = blockIdx.x * 32 + o * 8 + (j & 7);
+        if (c < C) {
+            if (j < 8) { if (dbeta) atomicAdd(dbeta + c, (float)(gacc * unscale)); }
+            else if (dgamma) atomicAdd(dgamma + c, (float)(gacc * unscale));
+        }
     }
 }
 
@@ -1027,33 +998,24 @@ int check_common(const void* y, int N, long V, int C, const char* what) {
 
 extern "C" int lnn_instnorm_small_volume(void) { return SMALL_V; }
 
-int lnn_launch_in_small_fwd(hipStream_t s, void* y, const SplitKDeferred* sk, void* z, int ld_z, int N, long V, int C, float eps,
-                            const float* gamma, const float* beta, float slope, float* mean, float* rstd) {
+int lnn_launch_in_small_fwd(hipStream_t s, const void* y, void* z, int ld_z, int N, long V, int C, float eps, const float* gamma,
+                            const float* beta, float slope, float* mean, float* rstd) {
     if (int e = check_common(y, N, V, C, "lnn_conv3d_fwd_in_lrelu(norm)")) return e;
     LNN_REQUIRE(V <= SMALL_V, "lnn_conv3d_fwd_in_lrelu(norm): %ld voxels per sample exceed the single-launch limit %d", V, SMALL_V);
     LNN_REQUIRE(z != nullptr && lnn_aligned16(z) && ld_z >= C && ld_z % 8 == 0, "lnn_conv3d_fwd_in_lrelu(norm): bad z / ld_z");
     LNN_REQUIRE(mean && rstd && gamma && beta, "lnn_conv3d_fwd_in_lrelu(norm): null parameter");
-    const dim3 grid(C / 8, N);
-    if (sk)
-        hipLaunchKernelGGL((in_small_fwd_kernel<true>), grid, dim3(SNT), 0, s, (half_t*)y, sk->scratch, sk->ksplit, sk->nvox, sk->Mpad,
-                           sk->bias, (half_t*)z, ld_z, (int)V, C, eps, gamma, beta, slope, mean, rstd);
-    else
-        hipLaunchKernelGGL((in_small_fwd_kernel<false>), grid, dim3(SNT), 0, s, (half_t*)y, (const float*)nullptr, 1, 0L, 0,
-                           (const float*)nullptr, (half_t*)z, ld_z, (int)V, C, eps, gamma, beta, slope, mean, rstd);
+    const dim3 grid(lnn_cdiv(C, 32), N);
+    hipLaunchKernelGGL(in_small_fwd_kernel, grid, dim3(SNT), 0, s, (const half_t*)y, (half_t*)z, ld_z, (int)V, C, eps, gamma, beta, slope,
+                       mean, rstd);
     LNN_CHECK_LAUNCH("lnn_conv3d_fwd_in_lrelu(norm)");
     return LNN_OK;
 }
 
-int lnn_launch_in_small_bwd(hipStream_t s, void* y, const void* dz, int ld_dz, const SplitKDeferred* sk, int N, long V, int C,
-                            const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, double* ws,
-                            float* dgamma, float* dbeta, float unscale) {
+int lnn_launch_in_small_bwd(hipStream_t s, void* y, const void* dz, int ld_dz, int N, long V, int C, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, float slope, double* ws, float* dgamma, float* dbeta, float unscale) {
     LNN_REQUIRE(V <= SMALL_V, "lnn_instnorm_lrelu_bwd(small): %ld voxels per sample exceed the single-launch limit %d", V, SMALL_V);
-    if (sk)
-        hipLaunchKernelGGL((in_small_bwd_kernel<true>), dim3(C / 8), dim3(SNT), 0, s, (half_t*)y, (const half_t*)nullptr, 0, sk->scratch,
-                           sk->ksplit, sk->nvox, sk->Mpad, N, (int)V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, unscale);
-    else
-        hipLaunchKernelGGL((in_small_bwd_kernel<false>), dim3(C / 8), dim3(SNT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz,
-                           (const float*)nullptr, 1, 0L, 0, N, (int)V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, unscale);
+    hipLaunchKernelGGL(in_small_bwd_kernel, dim3(lnn_cdiv(C, 32)), dim3(SNT), 0, s, (half_t*)y, (const half_t*)dz, ld_dz, N, (int)V, C, mean,
+                       rstd, gamma, beta, slope, ws, dgamma, dbeta, unscale);
     LNN_CHECK_LAUNCH("lnn_instnorm_lrelu_bwd(small)");
     return LNN_OK;
 }
@@ -1142,7 +1104,7 @@ extern "C" int lnn_instnorm_lrelu_bwd(lnn_stream_t s_, void* y, const void* dz, 
     LNN_REQUIRE(dz != nullptr && lnn_aligned16(dz) && ld_dz >= C && ld_dz % 8 == 0, "lnn_instnorm_lrelu_bwd: bad dz / ld_dz");
     LNN_REQUIRE(mean && rstd && gamma && beta && ws, "lnn_instnorm_lrelu_bwd: null parameter");
     if (V <= SMALL_V && !dbias && small_enabled())      // the lowest levels: reduce + sums + apply in one launch
-        return lnn_launch_in_small_bwd(s, y, dz, ld_dz, nullptr, N, V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, grad_unscale);
+        return lnn_launch_in_small_bwd(s, y, dz, ld_dz, N, V, C, mean, rstd, gamma, beta, slope, ws, dgamma, dbeta, grad_unscale);
     float* pws = reinterpret_cast<float*>(ws + (size_t)N * C * 3);
     const int nblk = blocks_for(V, C);
     const dim3 grid(nblk, N);

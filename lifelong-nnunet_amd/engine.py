@@ -467,8 +467,8 @@ class UNetEngine:
         # second block of a stage: pass 1 of the FIRST block's InstanceNorm backward rides the data gradient that produces its dL/dz
         # (lnn_conv3d_dgrad_in_bwd_sums; fused inside the z-streaming kernel where an instance exists): A/B switch
         self.fuse_in_bwd_reduce = os.environ.get("LNN_NO_FUSED_IN_BWD_REDUCE", "0") != "1"
-        # volumes up to this many voxels per sample run their normalisation (and the split-K finalize in front of it) as ONE launch per
-        # direction (csrc/norm_act.hip in_small_*; LNN_IN_SMALL=0: the multi-launch passes everywhere, A/B switch)
+        # volumes up to this many voxels per sample run their normalisation as ONE launch per direction (csrc/norm_act.hip
+        # in_small_*; LNN_IN_SMALL=0: the multi-launch passes everywhere, A/B switch)
         self.small_v = nat.query("lnn_instnorm_small_volume") if os.environ.get("LNN_IN_SMALL", "1") != "0" else 0
         # measurement hook (bench.py): {"layer": <block prefix>} -> the forward conv / data-gradient / weight-gradient calls of
         # that block are bracketed with timing events ON THE STREAM THEY LAUNCH ON, appended to probe["fwd" | "dgrad" | "wgrad"]
@@ -565,8 +565,8 @@ class UNetEngine:
                 seg = self._seg_after.get(id(item))
                 seg_fused = seg is not None and sw is None and self.fuse_seg_fwd and (C // 8) & (C // 8 - 1) == 0 and C <= 512
                 if item.iso and self.fuse_in_stats and V <= self.small_v and not seg_fused:
-                    # the lowest levels (<= 2048 voxels per sample): the convolution's split-K slices, the statistics and the
-                    # normalisation are one launch behind the convolution instead of four (lnn_conv3d_fwd_in_lrelu)
+                    # the lowest levels (<= 2048 voxels per sample): statistics, their finalize and the normalisation are one launch
+                    # behind the convolution instead of three (lnn_conv3d_fwd_in_lrelu)
                     self._probed("fwd", item, lambda: nat.call(
                         "lnn_conv3d_fwd_in_lrelu", xin, item.x2, ldx, item.x.C if item.x2 is not None else 0,
                         self._wp(item.wp_fwd), self.pview(item.b), item.y, N, D, H, W, item.cin_k, C, item.stride, IN_EPS, mean, rstd,
@@ -807,8 +807,8 @@ class UNetEngine:
                 elif (self.fuse_in_bwd_reduce and item.x_block is not None and item.stride == 1 and item.gx2 is None and item.iso
                       and not item.gx_accumulate and not self.numeric_conv_bias_grad and item.x_block.z.V <= self.small_v
                       and not item.x_block.first):
-                    # the lowest levels: dL/dz of the stage's first block is consumed from the data gradient's split-K slices by that
-                    # block's WHOLE normalisation backward, one launch (lnn_conv3d_dgrad_in_bwd); its turn in the loop skips the pass
+                    # the lowest levels: the WHOLE normalisation backward of the stage's first block (reduce, sums, apply) is one launch
+                    # behind the data gradient that produces its dL/dz (lnn_conv3d_dgrad_in_bwd); its turn in the loop skips the pass
                     xb = item.x_block
                     self._probed("dgrad", item, lambda: nat.call(
                         "lnn_conv3d_dgrad_in_bwd", item.y, K, self._wp(item.wp_dgrad), item.gx, item.gx.ld,

@@ -1,7 +1,6 @@
 """One-launch normalisation of the small volumes (-m gpu): lnn_conv3d_fwd_in_lrelu / lnn_conv3d_dgrad_in_bwd (csrc/norm_act.hip
 in_small_*_kernel behind csrc/igemm_conv.hip) with the library's DEFAULT kernel selection -- at the bench shapes of the two lowest
-levels the convolutions in front are the macro-tile kernel and the flattened-voxel kernels, both splitting their contraction over an
-fp32 workspace whose slices the normalisation kernel adds itself.  Reference ops: nn.Conv3d -> nn.InstanceNorm3d(eps 1e-5, affine) ->
+levels the convolutions in front are the macro-tile kernel and the flattened-voxel kernels, with and without their split-K workspace.  Reference ops: nn.Conv3d -> nn.InstanceNorm3d(eps 1e-5, affine) ->
 nn.LeakyReLU(1e-2) (ConvDropoutNormNonlin, test/network_architecture/test_MultiHead_Module.py:394-415) and their autograd, CPU fp32."""
 import pytest
 import torch
@@ -22,8 +21,7 @@ SMALL_BLOCKS = [(320, 320, 10, 12, 10, 1, 0), (640, 320, 10, 12, 10, 1, 1), (320
 def test_small_volume_block_forward_in_one_call(C, K, D, H, W, s, cat, ws_on):
     """lnn_conv3d_fwd_in_lrelu (the lowest levels at bench shapes N = 2 -- 320 -> 320 and 640 -> 320 cat @ 10x12x10, 320 -> 320 @ 5x6x5,
     the strided 256 -> 320 and 320 -> 320 -- ragged toy shapes, and a 2048-voxel block at the limit) == lnn_conv3d_fwd_in_stats +
-    lnn_instnorm_lrelu_fwd: y bit for bit (the normalisation kernel adds the split-K slices in the finalize kernel's order), mean /
-    rstd to fp32 summation order, z to one fp16 ulp; and z against conv3d -> instance_norm -> leaky_relu on the CPU in fp32."""
+    lnn_instnorm_lrelu_fwd: y bit for bit, mean / rstd to fp32 summation order, z to one fp16 ulp; and z against conv3d -> instance_norm -> leaky_relu on the CPU in fp32."""
     N = 2
     g = torch.Generator().manual_seed(C + K + D)
     x = q16(torch.randn(N, C, D, H, W, generator=g) * 0.7)
@@ -69,7 +67,7 @@ def test_small_volume_block_forward_in_one_call(C, K, D, H, W, s, cat, ws_on):
 @pytest.mark.parametrize("C,D,H,W", [(320, 10, 12, 10), (320, 5, 6, 5), (48, 3, 9, 10), (24, 12, 13, 13), (32, 16, 16, 8)])
 def test_small_volume_block_backward_in_one_call(C, D, H, W, ws_on):
     """lnn_conv3d_dgrad_in_bwd: the data gradient of a stride-1 convolution + the WHOLE InstanceNorm / LeakyReLU backward of the block
-    that produced its input, dL/dz consumed from the split-K slices where the data gradient splits (never written then).  Against
+    that produced its input (reduce, sums and apply as one launch).  Against
     autograd on the CPU in fp32: dL/du in place over u, the affine gradients (added to what is there, unscaled by grad_unscale), the
     (sample, channel) sums; and against the multi-launch passes on the same inputs (lnn_instnorm_lrelu_bwd takes the one-launch
     kernel on these volumes too: both routes, with and without the fp32 workspace, agree to an fp16 ulp)."""
@@ -105,8 +103,9 @@ def test_small_volume_block_backward_in_one_call(C, D, H, W, ws_on):
         else:
             nat.call("lnn_conv3d_dgrad_ws", dyb, K, wp, dx, C, N, D, H, W, C, K, 1, 0, sk, skn)
             nat.call("lnn_instnorm_lrelu_bwd", ub, dx, C, N, V, C, mean, rstd, ga, be, 0.01, dg, db, None, 0.5, ws)
-        res.append((ub, ws[:N * C * 3].view(N * C, 3)[:, :2].clone(), dg, db))
-    (u0, s0, dg0, db0), (u1, s1, dg1, db1) = res
+        res.append((ub, ws[:N * C * 3].view(N * C, 3)[:, :2].clone(), dg, db, dx))
+    (u0, s0, dg0, db0, dx0), (u1, s1, dg1, db1, dx1) = res
+    assert torch.equal(dx0, dx1)                                   # dL/dz of the data gradient, both routes
     us = float(u0.float().abs().max())
     assert float((u0.float() - u1.float()).abs().max()) <= 1e-3 * us
     scale = s0.abs().max(0).values

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call G: one-launch small-volume normalisation after the load restructuring (parity, isolated timing, step A/B, kernel
+# round 6, call G / H: one-launch small-volume normalisation (parity, isolated timing, step A/B, kernel trace), column bands in the
 # trace), column bands in the macro-tile kernel + z-streaming kernel from 16 planes (parity, prostate-shaped plan)
 TAG=${1:-r6g}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """Isolated timing of one ConvDropoutNormNonlin block of the two lowest levels, forward and backward, as ONE call per direction
-(lnn_conv3d_fwd_in_lrelu / lnn_conv3d_dgrad_in_bwd: conv -> one normalisation launch that adds the split-K slices itself) against
-the multi-launch sequence (conv -> split-K finalize -> statistics -> finalize -> normalise / data gradient -> finalize -> reduce ->
-sums -> apply).  The multi-launch arm needs LNN_IN_SMALL=0 in the environment (the library reads the switch once), so run it twice:
+(lnn_conv3d_fwd_in_lrelu / lnn_conv3d_dgrad_in_bwd: conv [-> split-K finalize] -> ONE normalisation launch) against the multi-launch
+sequence (conv [-> split-K finalize] -> statistics -> finalize -> normalise / data gradient [-> finalize] -> reduce -> sums -> apply).  The multi-launch arm needs LNN_IN_SMALL=0 in the environment (the library reads the switch once), so run it twice:
     LNN_IN_SMALL=0 python tools/kbench_small.py ; python tools/kbench_small.py"""
 import os
 import sys
