@@ -35,6 +35,11 @@ struct ConvParams {
     int red_ld = 0;
     const float *red_mean = nullptr, *red_rstd = nullptr, *red_gamma = nullptr, *red_beta = nullptr;
     float red_slope = 0.f;
+    // z-streaming kernel with explicit axis strides (igemm_conv_v9.hip, GS instances: the permuted-axes walk of a [1,3,3] convolution):
+    // element strides of the {walk, footprint-row, footprint-column} axes and of a sample, bytes a plane descriptor may span
+    int gs_in[3] = {0, 0, 0}, gs_out[3] = {0, 0, 0};
+    long gs_in_n = 0, gs_out_n = 0;
+    unsigned gs_nrec_in = 0, gs_nrec_out = 0;
     int ksplit = 1;               // macro-tile kernel: the 16-channel chunk range is split over ksplit blocks which write fp32 partial
     float* scratch = nullptr;     //   sums to scratch[part][voxel][Mpad]; lnn_launch_splitk_finalize adds the slices and converts
     unsigned long long* dbg;   // optional phase-cycle accumulators (LNN_DEBUG_PHASES), null in production
@@ -68,6 +73,9 @@ int lnn_launch_in_stats_finalize(hipStream_t s, const float* pws, int nslots, in
 int lnn_launch_in_bwd_sums_raw(hipStream_t s, const float* pws, int nslots, int N, int C, const float* mean, const float* rstd,
                                double* ws, float* dgamma, float* dbeta, float unscale);
 int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name);
+// [1,3,3] stride-1 convolution forward / data gradient on the z-streaming kernel with permuted axes (walk along H); -1 = not covered
+int lnn_conv_k133_on_v9(hipStream_t s, const void* x, int ld_x, const void* wp, const float* bias, void* y, int ld_y, int N, int D, int H,
+                        int W, int C, int M, int flip, const char* name);
 // macro-tile kernel with in-block split-K over the taps (igemm_conv_mt.hip): the deep levels (>= 128 channels, short volumes)
 bool lnn_conv_s1_mt_supported(const ConvParams& p);
 double lnn_conv_s1_mt_efficiency(const ConvParams& p);

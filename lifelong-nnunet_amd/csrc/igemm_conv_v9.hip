@@ -124,10 +124,19 @@ struct V9Launch {
 // stores 8 consecutive channels): +2.5 % on the data gradient against a 0.145 ms reduce pass; the 64-channel variant (8 bytes per
 // lane by two 4-byte direct loads, 32 cache lines each) cost the kernel +28 % -- as much as the pass it removes -- and was dropped
 // (profiles/r04_fused_in_bwd_reduce.txt).
-template <int NCK_, int NMB_, int NF_, int EPI>
+// KY = 1, GS (round 6): a [1,3,3] convolution (the first stages of anisotropic plans, nnUNetTrainerMultiHead.py:348-369) as the SAME
+// column walk with permuted axes: the walk runs along H (the three ky taps are the three rolling accumulators), the footprint spans
+// (D, W), and of the nine in-plane shifts only the three of the centre row exist (the kernel has extent 1 along D): 3 fragment reads
+// feed 9 MFMAs per plane, 9 resident weight fragments.  GS = the tensor axes come with explicit element strides (p.gs_*) instead of
+// the dense (D, H, W) order; p.Di / Hi / Wi (and Do / Ho / Wo, Ld / Lh / Lw) are then the extents of the WALK, footprint-row and
+// footprint-column axes.  The dense 3x3x3 instances (KY = 3, GS = false) are compiled from the same text and unchanged.
+template <int NCK_, int NMB_, int NF_, int EPI, int KY = 3, bool GS = false>
 __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvParams p, const V9Launch q) {
     using K = V9<NCK_, NMB_, NF_>;
     constexpr bool STATS = EPI == 1, RED = EPI == 2;
+    static_assert(KY == 3 || KY == 1, "in-plane rows of the kernel");
+    static_assert(!(RED && (GS || KY != 3)), "the fused reduce exists for the dense 3x3x3 data gradient only");
+    constexpr int I0 = KY == 3 ? 0 : 3, NI = 3 * KY;          // in-plane shifts i = dy * 3 + dx that exist: [I0, I0 + NI)
     constexpr int NCK = K::NCK, NMB = K::NMB, NFX = K::NFX, PXS = K::PXS, PY = K::PY, PX = K::PX;
     constexpr int GSLAB = K::GSLAB, PLANE = K::PLANE, DPW = K::DPW, D = K::D, R = K::R, QN = K::QN, EXB = K::EXB, NFIN = K::NFIN;
     static_assert(!RED || NCK == 2, "fused normalisation-backward reduce: every wave finalises 8 consecutive channels per lane");
@@ -179,11 +188,14 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         const int cabs = 32 * gg;
         const bool part2 = cabs >= p.csplit;
         gten[k] = part2 ? p.x2 : p.x;
-        drel[k] = (((py - 1) * p.Wi + (pxs - 1)) * p.ld_x + (part2 ? cabs - p.csplit : cabs) + (pc ^ key) * 8) * 2;
-        dpk[k] = (py < PY && pxs < PX) ? (py | (pxs << 8)) : -1;
+        if constexpr (GS) drel[k] = ((py - 1) * p.gs_in[1] + (pxs - 1) * p.gs_in[2] + (part2 ? cabs - p.csplit : cabs) + (pc ^ key) * 8) * 2;
+        else drel[k] = (((py - 1) * p.Wi + (pxs - 1)) * p.ld_x + (part2 ? cabs - p.csplit : cabs) + (pc ^ key) * 8) * 2;
+        // KY == 1: the halo rows of the footprint are never read -> not fetched (zeros land, no traffic)
+        dpk[k] = (py < PY && pxs < PX && (KY == 3 || (py >= 1 && py < PY - 1))) ? (py | (pxs << 8)) : -1;
     }
-    const unsigned in_plane_bytes = (unsigned)p.Hi * p.Wi * p.ld_x * 2u;
-    const unsigned out_plane_bytes = (unsigned)p.Ho * p.Wo * p.ld_y * 2u;
+    // GS: a plane's lanes reach across the whole sample (their offsets are checked lane by lane above / below)
+    const unsigned in_plane_bytes = GS ? (unsigned)p.gs_nrec_in : (unsigned)p.Hi * p.Wi * p.ld_x * 2u;
+    const unsigned out_plane_bytes = GS ? (unsigned)p.gs_nrec_out : (unsigned)p.Ho * p.Wo * p.ld_y * 2u;
 
     // ---- partial-sum exchange addresses ------------------------------------------------------------------------------
     // Finalising waves (ck < NFIN; all of them unless NCK = 8) rotate their MFMA rows by 8 QN ck, so their own output
@@ -235,7 +247,8 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             const int row = ((lane & 31) + (fin ? 8 * QN * ck : 0)) & 31;
 #pragma unroll
             for (int tl = 0; tl < 27; ++tl) {
-                const half_t* wp = p.wp + lnn_panel_off(p.taps.slot[tl], m0, 16 * ck, 27, p.KCpad);
+                if (KY == 1 && (tl % 9) / 3 != 1) continue;           // (compile time after unrolling: 9 resident fragments)
+                const half_t* wp = p.wp + lnn_panel_off(p.taps.slot[tl], m0, 16 * ck, KY == 3 ? 27 : p.wtaps, p.KCpad);
                 A[tl] = *reinterpret_cast<const half8*>(wp + row * 16 + hk * 8);
             }
 #pragma unroll
@@ -267,7 +280,8 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             const int py = dpk[k] & 255, pxs = (dpk[k] >> 8) & 255;
             const int iy = y0 - 1 + py, ix = x0 - 1 + pxs;
             const bool ok = dpk[k] >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            dvoff[k] = ok ? drel[k] + (y0 * p.Wi + x0) * p.ld_x * 2 : (int)0x80000000;
+            if constexpr (GS) dvoff[k] = ok ? drel[k] + (y0 * p.gs_in[1] + x0 * p.gs_in[2]) * 2 : (int)0x80000000;
+            else dvoff[k] = ok ? drel[k] + (y0 * p.Wi + x0) * p.ld_x * 2 : (int)0x80000000;
         }
         int svoff, uvoff = 0;
         half_t* yten;
@@ -277,15 +291,16 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             const bool part2 = m0 >= p.msplit;
             yten = part2 ? p.y2 : p.y;
             const int ch = (part2 ? m0 - p.msplit : m0) + (NCK == 2 ? 16 * ck + 8 * hk : 8 * ck + 4 * hk);
-            svoff = ok ? ((oy * p.Wo + ox) * p.ld_y + ch) * 2 : (int)0x80000000;
+            if constexpr (GS) svoff = ok ? (oy * p.gs_out[1] + ox * p.gs_out[2] + ch) * 2 : (int)0x80000000;
+            else svoff = ok ? ((oy * p.Wo + ox) * p.ld_y + ch) * 2 : (int)0x80000000;
             if constexpr (RED) uvoff = ok ? ((oy * p.Wo + ox) * p.red_ld + m0 + 16 * ck + 8 * hk) * 2 : (int)0x80000000;
         }
 
         // running plane pointers / ring offsets (scalar): no multiplications in the plane loop
-        const long in_plane = (long)p.Hi * p.Wi * p.ld_x, out_plane = (long)p.Ho * p.Wo * p.ld_y;
+        const long in_plane = GS ? (long)p.gs_in[0] : (long)p.Hi * p.Wi * p.ld_x, out_plane = GS ? (long)p.gs_out[0] : (long)p.Ho * p.Wo * p.ld_y;
         const half_t* din[DPW];
 #pragma unroll
-        for (int k = 0; k < DPW; ++k) din[k] = gten[k] + ((long)n * p.Di + (zs0 - 1)) * in_plane;
+        for (int k = 0; k < DPW; ++k) din[k] = gten[k] + (GS ? (long)n * p.gs_in_n + (zs0 - 1) * in_plane : ((long)n * p.Di + (zs0 - 1)) * in_plane);
         const int tp_lo = zs0 >= 1 ? 0 : 1;                            // planes tp in [tp_lo, tp_hi) lie inside the volume
         const int tp_hi = min(T, p.Di - (zs0 - 1));
         int dtp = 0, dslot_off = 0, duo = 0;
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
 
         // output plane completed at step tprev (z = zs0 + tprev - 2): own quads + the other chunks' partial sums -> y.
         // Split in two so that the LDS reads are in flight while the first MFMAs of the step issue.
-        half_t* optr = yten + ((long)n * p.Do + (zs0 - 3)) * out_plane;      // plane of tprev = -1
+        half_t* optr = yten + (GS ? (long)n * p.gs_out_n + (zs0 - 3) * out_plane : ((long)n * p.Do + (zs0 - 3)) * out_plane);      // plane of tprev = -1
         floatx4 pv[(NCK - 1) * QN];
         uint4v ur = {0, 0, 0, 0};            // RED: this lane's channels of u at its voxel of the plane being stored
         int ruo = 0;
@@ -416,8 +431,8 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
         for (int tp = 0; tp < D; ++tp) dma();
         wait_vm<(D - 2) * DPT, false>();
         __builtin_amdgcn_s_barrier();
-        b[0] = ldb(0, 0);
-        b[1] = ldb(0, 1);
+        b[0] = ldb(0, I0);
+        b[1] = ldb(0, I0 + 1);
         int ro = 0;
 
         auto step = [&](auto U_, int t) {
@@ -426,14 +441,14 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
             dma();
             const int rn = ro + PLANE == R * PLANE ? 0 : ro + PLANE;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                if (i == 3) fin_store(t - 1);
-                const int ii = i + 2;
-                b[ii % 3] = ii < 9 ? ldb(ro, ii) : ldb(rn, ii - 9);
+            for (int j = 0; j < NI; ++j) {                   // in-plane shift i = I0 + j
+                if (j == NI / 3) fin_store(t - 1);
+                const int jj = j + 2;
+                b[jj % 3] = jj < NI ? ldb(ro, I0 + jj) : ldb(rn, I0 + jj - NI);
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
                     const int a = (U + 1 - dz + 3) % 3;
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[dz * 9 + i], b[i % 3], (i == 0 && dz == 0) ? zero16 : acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[dz * 9 + I0 + j], b[j % 3], (j == 0 && dz == 0) ? zero16 : acc[a], 0, 0, 0);
                 }
             }
             ro = rn;
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void igemm_conv_s1_v9_kernel(const ConvPara
 
 int g_v9_zseg = 0;     // lnn_debug_set_v9_zseg (parity tests): 0 = automatic
 
-template <class K, int EPI>
+template <class K, int EPI, int KY = 3, bool GS = false>
 int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
     const int tiles_y = lnn_cdiv(p.Lh, K::FY), tiles_x = lnn_cdiv(p.Lw, K::FX);
     const int mgroups = p.M / (32 * K::NMB);
@@ -519,13 +534,13 @@ int launch_v9(hipStream_t s, ConvParams& p, int num_cu, const char* name) {
     static_assert(lds <= 160 * 1024, "LDS of a CU");
     static bool attr_set = false;     // per instantiation; idempotent attribute of the code object
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, EPI, KY, GS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     if (EPI != 0) {
         p.stats_nblk = grid * K::NF;          // (every launched block zeroes its own rows)
     }
-    hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, EPI>), dim3(grid), dim3(512), lds, s, p, q);
+    hipLaunchKernelGGL((igemm_conv_s1_v9_kernel<K::NCK, K::NMB, K::NF, EPI, KY, GS>), dim3(grid), dim3(512), lds, s, p, q);
     LNN_CHECK_LAUNCH(name);
     return LNN_OK;
 }
@@ -605,4 +620,58 @@ int lnn_launch_conv_s1_v9(hipStream_t s, ConvParams& p, const char* name) {
     }
     if (p.M % 64 == 0) return launch_v9<V9<4, 2, 1>, 0>(s, p, num_cu, name);
     return launch_v9<V9<4, 1, 2>, 0>(s, p, num_cu, name);
+}
+
+// ---- [1,3,3] stride-1 convolutions on the z-streaming kernel with permuted axes (KY = 1, GS instances) ------------------------------
+// -1 automatic (LNN_CONV_K133_V9=0 forbids), 0 never, 1 wherever supported (parity tests: lnn_debug_set_k133_v9)
+static int g_k133_v9 = -1;
+extern "C" int lnn_debug_set_k133_v9(int mode) {
+    LNN_REQUIRE(mode >= -1 && mode <= 1, "lnn_debug_set_k133_v9: %d is not one of -1, 0, 1", mode);
+    g_k133_v9 = mode;
+    return LNN_OK;
+}
+static int g_k133_last = 0;
+extern "C" int lnn_debug_last_k133_on_v9(void) { return g_k133_last; }
+
+// x: gathered tensor (C channels, channel stride ld_x), y: output (M channels, ld_y), both (N, D, H, W, ld) channels-last; wp: panel of
+// 9 tap slots [ky][kx]; flip = 0 forward (tap offset (ky, kx) uses slot ky * 3 + kx), 1 data gradient (offset (ky', kx') uses slot
+// (2 - ky') * 3 + (2 - kx')).  Returns LNN_OK after launching, -1 when the shape is not covered (the caller runs the generic kernel).
+int lnn_conv_k133_on_v9(hipStream_t s, const void* x, int ld_x, const void* wp, const float* bias, void* y, int ld_y, int N, int D, int H,
+                        int W, int C, int M, int flip, const char* name) {
+    g_k133_last = 0;
+    if (g_k133_v9 == 0) return -1;
+    if (g_k133_v9 < 0) {
+        static int env = -1;
+        if (env < 0) { const char* e = getenv("LNN_CONV_K133_V9"); env = (e && e[0] == '0') ? 0 : 1; }
+        // the walk runs along H: short walks (and tiny planes) stay on the flattened-voxel kernel
+        if (!env || H < 32 || (long)D * W < 256) return -1;
+    }
+    if (C != 32 && C != 64 && C != 128) return -1;
+    if (M % 32 != 0 || ld_x % 8 != 0 || ld_y % 8 != 0 || ld_x < C || ld_y < M) return -1;
+    if (!x || !y || !wp || !lnn_aligned16(x) || !lnn_aligned16(y) || !lnn_aligned16(wp)) return -1;
+    const double in_bytes = (double)D * H * W * ld_x * 2.0, out_bytes = (double)D * H * W * ld_y * 2.0;
+    if (in_bytes >= 2147483648.0 || out_bytes >= 2147483648.0) return -1;
+    ConvParams p{};
+    p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.bias = bias; p.y = (half_t*)y;
+    p.ld_x = ld_x; p.ld_y = ld_y; p.N = N;
+    // walk axis = H, footprint rows = D, footprint columns = W
+    p.Di = p.Do = p.Ld = H; p.Hi = p.Ho = p.Lh = D; p.Wi = p.Wo = p.Lw = W;
+    p.C = C; p.M = M; p.Mpad = lnn_round_up(M, 32); p.KCpad = lnn_round_up(C, 16); p.wtaps = 9;
+    p.os = 1; p.pad_lo = 1; p.accumulate = 0; p.dbg = nullptr;
+    p.taps.ntaps = 27;
+    for (int t = 0; t < 27; ++t) {
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;       // the walk's (plane, row, column) shift = (ky, kz, kx) of the conv
+        p.taps.pos_off[t] = 0;
+        p.taps.slot[t] = (unsigned char)(dy != 1 ? 0 : (flip ? (2 - dz) * 3 + (2 - dx) : dz * 3 + dx));
+    }
+    p.gs_in[0] = W * ld_x; p.gs_in[1] = H * W * ld_x; p.gs_in[2] = ld_x; p.gs_in_n = (long)D * H * W * ld_x;
+    p.gs_out[0] = W * ld_y; p.gs_out[1] = H * W * ld_y; p.gs_out[2] = ld_y; p.gs_out_n = (long)D * H * W * ld_y;
+    p.gs_nrec_in = (unsigned)in_bytes; p.gs_nrec_out = (unsigned)out_bytes;
+    const int num_cu = v9_num_cu();
+    int rc;
+    if (C == 128) rc = launch_v9<V9<8, 1, 1>, 0, 1, true>(s, p, num_cu, name);
+    else if (C == 32) rc = M % 64 == 0 ? launch_v9<V9<2, 2, 2>, 0, 1, true>(s, p, num_cu, name) : launch_v9<V9<2, 1, 4>, 0, 1, true>(s, p, num_cu, name);
+    else rc = M % 64 == 0 ? launch_v9<V9<4, 2, 1>, 0, 1, true>(s, p, num_cu, name) : launch_v9<V9<4, 1, 2>, 0, 1, true>(s, p, num_cu, name);
+    if (rc == LNN_OK) g_k133_last = 1;
+    return rc;
 }

@@ -508,6 +508,11 @@ int lnn_gen_conv3d_fwd(hipStream_t s, const void* x, int ld_x, const void* wp, c
     if (int e = gen_check_act(y, ld_y, K, "lnn_conv3d_fwd_g(y)")) return e;
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_conv3d_fwd_g: weight panel null/misaligned");
     LNN_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0, "lnn_conv3d_fwd_g: bad dims");
+    if (k[0] == 1 && k[1] == 3 && k[2] == 3 && st[0] == 1 && st[1] == 1 && st[2] == 1) {
+        // the first stages of anisotropic plans: the z-streaming kernel walks H with the ky taps as its rolling accumulators
+        const int rc = lnn_conv_k133_on_v9(s, x, ld_x, wp, bias, y, ld_y, N, Di, Hi, Wi, C, K, 0, "lnn_conv3d_fwd_g(k133,v9)");
+        if (rc >= 0) return rc;
+    }
     GenParams p{};
     p.x = (const half_t*)x; p.wp = (const half_t*)wp; p.bias = bias; p.y = (half_t*)y; p.ld_x = ld_x; p.ld_y = ld_y;
     p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi;
@@ -523,6 +528,10 @@ int lnn_gen_conv3d_dgrad(hipStream_t s, const void* dy, int ld_dy, const void* w
     if (int e = gen_check_act(dy, ld_dy, K, "lnn_conv3d_dgrad_g(dy)")) return e;
     if (int e = gen_check_act(dx, ld_dx, C, "lnn_conv3d_dgrad_g(dx)")) return e;
     LNN_REQUIRE(wp != nullptr && lnn_aligned16(wp), "lnn_conv3d_dgrad_g: weight panel null/misaligned");
+    if (k[0] == 1 && k[1] == 3 && k[2] == 3 && st[0] == 1 && st[1] == 1 && st[2] == 1 && !accumulate) {
+        const int rc = lnn_conv_k133_on_v9(s, dy, ld_dy, wp, nullptr, dx, ld_dx, N, Di, Hi, Wi, K, C, 1, "lnn_conv3d_dgrad_g(k133,v9)");
+        if (rc >= 0) return rc;
+    }
     GenParams p{};
     // roles: gathered input = dy (K channels, the conv's output extents), output = dx (C channels); panel wp[slot][C][K]
     p.x = (const half_t*)dy; p.wp = (const half_t*)wp; p.y = (half_t*)dx; p.ld_x = ld_dy; p.ld_y = ld_dx;

@@ -26,6 +26,12 @@ int lnn_debug_force_down2_kernel(int which);
 /* Parity tests only: number of z segments the v9 kernel cuts a column into (0 = automatic).  Process-wide. */
 int lnn_debug_set_v9_zseg(int segments);
 
+/* Parity tests only: [1,3,3] stride-1 convolutions (lnn_conv3d_fwd_g / lnn_conv3d_dgrad_g) on the z-streaming kernel with permuted
+ * axes: -1 automatic (32 / 64 / 128 gathered channels, H >= 32), 0 never (the flattened-voxel kernel), 1 wherever the kernel supports
+ * the shape; lnn_debug_last_k133_on_v9: 1 when the last such call ran on the z-streaming kernel.  Process-wide. */
+int lnn_debug_set_k133_v9(int mode);
+int lnn_debug_last_k133_on_v9(void);
+
 /* Parity tests only: the isotropic entry points hand small volumes (<= 4096 output voxels) to the generic flattened-voxel
  * kernels of igemm_gen.hip; -1 = that automatic rule, 0 = never (pins the specialised kernels on the tests' small shapes),
  * 1 = every layer the generic kernels support.  Process-wide. */

@@ -111,6 +111,8 @@ SIGNATURES = {
     "lnn_debug_force_conv_kernel": (_i, [_i]),
     "lnn_debug_force_down2_kernel": (_i, [_i]),
     "lnn_debug_set_v9_zseg": (_i, [_i]),
+    "lnn_debug_set_k133_v9": (_i, [_i]),
+    "lnn_debug_last_k133_on_v9": (_i, []),
     "lnn_debug_set_gen_mode": (_i, [_i]),
     "lnn_debug_last_dgrad_reduce_fused": (_i, []),
     "lnn_debug_set_cu_budget": (_i, [_i]),

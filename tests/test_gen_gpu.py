@@ -204,3 +204,54 @@ def test_isotropic_convT_entries_on_the_generic_kernels(gen_forced, N, C, K, D, 
     panel2 = torch.zeros_like(panel)
     nat.call("lnn_convT3d_k2s2_wgrad_det", xb, C, dyb, K, panel2, N, D, H, W, C, K, parts, parts.numel())
     assert rel_err(panel2.cpu(), panel.cpu()) < 1e-5
+
+
+K133_CASES = [
+    # N, C, K, D, H, W   (walk along H; footprint rows span D, columns W)
+    (2, 32, 32, 5, 12, 18),         # ragged footprint rows (5 of 8) and columns (18 = 16 + 2), short walk
+    (1, 64, 32, 9, 37, 9),          # the decoder's 64 -> 32: two chunk waves per footprint, odd walk length (z segments)
+    (1, 64, 64, 4, 20, 24),         # 64 output channels per item
+    (2, 32, 64, 7, 9, 33),          # the data-gradient shape of 64 -> 32
+    (1, 128, 96, 6, 16, 10),        # eight chunk waves, three output blocks
+    (1, 32, 32, 20, 40, 48),        # a slab of the Prostate-shaped top level
+]
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W", K133_CASES)
+def test_k133_conv_on_the_z_streaming_kernel(N, C, K, D, H, W):
+    """[1,3,3] stride-1 convolutions (the first stages of anisotropic plans, nnUNetTrainerMultiHead.py:348-369) on the z-streaming kernel
+    with permuted axes (igemm_conv_v9.hip KY = 1: the walk runs along H, the three ky taps are its rolling accumulators), forced through
+    lnn_debug_set_k133_v9(1): forward with bias and data gradient against torch's CPU fp32 ops, channel-padded tensors untouched
+    outside their channels, and bit-equal to nothing else -- the flattened-voxel kernel (mode 0) must agree to fp16 rounding."""
+    k, st = (1, 3, 3), (1, 1, 1)
+    x = _rand((N, C, D, H, W), 1).requires_grad_(True)
+    w = _rand((K, C) + k, 2, 0.1)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3))
+    ref = F.conv3d(x, w, b, stride=st, padding=(0, 1, 1))
+    dy = _rand(ref.shape, 4)
+    ref.backward(dy)
+    xb, _ = to_cl_h(x.detach(), ld=C + 8, offset=8)
+    dyb, _ = to_cl_h(dy)
+    wpf = pack(w.to(DEV), 9, K, C, C * 9, 9, 1)
+    wpd = pack(w.to(DEV), 9, C, K, 9, C * 9, 1)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            assert nat.lib().lnn_debug_set_k133_v9(mode) == 0
+            yb = torch.full((N, D, H, W, K + 16), 7.0, dtype=torch.float16, device=DEV)
+            nat.call("lnn_conv3d_fwd_g", View(xb, 8), C + 8, wpf, b.to(DEV), View(yb, 16), K + 16, N, D, H, W, C, K, *k, *st, None, 0)
+            assert nat.lib().lnn_debug_last_k133_on_v9() == mode
+            dxb = torch.full((N, D, H, W, C + 8), 5.0, dtype=torch.float16, device=DEV)
+            nat.call("lnn_conv3d_dgrad_g", dyb, K, wpd, dxb, C + 8, N, D, H, W, C, K, *k, *st, 0, None, 0)
+            # (the data gradient gathers the K channels of dy: 96 is not one of the kernel's 32 / 64 / 128 -> the flattened-voxel kernel)
+            assert nat.lib().lnn_debug_last_k133_on_v9() == (mode if K in (32, 64, 128) else 0)
+            outs[mode] = (yb, dxb)
+    finally:
+        nat.lib().lnn_debug_set_k133_v9(-1)
+    for mode in (1, 0):
+        yb, dxb = outs[mode]
+        assert rel_err(from_cl_h(yb, K, 16), ref) < 2e-3, mode
+        assert torch.all(yb[..., :16] == 7.0)
+        assert rel_err(from_cl_h(dxb, C), x.grad) < 3e-3, mode
+        assert torch.all(dxb[..., C:] == 5.0)
+    assert rel_err(from_cl_h(outs[1][0], K, 16), from_cl_h(outs[0][0], K, 16)) < 2e-3

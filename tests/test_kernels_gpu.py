@@ -283,7 +283,10 @@ def test_first_layer_wgrad_with_folded_norm_backward(N, K, D, H, W):
     pf = torch.zeros_like(p_u)
     nat.call("lnn_conv3d_wgrad_c1_in_bwd", xb, y_f, dzb, K + 8, pf, N, D, H, W, K, mean, rstd, ga, be, 0.01, ws, None, 0)
     assert torch.equal(y_f, yb)
-    assert torch.equal(dg, dg_u) and torch.equal(db, db_u)
+    if V > nat.query("lnn_instnorm_small_volume"):
+        assert torch.equal(dg, dg_u) and torch.equal(db, db_u)
+    else:       # lnn_instnorm_lrelu_bwd is ONE launch on such volumes (csrc/norm_act.hip in_small_bwd_kernel): another summation order
+        assert rel_err(dg.cpu(), dg_u.cpu()) < 1e-5 and rel_err(db.cpu(), db_u.cpu()) < 1e-5
     dw_u = torch.zeros((K, 1, 3, 3, 3), device=DEV); dw_f = torch.zeros_like(dw_u)
     nat.call("lnn_unpack_wgrad", p_u, dw_u, 1, K, 27, 27, 1, 0, 1.0, 0)
     nat.call("lnn_unpack_wgrad", pf, dw_f, 1, K, 27, 27, 1, 0, 1.0, 0)
