@@ -94,6 +94,7 @@ class ConvBlock:
     panel: int = 0
     in_dims: tuple = ()
     x_block: object = None         # the ConvBlock whose output IS this block's only input (second block of a stage): its gz = gx
+    wgrad_333: bool = False        # [1,3,3] stride-1 block whose weight gradient is taken as the kz = 1 slice of a 3x3x3 weight gradient
 
     @property
     def iso(self):
@@ -366,7 +367,14 @@ class UNetEngine:
                 else:
                     item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", nt, item.cout, item.cin)
                     item.wp_dgrad = wp_off; wp_off += nat.query("lnn_packed_weight_elems", nt, item.cin, item.cout)
-                    item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", nt, item.cout, item.cin)
+                    # The weight gradient of a [1,3,3] stride-1 convolution IS the kz = 1 slice of the 3x3x3 weight gradient of the same
+                    # tensors (dW[kz = 1, ky, kx] = sum_v dy[v] x[v + (0, ky - 1, kx - 1)]): the stride-1 tile kernel (~1000 TFLOP/s,
+                    # two thirds of it on taps nobody reads) beats the flattened-voxel kernel (204-234 TFLOP/s) on the first stages of
+                    # an anisotropic plan; fp32 panels are tap-major, so the 9 wanted taps are one contiguous run of a 27-tap panel.
+                    # LNN_K133_WGRAD_333=0: the generic-geometry weight gradient (A/B switch)
+                    item.wgrad_333 = (item.kernel == (1, 3, 3) and item.strides == (1, 1, 1) and item.cin_k % 8 == 0
+                                      and os.environ.get("LNN_K133_WGRAD_333", "1") != "0")
+                    item.panel = pn_off; pn_off += nat.query("lnn_wgrad_panel_elems", 27 if item.wgrad_333 else nt, item.cout, item.cin)
             elif isinstance(item, UpBlock):
                 nt = item.ntaps
                 item.wp_fwd = wp_off; wp_off += nat.query("lnn_packed_weight_elems", nt, item.cout, item.cin)
@@ -400,7 +408,7 @@ class UNetEngine:
                 else:
                     add_pack(item.w, item.wp_fwd, nt, K, C, C * nt, nt, 1)
                     add_pack(item.w, item.wp_dgrad, nt, C, K, nt, C * nt, 1)
-                    add_unpack(item.w, item.panel, nt, K, C, C * nt, nt, 1)
+                    add_unpack(item.w, self._panel_live(item), nt, K, C, C * nt, nt, 1)
             elif isinstance(item, UpBlock):
                 C, K, nt = item.cin, item.cout, item.ntaps
                 add_pack(item.w, item.wp_fwd, nt, K, C, nt, K * nt, 1)
@@ -503,6 +511,14 @@ class UNetEngine:
         if v is None:
             v = self._pviews[key] = a[slot.offset:slot.offset + slot.numel].view(slot.shape)
         return v
+
+    @staticmethod
+    def _panel_live(item):
+        """Offset (in floats) of the taps of ``item``'s weight-gradient panel that are folded into the gradient: the whole panel, or
+        the kz = 1 run of the 27-tap panel a [1,3,3] block computes (see ``wgrad_333``)."""
+        if getattr(item, "wgrad_333", False):
+            return item.panel + 9 * (-(-item.cout // 32) * 32) * (-(-item.cin // 32) * 32)
+        return item.panel
 
     def _wp(self, off):
         return _Ptr(self.wpanels, off)
@@ -696,7 +712,7 @@ class UNetEngine:
                 if item.cin_k == 1:
                     nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, 1, K, 27, 27, 1, 0, 1.0, 1)
                 else:
-                    nat.call("lnn_unpack_wgrad", self._pn(item.panel), gw, nt, K, C, C * nt, nt, 1, 1.0, 1)
+                    nat.call("lnn_unpack_wgrad", self._pn(self._panel_live(item)), gw, nt, K, C, C * nt, nt, 1, 1.0, 1)
             else:
                 C, K = item.cin, item.cout
                 nat.call("lnn_unpack_wgrad", self._pn(item.panel), self.pview(item.w, self.grad), nt, C, K, K * nt, nt, 1, 1.0, 1)
@@ -781,7 +797,13 @@ class UNetEngine:
 
                 def conv_wgrad_call(item, xin, ldx, K, C, D, H, W):
                     det = self._det_scratch()
-                    if not item.iso:
+                    if item.wgrad_333:
+                        # the 27-tap panel of this block; only its taps 9..17 (kz = 1) are folded into the gradient
+                        if det is not None:
+                            nat.call("lnn_conv3d_wgrad_det", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K, 1, det, det.numel())
+                        else:
+                            nat.call("lnn_conv3d_wgrad", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K, 1)
+                    elif not item.iso:
                         nat.call("lnn_conv3d_wgrad_g", xin, ldx, item.y, K, self._pn(item.panel), N, D, H, W, C, K,
                                  *item.kernel, *item.strides, det, 0 if det is None else det.numel())
                     elif item.x2 is not None and det is not None:

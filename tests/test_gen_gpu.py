@@ -255,3 +255,29 @@ def test_k133_conv_on_the_z_streaming_kernel(N, C, K, D, H, W):
         assert rel_err(from_cl_h(dxb, C), x.grad) < 3e-3, mode
         assert torch.all(dxb[..., C:] == 5.0)
     assert rel_err(from_cl_h(outs[1][0], K, 16), from_cl_h(outs[0][0], K, 16)) < 2e-3
+
+
+@pytest.mark.parametrize("N,C,K,D,H,W", [(2, 32, 32, 5, 12, 18), (1, 64, 32, 9, 20, 9), (1, 16, 32, 4, 9, 24)])
+def test_k133_weight_gradient_is_the_centre_slice_of_the_333_weight_gradient(N, C, K, D, H, W):
+    """engine.ConvBlock.wgrad_333: dW of a [1,3,3] stride-1 convolution = taps 9..17 (kz = 1) of the 3x3x3 stride-1 weight gradient of
+    the same x / dy (lnn_conv3d_wgrad, tap-major fp32 panel), unpacked as a 9-tap panel; against autograd on the CPU in fp32 and against
+    lnn_conv3d_wgrad_g."""
+    x = _rand((N, C, D, H, W), 1)
+    w = _rand((K, C, 1, 3, 3), 2, 0.1).requires_grad_(True)
+    y = F.conv3d(x, w, None, padding=(0, 1, 1))
+    dy = _rand(y.shape, 4)
+    y.backward(dy)
+    xb, _ = to_cl_h(x)
+    dyb, _ = to_cl_h(dy)
+    p27 = torch.zeros(nat.query("lnn_wgrad_panel_elems", 27, K, C), device=DEV)
+    nat.call("lnn_conv3d_wgrad", xb, C, dyb, K, p27, N, D, H, W, C, K, 1)
+    mp, cp = -(-K // 32) * 32, -(-C // 32) * 32
+    assert nat.query("lnn_wgrad_panel_elems", 9, K, C) == 9 * mp * cp
+    dw = torch.zeros((K, C, 1, 3, 3), device=DEV)
+    nat.call("lnn_unpack_wgrad", View(p27, 9 * mp * cp), dw, 9, K, C, C * 9, 9, 1, 1.0, 0)
+    assert rel_err(dw.cpu(), w.grad) < 2e-3
+    p9 = torch.zeros(9 * mp * cp, device=DEV)
+    nat.call("lnn_conv3d_wgrad_g", xb, C, dyb, K, p9, N, D, H, W, C, K, 1, 3, 3, 1, 1, 1, None, 0)
+    dg = torch.zeros_like(dw)
+    nat.call("lnn_unpack_wgrad", p9, dg, 9, K, C, C * 9, 9, 1, 1.0, 0)
+    assert rel_err(dw.cpu(), dg.cpu()) < 1e-3
