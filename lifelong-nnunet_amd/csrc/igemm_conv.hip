@@ -187,7 +187,9 @@ bool use_v9(const ConvParams& p) {
     // automatic: not on short z columns (the column walk has ~4 plane steps of fixed cost per item).  16 since round 6: on the
     // 20-plane levels of a Task005_Prostate-shaped plan (64 / 128 channels @ 20x160x128 / 20x80x64) the z-streaming kernel runs
     // 780-1020 TFLOP/s where the tile kernel ran 420-700 (step 19.26 -> 17.64 ms, gpurun_out/r6f)
-    return p.Ld >= 16;
+    static int min_planes = 0;
+    if (!min_planes) { const char* e = getenv("LNN_CONV_V9_MIN_PLANES"); min_planes = e && atoi(e) > 0 ? atoi(e) : 16; }
+    return p.Ld >= min_planes;
 }
 
 // stride-2 conv forward: z-streaming kernel (igemm_down2s.hip) for 32 / 64 input channels with >= 16 output planes;

@@ -47,3 +47,8 @@ python tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json 2>&1 | head -6
 python tools/pmc_mfma_clock.py $OUT/pmc_mfma.txt $OUT/pmc_fetch.txt $OUT/pmc_mfma_clock.json 2>&1 | head -16
 timeout 200 python tools/gemm_roof.py > $OUT/library_gemm_roof.txt 2>&1; tail -4 $OUT/library_gemm_roof.txt
 timeout 300 python tools/layer_table.py --steps 6 --workload prostate > $OUT/layer_table_prostate.txt 2> $OUT/layer_table_prostate.err; tail -8 $OUT/layer_table_prostate.txt
+# the z-streaming kernel on 20-plane volumes of a Hippocampus-sized plan (C1: 40x56x40 patches): automatic rule 16 planes vs the old 32
+for mp in 32 16 32 16; do
+  LNN_CONV_V9_MIN_PLANES=$mp timeout 200 python bench.py --workload c1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-extras --other-workloads none > $OUT/bench_c1_minplanes$mp.json 2> $OUT/bench_c1.err
+  python -c "import json;d=json.load(open('$OUT/bench_c1_minplanes$mp.json'));print('c1 LNN_CONV_V9_MIN_PLANES=$mp', round(d['ms_per_step'],3))"
+done
