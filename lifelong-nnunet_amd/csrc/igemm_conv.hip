@@ -208,10 +208,11 @@ bool use_down2s(const ConvParams& p) {
     return p.Ld >= 16;
 }
 
-// Macro-tile kernel with in-block split-K (igemm_conv_mt.hip, round 6): the deep levels -- >= 128 input channels on volumes too short
-// for the z-streaming kernel -- wherever its band geometry fills >= 70 % of its MFMA columns (levels 3 and 4 of the 160x192x160 plan:
-// 1.0 / 0.94; level 5's 5x6x5 volume fills 0.2 of them and is still 5-8 % faster than the retired split-K tile kernel was), and the
-// >= 128-channel layers the z-streaming kernel has no instance for (256 -> 128 @ 40x48x40: 0.296 vs 0.309 ms on the retired v8).
+// Macro-tile kernel with in-block split-K (igemm_conv_mt.hip, round 6): every stride-1 layer with >= 128 input channels that the
+// z-streaming kernel does not take -- the deep levels (its bands fill 1.0 / 0.94 of their MFMA columns on levels 3 / 4 of the
+// 160x192x160 plan; level 5's 5x6x5 volume fills 0.2 of them and is still 5-8 % faster than the retired split-K tile kernel was), the
+// 256-input-channel layers of level 2 (256 -> 128 @ 40x48x40: 0.296 vs 0.309 ms on the retired v8) and, with column bands, the wide
+// 20-plane levels of anisotropic plans (lnn_conv_s1_mt_efficiency reports the fill of a shape).
 // LNN_CONV_MT=1 / 0 forces / forbids it (A/B measurements); lnn_debug_force_conv_kernel(10) forces it wherever supported.
 bool use_mt(const ConvParams& p) {
     if (!lnn_conv_s1_mt_supported(p)) return false;
