@@ -214,6 +214,8 @@ K133_CASES = [
     (2, 32, 64, 7, 9, 33),          # the data-gradient shape of 64 -> 32
     (1, 128, 96, 6, 16, 10),        # eight chunk waves, three output blocks
     (1, 32, 32, 20, 40, 48),        # a slab of the Prostate-shaped top level
+    (1, 32, 32, 1, 33, 40),         # a single plane (a 2-D image): one live footprint row
+    (3, 64, 64, 3, 18, 5),          # fewer columns than a footprint is wide, three samples
 ]
 
 

@@ -121,3 +121,31 @@ def test_small_volume_entry_refuses_large_volumes():
     ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", 1, 32), dtype=torch.float64, device=DEV)
     with pytest.raises(RuntimeError, match="voxels per sample"):
         nat.call("lnn_conv3d_dgrad_in_bwd", x, 32, x, x, 32, 1, 16, 16, 16, 32, 32, x, f, f, f, f, 0.01, f, f, 1.0, ws, None, 0)
+
+
+@pytest.mark.parametrize("N,C,D,H,W", [(3, 8, 2, 2, 2), (1, 40, 1, 1, 7), (3, 72, 4, 16, 32), (2, 320, 5, 6, 5)])
+def test_small_volume_norm_backward_odd_shapes(N, C, D, H, W):
+    """lnn_instnorm_lrelu_bwd on volumes up to lnn_instnorm_small_volume() (one launch: csrc/norm_act.hip in_small_bwd_kernel) with
+    channel counts that are not multiples of 32 (idle octet lanes), 8 voxels, exactly 2048 voxels, three samples (dgamma / dbeta are an
+    ordered sum over the samples): against autograd through leaky_relu(instance_norm(u)) on the CPU in fp32."""
+    g = torch.Generator().manual_seed(N * C + W)
+    u = q16(torch.randn(N, C, D, H, W, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)); gamma[::3] *= -1.0
+    gamma = gamma.requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    z = F.leaky_relu(F.instance_norm(u, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    dz = q16(torch.randn(z.shape, generator=g))
+    z.backward(dz)
+    V = D * H * W
+    assert V <= nat.query("lnn_instnorm_small_volume")
+    ub, _ = to_cl_h(u.detach())
+    dzb, _ = to_cl_h(dz, ld=C + 8)
+    mean = torch.empty(N * C, device=DEV); rstd = torch.empty(N * C, device=DEV)
+    ws = torch.zeros(nat.query("lnn_instnorm_ws_doubles", N, C), dtype=torch.float64, device=DEV)
+    nat.call("lnn_instnorm_stats", ub, N, V, C, 1e-5, mean, rstd, ws)
+    dg = torch.full((C,), 0.5, device=DEV); db = torch.full((C,), -1.0, device=DEV)
+    nat.call("lnn_instnorm_lrelu_bwd", ub, dzb, C + 8, N, V, C, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV), 0.01, dg, db,
+             None, 2.0, ws)
+    tol = 2e-2 if V < 16 else 4e-3          # 8 voxels: the statistics themselves carry the fp16 rounding of u
+    assert rel_err(from_cl_h(ub, C), u.grad) < tol
+    assert rel_err(dg.cpu() - 0.5, 2.0 * gamma.grad) < tol and rel_err(db.cpu() + 1.0, 2.0 * beta.grad) < tol
