@@ -40,14 +40,24 @@ class Cfg:
         s.EXB = NF * NMB * s.NFIN * (NCK - 1) * s.QN * 1024
 
 
-def emulate(cfg, x, w, bias, S=1, flip=False):
-    """x (N,C,D,H,W), w (M,C,3,3,3) -> y (N,M,D,H,W) the way the kernel computes it (fp32 math on fp16-rounded data)."""
+def emulate(cfg, x, w, bias, S=1, flip=False, k133=False):
+    """x (N,C,D,H,W), w (M,C,3,3,3) -> y (N,M,D,H,W) the way the kernel computes it (fp32 math on fp16-rounded data).
+    k133 (the KY = 1, GS instances): w is (M,C,1,3,3); the column walk runs along H, the footprint spans (D, W): the tensors stay in
+    their dense NDHWC order and every access goes through the element strides the host sets up (lnn_conv_k133_on_v9)."""
     K = cfg
     N, C, Dz, H, W = x.shape
     M = w.shape[0]
     assert C == 16 * K.NCK and M % (32 * K.NMB) == 0
-    xcl = x.permute(0, 2, 3, 4, 1).contiguous().numpy()            # NDHWC
-    y = np.full((N, Dz, H, W, M), np.nan, dtype=np.float32)
+    xflat = x.permute(0, 2, 3, 4, 1).contiguous().numpy().reshape(-1)            # NDHWC, flat
+    yflat = np.full(N * Dz * H * W * M, np.nan, dtype=np.float32)
+    if k133:
+        # walk = H, footprint rows = D, footprint columns = W: strides of {walk, row, column}, of a sample
+        gs_in, gs_in_n = (W * C, H * W * C, C), Dz * H * W * C
+        gs_out, gs_out_n = (W * M, H * W * M, M), Dz * H * W * M
+        Dz, H = H, Dz                                                              # extents of the walk / footprint-row axes
+    else:
+        gs_in, gs_in_n = (H * W * C, W * C, C), Dz * H * W * C
+        gs_out, gs_out_n = (H * W * M, W * M, M), Dz * H * W * M
     wn = w.numpy()
     tiles_y, tiles_x = -(-H // K.FY), -(-W // K.FX)
     L = -(-Dz // S)
@@ -68,11 +78,14 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
             # A[tap][row rho][k 0..15]: row rho <-> channel m0 + ((rho + 8 QN ck) & 31)
             A = np.zeros((27, 32, 16), np.float32)
             for tl in range(27):
+                if k133 and (tl % 9) // 3 != 1:
+                    continue                                # 9 resident fragments: the centre row of the in-plane shifts
                 slot = 26 - tl if flip else tl
                 dz, dy, dx = slot // 9, (slot // 3) % 3, slot % 3
                 for rho in range(32):
                     ch = m0 + ((rho + (8 * K.QN * ck if ck < K.NFIN else 0)) & 31)
-                    A[tl, rho] = wn[ch, 16 * ck:16 * ck + 16, dz, dy, dx]
+                    # k133: the walk's plane shift is ky, its column shift kx (panel slot dz * 3 + dx of a 9-tap panel)
+                    A[tl, rho] = wn[ch, 16 * ck:16 * ck + 16, 0, dz, dx] if k133 else wn[ch, 16 * ck:16 * ck + 16, dz, dy, dx]
             st["A"] = A
             waves.append(st)
 
@@ -91,10 +104,13 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
                         piece = pc ^ key
                         iy, ix = y0 - 1 + py, x0 - 1 + pxs
                         ok = zok and py < K.PY and pxs < K.PX and 0 <= iy < H and 0 <= ix < W
+                        if k133 and not (1 <= py < K.PY - 1):
+                            ok = False                      # the footprint's halo rows are never read: not fetched
                         dst = (slot * K.PLANE + j * 1024 + lane * 16) // 2
                         if ok:
                             c0 = 32 * gg + piece * 8
-                            lds[dst:dst + 8] = xcl[n, zi, iy, ix, c0:c0 + 8]
+                            src = n * gs_in_n + zi * gs_in[0] + iy * gs_in[1] + ix * gs_in[2] + c0
+                            lds[dst:dst + 8] = xflat[src:src + 8]
                         else:
                             lds[dst:dst + 8] = 0.0
 
@@ -145,10 +161,12 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
                             lo = fin[8:12, v]; hi = fin[12:16, v]
                         ch = st["m0"] + 16 * ck + 8 * hk
                         vals = np.concatenate([lo, hi])
-                        y[n, o, oy, ox, ch:ch + 8] = vals + bias[ch:ch + 8]
+                        dsto = n * gs_out_n + o * gs_out[0] + oy * gs_out[1] + ox * gs_out[2] + ch
+                        yflat[dsto:dsto + 8] = vals + bias[ch:ch + 8]
                     else:
                         ch = st["m0"] + 8 * ck + 4 * hk
-                        y[n, o, oy, ox, ch:ch + 4] = fin[4 * hk:4 * hk + 4, v] + bias[ch:ch + 4]
+                        dsto = n * gs_out_n + o * gs_out[0] + oy * gs_out[1] + ox * gs_out[2] + ch
+                        yflat[dsto:dsto + 4] = fin[4 * hk:4 * hk + 4, v] + bias[ch:ch + 4]
 
         T3 = (T + 1 + 2) // 3 * 3
         for tp in range(K.D):
@@ -160,12 +178,14 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
             finalize(t - 1)
             dma(dtp, dtp % K.R); dtp += 1
             slot = t % K.R
+            i0, ni = (3, 3) if k133 else (0, 9)
             for st in waves:
-                for i in range(9):
+                for j in range(ni):
+                    i = i0 + j
                     B = bfrag(st, slot, i)
                     for dz in range(3):
                         a = (U + 1 - dz + 3) % 3
-                        if i == 0 and dz == 0:
+                        if j == 0 and dz == 0:
                             st["acc"][a][:] = 0
                         st["acc"][a] += st["A"][dz * 9 + i] @ B
             # publish
@@ -185,7 +205,8 @@ def emulate(cfg, x, w, bias, S=1, flip=False):
                     for lane in range(64):
                         hk, v = lane >> 5, lane & 31
                         blk[lane] = st["acc"][c][8 * a + 4 * hk:8 * a + 4 * hk + 4, v]
-    return torch.from_numpy(y).permute(0, 4, 1, 2, 3)
+    dd, hh = (H, Dz) if k133 else (Dz, H)              # back to the tensor's own (D, H)
+    return torch.from_numpy(yflat.reshape(N, dd, hh, W, M)).permute(0, 4, 1, 2, 3)
 
 
 def main():
@@ -203,6 +224,19 @@ def main():
             err = float((got - ref).abs().max())
             nan = int(torch.isnan(got).sum())
             print(f"cfg {cfg} {C}->{M} @{D}x{H}x{W} S={S}: max err {err:.2e}  unwritten {nan}")
+            bad += err > 1e-3 or nan > 0
+    # [1,3,3] convolutions: the walk along H with permuted axes (KY = 1, GS instances), forward and flipped (data gradient) taps
+    for cfg, (N, C, M, D, H, W) in [((2, 1, 4), (1, 32, 32, 5, 7, 18)), ((4, 2, 1), (2, 64, 64, 3, 9, 9)), ((8, 1, 1), (1, 128, 32, 6, 5, 10))]:
+        x = torch.randn(N, C, D, H, W).half().float()
+        w = (torch.randn(M, C, 1, 3, 3) * 0.1).half().float()
+        b = torch.randn(M)
+        for flip in (False, True):
+            wr = w.flip(3, 4) if flip else w
+            ref = F.conv3d(x, wr, b, padding=(0, 1, 1))
+            got = emulate(Cfg(*cfg), x, w, b.numpy(), S=2, flip=flip, k133=True)
+            err = float((got - ref).abs().max())
+            nan = int(torch.isnan(got).sum())
+            print(f"cfg {cfg} k133 {C}->{M} @{D}x{H}x{W} flip={int(flip)}: max err {err:.2e}  unwritten {nan}")
             bad += err > 1e-3 or nan > 0
     sys.exit(1 if bad else 0)
 
